@@ -1,0 +1,217 @@
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+Imports the reference's ``model`` package through ``tools/oracle_shim.py``,
+loads seed-recipe weights (``slnlp.synth.make_weights`` -- pure numpy, so the
+fixtures store only the seed, never weights), runs forward / train steps with
+stock torch components exactly as skorch would (CrossEntropyLoss(ignore_index),
+clip_grad_norm_(0.5), SGD(momentum .9)) and stores inputs' recipe + outputs.
+Fixture ids follow SURVEY.md section 8c (G1..G7).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sign-language-nlp_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from oracle_shim import Vocab, import_reference_model  # noqa: E402
+from slnlp import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+TF_CASES = {
+    # name: Vs, Vt, E, H, N, F, B, S, min_len, train_steps
+    "tiny": dict(Vs=64, Vt=16, E=32, H=4, N=2, F=64, B=4, S=12, min_len=3, steps=5),
+    "cfg1": dict(Vs=3000, Vt=202, E=128, H=4, N=2, F=256, B=50, S=48, min_len=8, steps=5),
+    "cfg2": dict(Vs=3000, Vt=202, E=512, H=8, N=6, F=512, B=50, S=48, min_len=8, steps=1),
+    "e1024": dict(Vs=3000, Vt=202, E=1024, H=4, N=2, F=128, B=50, S=48, min_len=8, steps=0),
+}
+RNN_CASES = {
+    "tiny": dict(Vs=64, Vt=16, E=24, Hd=32, N=2, B=4, S=12, min_len=3, steps=5),
+    "mid": dict(Vs=3000, Vt=202, E=128, Hd=256, N=2, B=50, S=48, min_len=8, steps=2),
+    "cfg3": dict(Vs=3000, Vt=202, E=512, Hd=512, N=4, B=50, S=48, min_len=8, steps=0),
+}
+LR, MOM, CLIP, PAD = 0.01, 0.9, 0.5, 1
+HEAD = 16  # leading elements of each tensor kept as a slice
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def summarize(named, prefix, out):
+    """Per-tensor L2 norm + leading HEAD elements: a compact but strong pin."""
+    names = sorted(named)
+    out[prefix + "_names"] = np.array(names)
+    out[prefix + "_norm"] = np.array(
+        [0.0 if named[k] is None else float(named[k].double().norm()) for k in names])
+    out[prefix + "_head"] = np.stack([
+        np.zeros(HEAD, np.float32) if named[k] is None else
+        np.pad(named[k].flatten()[:HEAD].numpy(), (0, max(0, HEAD - named[k].numel())))
+        for k in names]).astype(np.float32)
+    out[prefix + "_isnone"] = np.array([named[k] is None for k in names])
+
+
+def load_recipe(module, seed=1):
+    shapes = [(k, tuple(v.shape)) for k, v in module.state_dict().items()
+              if not k.endswith(".pe")]
+    w = synth.make_weights(shapes, seed=seed)
+    sd = module.state_dict()
+    for k, v in w.items():
+        sd[k] = t(v)
+    module.load_state_dict(sd)
+    return [k for k, _ in shapes]
+
+
+def train_steps(module, X, y, lengths, steps, out):
+    module.train()
+    opt = torch.optim.SGD(module.parameters(), lr=LR, momentum=MOM, nesterov=False)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=PAD)
+    losses, norms = [], []
+    for s in range(steps):
+        opt.zero_grad()
+        logp = module(X=X, y=y, lengths=lengths)
+        loss = crit(logp, y)
+        loss.backward()
+        if s == 0:
+            summarize({k: (None if p.grad is None else p.grad.detach().clone())
+                       for k, p in module.named_parameters()}, "grad0", out)
+        params = [p for p in module.parameters() if p.grad is not None]
+        norms.append(float(torch.nn.utils.clip_grad_norm_(params, CLIP)))
+        opt.step()
+        losses.append(float(loss))
+    out["losses"] = np.array(losses, np.float64)
+    out["grad_norms"] = np.array(norms, np.float64)
+    summarize({k: p.detach().clone() for k, p in module.named_parameters()},
+              "wfinal", out)
+
+
+def gen_transformer(model, name, c):
+    torch.manual_seed(0)
+    m = model.Transformer(embedding_size=c["E"], num_heads=c["H"], num_layers=c["N"],
+                          hidden_size=c["F"], dropout=0.0, src_vocab=Vocab(c["Vs"]),
+                          tgt_vocab=Vocab(c["Vt"]), device=torch.device("cpu"),
+                          batch_first=True)
+    m = m.to(torch.device("cpu"))
+    order = load_recipe(m)
+    Xn, Ln, yn = synth.make_batch(c["B"], c["S"], c["Vs"], c["Vt"], seed=1, min_len=c["min_len"])
+    X, L, y = t(Xn), t(Ln), t(yn)
+    out = {"cfg": np.array([c[k] for k in ("Vs", "Vt", "E", "H", "N", "F", "B", "S", "min_len")]),
+           "param_order": np.array(order), "lr_mom_clip": np.array([LR, MOM, CLIP])}
+    m.eval()
+    taps = {}
+    hooks = []
+    if name == "tiny":
+        def grab(key):
+            return lambda mod, i, o: taps.__setitem__(key, o.detach().clone())
+        hooks.append(m.src_pos_encoding.register_forward_hook(grab("src_embed")))
+        hooks.append(m.tgt_pos_encoding.register_forward_hook(grab("tgt_embed")))
+        for i, l in enumerate(m.transformer.encoder.layers):
+            hooks.append(l.register_forward_hook(grab(f"enc{i}")))
+        hooks.append(m.transformer.encoder.register_forward_hook(grab("memory")))
+        for i, l in enumerate(m.transformer.decoder.layers):
+            hooks.append(l.register_forward_hook(grab(f"dec{i}")))
+        hooks.append(m.linear.register_forward_hook(grab("logits")))
+    with torch.no_grad():
+        logp = m(X=X, y=y, lengths=L)
+    for h in hooks:
+        h.remove()
+    out["logp"] = logp.numpy()
+    out["argmax"] = logp.argmax(-1).numpy()
+    for k, v in taps.items():
+        out["tap_" + k] = v.numpy()
+    if name == "tiny":
+        # G7 behaviour pins (SURVEY.md section 3.4 quirk list)
+        with torch.no_grad():
+            y2 = y.clone(); y2[1] = (y2[1] - 2 + 1) % (c["Vt"] - 2) + 2
+            out["pin_y_changed"] = m(X=X, y=y2, lengths=L).numpy()       # row-local y dependence
+            X2 = X.clone(); X2[:, 5] = (X2[:, 5] - 2 + 7) % (c["Vs"] - 2) + 2
+            taps2 = {}
+            h = m.transformer.encoder.layers[-1].register_forward_hook(
+                lambda mod, i, o: taps2.__setitem__("enc", o.detach().clone()))
+            m(X=X2, y=y, lengths=L); h.remove()
+            out["pin_causal_enc_last"] = taps2["enc"].numpy()             # positions <5 unchanged
+    if c["steps"]:
+        train_steps(m, X, y, L, c["steps"], out)
+    np.savez_compressed(os.path.join(OUT, f"tf_{name}.npz"), **out)
+    print("tf", name, "logp[0,:3]", out["logp"][0, :3], "losses", out.get("losses"))
+
+
+def gen_rnn(model, rnn_type, name, c):
+    torch.manual_seed(0)
+    cls = model.EncoderDecoderLSTMAttn if rnn_type == "lstm" else model.EncoderDecoderGRUAttn
+    m = cls(src_vocab=Vocab(c["Vs"]), tgt_vocab=Vocab(c["Vt"]), batch_first=True,
+            embedding_size=c["E"], hidden_size=c["Hd"], num_layers=c["N"], dropout=0.0)
+    m = m.to(torch.device("cpu"))
+    order = load_recipe(m)
+    Xn, Ln, yn = synth.make_batch(c["B"], c["S"], c["Vs"], c["Vt"], seed=1, min_len=c["min_len"])
+    X, L, y = t(Xn), t(Ln), t(yn)
+    out = {"cfg": np.array([c[k] for k in ("Vs", "Vt", "E", "Hd", "N", "B", "S", "min_len")]),
+           "param_order": np.array(order), "lr_mom_clip": np.array([LR, MOM, CLIP])}
+    m.eval()
+    taps = {}
+    hooks = [m.model.encoder.register_forward_hook(
+        lambda mod, i, o: taps.update(enc_out=o[0].detach().clone(), enc_final=o[1].detach().clone())),
+        m.model.decoder.attention.register_forward_hook(
+        lambda mod, i, o: taps.update(context=o[0].detach().clone(), alphas=o[1].detach().clone()))]
+    with torch.no_grad():
+        logp = m(X=X, y=y, lengths=L)
+    for h in hooks:
+        h.remove()
+    out["logp"] = logp.numpy()
+    out["argmax"] = logp.argmax(-1).numpy()
+    if name == "tiny":
+        for k, v in taps.items():
+            out["tap_" + k] = v.numpy()
+    else:  # keep fixtures small: first 8 batch rows of the big taps
+        out["tap_enc_final"] = taps["enc_final"][:, :8].numpy()
+        out["tap_alphas"] = taps["alphas"].numpy()
+        out["tap_context"] = taps["context"][:8].numpy()
+    if name == "tiny":
+        with torch.no_grad():
+            y2 = (y - 2 + 3) % (c["Vt"] - 2) + 2
+            out["pin_y_changed"] = m(X=X, y=y2, lengths=L).numpy()        # independent of y
+    if c["steps"]:
+        train_steps(m, X, y, L, c["steps"], out)
+    np.savez_compressed(os.path.join(OUT, f"rnn_{rnn_type}_{name}.npz"), **out)
+    print("rnn", rnn_type, name, "logp[0,:3]", out["logp"][0, :3], "losses", out.get("losses"))
+
+
+def gen_masks_pe(model):
+    from model.util import generate_mask, generate_padding_mask
+    from model.component import PositionalEncoding
+    Xn, _, _ = synth.make_batch(50, 48, 3000, 202, seed=1)
+    src = t(Xn).transpose(0, 1)
+    out = {"mask1": generate_mask(torch.zeros(1, 50, dtype=torch.long)).numpy(),
+           "mask48": generate_mask(src).numpy(),
+           "padmask": generate_padding_mask(src, Vocab(3000)).numpy()}
+    rows = [0, 1, 2, 47, 63]
+    out["pe_rows"] = np.array(rows)
+    for E in (128, 512, 1024):
+        pe = PositionalEncoding(d_model=E, dropout=0.0).pe[:, 0, :]
+        out[f"pe{E}"] = (pe[:64] if E == 128 else pe[rows]).numpy()
+    np.savez_compressed(os.path.join(OUT, "masks_pe.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    model = import_reference_model()
+    torch.set_num_threads(8)
+    gen_masks_pe(model)
+    for name, c in TF_CASES.items():
+        gen_transformer(model, name, c)
+    for rnn_type in ("lstm", "gru"):
+        for name, c in RNN_CASES.items():
+            if name == "cfg3" and rnn_type == "gru":
+                continue
+            gen_rnn(model, rnn_type, name, c)
+
+
+if __name__ == "__main__":
+    main()
