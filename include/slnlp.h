@@ -1,0 +1,225 @@
+/* slnlp.h -- C ABI of libslnlp.so, the MI355X (gfx950) hot path for
+ * amorim-cleison/sign-language-nlp.
+ *
+ * The reference has no native code and no FFI: its hot path is the Python
+ * call `module(**{"X","lengths","y"})` + criterion + backward + clip + SGD that
+ * skorch issues per batch.  The entry points below are
+ * what a binding for that path attaches to; each cites the reference interface
+ * it replaces as /root/reference/<file>:<line>.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer
+ *    into memory the caller owns (the library never allocates or frees
+ *    persistent memory); `stream` is a hipStream_t passed as void*;
+ *  - all floating-point tensors are fp32 row-major; token ids / labels /
+ *    lengths are int64 exactly as `collate_data` builds them (helper.py:293-304);
+ *  - activations are sequence-first like the reference: token row m = s*B + b;
+ *  - return 0 on success, an SLNLP_ERR_* code otherwise (never aborts);
+ *    `slnlp_last_error()` returns a thread-local message;
+ *  - every launch is asynchronous on `stream` and hipGraph-capturable (no
+ *    allocation, no synchronisation inside).
+ */
+#ifndef SLNLP_H
+#define SLNLP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLNLP_OK 0
+#define SLNLP_ERR_INVALID_ARG 1
+#define SLNLP_ERR_LAUNCH 2
+#define SLNLP_ERR_UNSUPPORTED 3
+
+#define SLNLP_ABI_VERSION 1
+
+const char* slnlp_last_error(void);
+int slnlp_abi_version(void);
+
+/* ------------------------------------------------------------------ GEMM --
+ * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ) on bf16 MFMA with fp32
+ * accumulate.  Replaces every torch.nn.Linear / in_proj / out_proj matmul the
+ * reference reaches through nn.Transformer (model/transformer.py:40-48,82-88)
+ * and nn.LSTM/GRU/Linear (model/base/encoder_decoder_attn_bkp.py:95-100,
+ * 186-200,297-299), and their autograd backward (dgrad / wgrad).
+ *
+ * Operand (i,k) lives at ptr + i*ld + k when *_kmajor, else at ptr + k*ld + i.
+ *   forward   y = x W^T      : A=x   kmajor, B=W  kmajor
+ *   dgrad     dx = dy W      : A=dy  kmajor, B=W  NOT kmajor (k = W row)
+ *   wgrad     dW = dy^T x    : A=dy  NOT kmajor, B=x NOT kmajor (k = token)
+ * precision: 1 = single bf16 pass (~5e-3 rel); 3 = split-bf16 hi/lo, three MFMA
+ * passes (~2e-5 rel, the parity-grade default).
+ * Epilogue order: +bias[n] -> relu -> *gate -> dropout -> +resid.
+ */
+typedef struct slnlp_gemm_args {
+    const float* A; int64_t lda; int32_t a_kmajor;
+    const float* B; int64_t ldb; int32_t b_kmajor;
+    float* C; int64_t ldc;
+    int32_t M, N, K;
+    const float* bias;            /* [N] or NULL */
+    int32_t relu;                 /* max(x,0) after bias */
+    const float* gate; int64_t ldg; float gate_scale; /* C *= gate>0 ? gate_scale : 0 (ReLU+dropout backward) */
+    float drop_p; int32_t drop_site; const unsigned long long* rng; /* inverted dropout, mask regenerated from rng */
+    const float* resid; int64_t ldr; /* added last; may alias C */
+    float* rowsum_a;              /* [M] or NULL: sum_k A(m,k) (bias grad fused into wgrad) */
+    int32_t precision;            /* 1 or 3 */
+} slnlp_gemm_args;
+
+int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------- embedding --
+ * x[s*B+b, :] = table[ids[b,s], :] * sqrt(E) + pe[s, :], then dropout.
+ * model/transformer.py:106-109 forward_embedding; positional_encoding.py:48-49.
+ * ids is batch-first int64 [B,S] with row stride ld_ids (for y: S=1). */
+int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V,
+                    const float* table, const float* pe, float* out,
+                    float drop_p, int drop_site, const unsigned long long* rng,
+                    int64_t nan_idx /* id whose rows become NaN (decoder <pad> target), or -1 */, void* stream);
+/* dtable[v,:] = sqrt(E) * sum_{tokens with id v} dropout_bwd(dx[token,:]);
+ * rows with no token are zeroed.  Deterministic (fixed token order). */
+int slnlp_embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V,
+                    const float* dx, float* dtable,
+                    float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+
+/* -------------------------------------------------------- self attention --
+ * Encoder self-attention core for one layer, all (b,h) pairs: scores =
+ * q k^T / sqrt(dh), blocked where key j > query i (causal, transformer.py:68 /
+ * util.py:11-42) or ids[b,j] == pad (util.py:45-61), softmax, dropout, @ v.
+ * qkv [S*B, 3E] is the in_proj output (q | k | v); ctx [S*B, E]; probs
+ * [B,H,S,S] keeps the pre-dropout softmax for backward.  Requires S <= 64. */
+int slnlp_attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx,
+                        int causal, int B, int S, int H, int dh,
+                        float* ctx, float* probs,
+                        float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+int slnlp_attn_self_bwd(const float* qkv, const float* probs, const float* dctx,
+                        int B, int S, int H, int dh, float* dqkv,
+                        float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+
+/* Decoder cross-attention with ONE query per sequence (tgt length 1) over S
+ * memory positions, no masks (transformer.py:82-87 passes neither memory_mask
+ * nor memory_key_padding_mask).  q [B,E]; kv rows m = s*B+b with row stride
+ * ld_kv, k at column 0 and v at column E; probs [B,H,S]. */
+int slnlp_attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh,
+                         float* ctx, float* probs,
+                         float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+int slnlp_attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs,
+                         const float* dctx, int B, int S, int H, int dh,
+                         float* dq, float* dkv, int64_t ld_dkv,
+                         float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+
+/* -------------------------------------------------------------- layernorm --
+ * y = (x - mean) * rstd * gamma + beta, eps added to the biased variance
+ * (torch.nn.LayerNorm as used by nn.Transformer, eps 1e-5).  stats [rows,2] =
+ * (mean, rstd) kept for backward.  The residual add is fused into the GEMM
+ * that produced x. */
+int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E,
+                        float eps, float* y, float* stats, void* stream);
+/* dx (+ optional add_to_dx [rows,E]) ; dx_drop (optional) = dropout_bwd(dx) at
+ * drop_site for the sub-layer branch; partial [nblk,2,E] per-block partial
+ * (dgamma, dbeta) sums, reduced later by slnlp_ln_param_reduce. nblk is
+ * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS). */
+#define SLNLP_LN_MAX_PARTIALS 64
+int slnlp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
+                        int rows, int E, const float* add_to_dx, float* dx, float* dx_drop,
+                        float drop_p, int drop_site, const unsigned long long* rng,
+                        float* partial, int* nblk_out, void* stream);
+/* table: n entries of {partial ptr, nblk, dgamma ptr, dbeta ptr} in DEVICE memory */
+typedef struct slnlp_ln_reduce_entry {
+    const float* partial; float* dgamma; float* dbeta; int32_t nblk; int32_t E;
+} slnlp_ln_reduce_entry;
+int slnlp_ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, void* stream);
+
+/* ------------------------------------------------------------------ loss --
+ * logp = log_softmax(logits) (transformer.py:88-89 / bkp.py:75-76) and
+ * CrossEntropyLoss(ignore_index) ON THE LOG-PROBS as skorch applies it
+ * (helper.py:61-70): loss = -mean_{y!=ignore} log_softmax(logp)[y].
+ * Writes logp [B,V] (ld = V), loss[0], and (if dlogits) d loss / d logits. */
+int slnlp_lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V,
+                  int64_t ignore_index, float* logp, float* loss, float* dlogits, int64_t ld_dlogits,
+                  void* stream);
+/* backward of log_softmax alone, for callers that own the criterion (torch
+ * autograd): dlogits = dlogp - exp(logp) * rowsum(dlogp). */
+int slnlp_lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits,
+                  int64_t ld_dlogits, void* stream);
+
+/* -------------------------------------------------------------- optimizer --
+ * clip_grad_norm_(max_norm, 2) + SGD(momentum, dampening 0, nesterov False,
+ * no weight decay) over ONE flat parameter arena (helper.py:227-229,
+ * config-transformer.yaml:19-20,40-43).  lr is read from device memory so a
+ * captured graph follows ReduceLROnPlateau.  norm_out[0] receives the pre-clip
+ * total norm; rng[1] (the dropout step counter) is incremented if rng != NULL. */
+int slnlp_clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
+                        const float* lr_dev, float momentum, float max_norm,
+                        float* partials /* [1024] scratch */, float* norm_out,
+                        unsigned long long* rng, void* stream);
+
+/* debug / test helper: materialise the keep mask (1.0 / 0.0) of a dropout site */
+int slnlp_dropout_mask(float* out, int R, int C, float p, int site,
+                       const unsigned long long* rng, void* stream);
+
+/* ------------------------------------------------------ Transformer plan --
+ * Whole-model drop-in for model.Transformer (model/transformer.py:10-109):
+ * the library owns the parameter-arena LAYOUT (names follow the reference
+ * state_dict), the activation workspace layout and the launch sequence. */
+typedef struct slnlp_tf_config {
+    int32_t E, H, N, F;          /* embedding_size, num_heads, num_layers, hidden_size */
+    int32_t Vs, Vt;              /* len(src_vocab), len(tgt_vocab) */
+    int32_t B, S;                /* max batch, sequence length (S <= 64) */
+    int32_t pad_src, pad_tgt;    /* vocab.stoi['<pad>'] (util.py:5-6) */
+    float dropout;
+    int32_t precision;           /* 1 | 3 */
+} slnlp_tf_config;
+
+int slnlp_tf_num_params(const slnlp_tf_config* cfg);
+/* i-th parameter in reference state_dict order: name (<=127 chars), shape, offset (floats) */
+int slnlp_tf_param_info(const slnlp_tf_config* cfg, int i, char* name, int64_t shape[2], int* ndim,
+                        int64_t* offset);
+int64_t slnlp_tf_arena_floats(const slnlp_tf_config* cfg);
+int64_t slnlp_tf_workspace_bytes(const slnlp_tf_config* cfg);
+
+typedef struct slnlp_tf_buffers {
+    float* params;               /* arena, slnlp_tf_arena_floats */
+    float* grads;                /* arena-shaped */
+    float* momentum;             /* arena-shaped */
+    const float* pe;             /* [>=S, E] positional table (positional_encoding.py:27-35) */
+    void* workspace;             /* slnlp_tf_workspace_bytes */
+    unsigned long long* rng;     /* [2] = {seed, step} */
+    float* lr;                   /* [1] */
+    float* scalars;              /* [4] = {loss, grad_norm, -, -} */
+} slnlp_tf_buffers;
+
+typedef struct slnlp_tf_plan slnlp_tf_plan;
+int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, slnlp_tf_plan** out);
+void slnlp_tf_destroy(slnlp_tf_plan* plan);
+/* forward: X int64 [B,S] (row stride S), y int64 [B] -> logp [B,Vt] (may be
+ * NULL).  Always evaluates the criterion too (scalars[0] = loss); train != 0
+ * applies dropout, keeps activations and seeds backward with d loss/d logits. */
+int slnlp_tf_forward(slnlp_tf_plan* plan, const int64_t* X, const int64_t* y, int B, int train,
+                     float* logp, void* stream);
+/* re-seed backward from an external d loss / d logp (torch autograd owns the criterion) */
+int slnlp_tf_seed_dlogp(slnlp_tf_plan* plan, const float* dlogp, void* stream);
+/* backward through the whole model into buf.grads (every element written) */
+int slnlp_tf_backward(slnlp_tf_plan* plan, void* stream);
+/* clip + SGD-momentum on the arena; scalars[1] = pre-clip grad norm */
+int slnlp_tf_optim(slnlp_tf_plan* plan, float momentum, float max_norm, void* stream);
+/* forward(train) + loss + backward + optim in one call */
+int slnlp_tf_train_step(slnlp_tf_plan* plan, const int64_t* X, const int64_t* y, int B,
+                        float momentum, float max_norm, float* logp, void* stream);
+/* Capture one train step over FIXED device buffers (X, y, logp) and batch size
+ * into a hipGraph kept inside the plan; slnlp_tf_graph_launch replays it.  lr,
+ * the dropout step counter and the data are read from device memory, so one
+ * captured graph serves every step of a fit. `stream` must not be the null
+ * stream. */
+int slnlp_tf_graph_capture_train(slnlp_tf_plan* plan, const int64_t* X, const int64_t* y, int B,
+                                 float momentum, float max_norm, float* logp, void* stream);
+int slnlp_tf_graph_launch(slnlp_tf_plan* plan, void* stream);
+/* test helper: copy a named activation tap ("enc0", "memory", "dec1", "logits", ...) */
+int slnlp_tf_tap(slnlp_tf_plan* plan, const char* name, float* out, int64_t max_floats,
+                 int64_t* n_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLNLP_H */

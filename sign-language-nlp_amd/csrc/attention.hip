@@ -1,0 +1,453 @@
+// attention.hip -- attention cores for the short (S <= 64) ASL-Phono sequences.
+//
+// Self-attention (encoder; /root/reference/model/transformer.py:68-73,82-87 ->
+// nn.MultiheadAttention slow path): one workgroup per (batch, head); the whole
+// S x S score tile lives in LDS, Q/K/V/dO are streamed through LDS in
+// head-dim chunks of <= 64 so any head_dim in {16..256} of the reference grid
+// (config-transformer.yaml:49,53) fits.  Exact fp32 arithmetic: attention is
+// ~3 % of the step's FLOPs (4SE vs 8E^2+4EF per token), the projections
+// around it run on MFMA (gemm.hip).
+//
+// Cross-attention (decoder, tgt length 1, no masks): one wave per (batch, head).
+#include "common.hpp"
+
+namespace slnlp {
+
+constexpr int SMAX = 64;   // max sequence length held in one tile
+constexpr int DCH = 64;    // head-dim chunk
+constexpr int TLD = 68;    // LDS row stride (floats): 16-B aligned rows, conflict-free b128 column access
+
+// load rows [0,S) x cols [d0, d0+dc) of a [S*B, ld] token-major matrix (row m = s*B+b) into T; zero-fill the rest
+__device__ __forceinline__ void load_chunk(float* __restrict__ T, const float* __restrict__ src, long ld,
+                                           int B, int b, int S, int col0, int dc, int tid) {
+    for (int idx = tid; idx < SMAX * (DCH / 4); idx += 256) {
+        int s = idx / (DCH / 4), c = (idx % (DCH / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < S && c < dc) v = *reinterpret_cast<const float4*>(src + ((long)s * B + b) * ld + col0 + c);
+        *reinterpret_cast<float4*>(T + s * TLD + c) = v;
+    }
+}
+
+// acc[r][c] += sum_d X[ti+16r][d] * Y[tj+16c][d]
+__device__ __forceinline__ void dot_tiles(const float* __restrict__ X, const float* __restrict__ Y, int dc,
+                                          int ti, int tj, float (&acc)[4][4]) {
+    for (int d = 0; d < dc; d += 4) {
+        float4 x[4], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const float4*>(X + (ti + 16 * r) * TLD + d);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = *reinterpret_cast<const float4*>(Y + (tj + 16 * c) * TLD + d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[r][c] += x[r].x * y[c].x + x[r].y * y[c].y + x[r].z * y[c].z + x[r].w * y[c].w;
+    }
+}
+
+// out[r] (float4 over d = td*4..) = sum_j W[ti+16r][j] * V[j][d]      (W row-major S x S, j < Sp)
+__device__ __forceinline__ void rows_times_tile(const float* __restrict__ W, const float* __restrict__ V, int Sp,
+                                                int ti, int td, float4 (&o)[4]) {
+    for (int j = 0; j < Sp; j += 4) {
+        float4 w[4], v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const float4*>(W + (ti + 16 * r) * TLD + j);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v[jj] = *reinterpret_cast<const float4*>(V + (j + jj) * TLD + td * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ww[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                o[r].x += ww[jj] * v[jj].x; o[r].y += ww[jj] * v[jj].y;
+                o[r].z += ww[jj] * v[jj].z; o[r].w += ww[jj] * v[jj].w;
+            }
+        }
+    }
+}
+
+// out[r] (float4 over d) = sum_i W[i][tj+16r] * X[i][d]        (transposed use of W; i < S)
+__device__ __forceinline__ void cols_times_tile(const float* __restrict__ W, const float* __restrict__ X, int S,
+                                                int tj, int td, float4 (&o)[4]) {
+    for (int i = 0; i < S; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(X + i * TLD + td * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float w = W[i * TLD + tj + 16 * r];
+            o[r].x += w * x.x; o[r].y += w * x.y; o[r].z += w * x.z; o[r].w += w * x.w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_self_fwd_kernel(
+    const float* __restrict__ qkv, const long* __restrict__ ids, long ld_ids, long pad_idx, int causal, int B,
+    int S, int H, int dh, float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr,
+    int drop_site, const unsigned long long* __restrict__ rng) {
+    __shared__ __attribute__((aligned(16))) float Qs[SMAX * TLD];
+    __shared__ __attribute__((aligned(16))) float Ks[SMAX * TLD];
+    __shared__ __attribute__((aligned(16))) float Ps[SMAX * TLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = H * dh, ti = tid >> 4, tj = tid & 15;
+    const long ld = 3L * E;
+    const int dc_full = dh < DCH ? dh : DCH;
+
+    float acc[4][4] = {};
+    for (int d0 = 0; d0 < dh; d0 += DCH) {
+        __syncthreads();
+        load_chunk(Qs, qkv, ld, B, b, S, h * dh + d0, dc_full, tid);
+        load_chunk(Ks, qkv, ld, B, b, S, E + h * dh + d0, dc_full, tid);
+        __syncthreads();
+        dot_tiles(Qs, Ks, dc_full, ti, tj, acc);
+    }
+    const float scale = rsqrtf((float)dh);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ti + 16 * r, j = tj + 16 * c;
+            float v = acc[r][c] * scale;
+            bool blocked = (j >= S) || (causal && j > i);
+            if (!blocked && ids) blocked = ids[(long)b * ld_ids + j] == pad_idx;
+            Ps[i * TLD + j] = blocked ? -INFINITY : v;
+        }
+    __syncthreads();
+    // softmax: one wave per row, one key per lane (S <= 64)
+    const float inv_keep = 1.f / (1.f - drop_p);
+    for (int i = wave; i < SMAX; i += 4) {
+        float p = 0.f;
+        if (i < S) {
+            const float v = Ps[i * TLD + lane];  // -inf for lane >= S
+            const float m = wave_max(v);
+            const float e = expf(v - m);       // all-masked row: (-inf) - (-inf) = NaN, as torch
+            const float sum = wave_sum(e);
+            p = e / sum;
+            if (lane < S) {
+                const long row = ((long)b * H + h) * S + i;
+                probs[row * S + lane] = p;
+                if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)row, (unsigned)lane, drop_thr) ? p * inv_keep : 0.f;
+            } else {
+                p = 0.f;
+            }
+        }
+        Ps[i * TLD + lane] = p;
+    }
+    // ctx = P_dropped @ V, chunk by chunk
+    const int Sp = (S + 3) & ~3, td = tid & 15;
+    for (int d0 = 0; d0 < dh; d0 += DCH) {
+        __syncthreads();
+        load_chunk(Ks, qkv, ld, B, b, S, 2 * E + h * dh + d0, dc_full, tid);
+        __syncthreads();
+        float4 o[4] = {};
+        if (td * 4 < dc_full) {
+            rows_times_tile(Ps, Ks, Sp, ti, td, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti + 16 * r;
+                if (i < S) *reinterpret_cast<float4*>(ctx + ((long)i * B + b) * E + h * dh + d0 + td * 4) = o[r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_self_bwd_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dctx, int B, int S,
+    int H, int dh, float* __restrict__ dqkv, float drop_p, unsigned drop_thr, int drop_site,
+    const unsigned long long* __restrict__ rng) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ta = smem;                 // dO chunk / Q chunk
+    float* Tb = Ta + SMAX * TLD;      // V chunk / K chunk
+    float* Tc = Tb + SMAX * TLD;      // dP scratch / dO chunk
+    float* Ps = Tc + SMAX * TLD;      // P -> dS
+    float* Pd = Ps + SMAX * TLD;      // dropped P
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = H * dh, ti = tid >> 4, tj = tid & 15, td = tid & 15;
+    const long ld = 3L * E;
+    const int dc_full = dh < DCH ? dh : DCH;
+    const float inv_keep = 1.f / (1.f - drop_p);
+
+    // pass 1: dPd = dO V^T
+    float acc[4][4] = {};
+    for (int d0 = 0; d0 < dh; d0 += DCH) {
+        __syncthreads();
+        load_chunk(Ta, dctx, E, B, b, S, h * dh + d0, dc_full, tid);
+        load_chunk(Tb, qkv, ld, B, b, S, 2 * E + h * dh + d0, dc_full, tid);
+        __syncthreads();
+        dot_tiles(Ta, Tb, dc_full, ti, tj, acc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Tc[(ti + 16 * r) * TLD + tj + 16 * c] = acc[r][c];
+    __syncthreads();
+    // softmax backward per row; Ps <- dS * scale, Pd <- dropped P
+    const float scale = rsqrtf((float)dh);
+    for (int i = wave; i < SMAX; i += 4) {
+        float ds = 0.f, pd = 0.f;
+        if (i < S) {
+            const long row = ((long)b * H + h) * S + i;
+            float p = 0.f, dp = 0.f;
+            if (lane < S) {
+                p = probs[row * S + lane];
+                dp = Tc[i * TLD + lane];
+                pd = p;
+                if (drop_p > 0.f) {
+                    const bool keep = dropout_keep(rng, drop_site, (unsigned)row, (unsigned)lane, drop_thr);
+                    pd = keep ? p * inv_keep : 0.f;
+                    dp = keep ? dp * inv_keep : 0.f;
+                }
+            }
+            const float s = wave_sum(dp * p);
+            ds = p * (dp - s) * scale;
+        }
+        Ps[i * TLD + lane] = ds;
+        Pd[i * TLD + lane] = pd;
+    }
+    // pass 2: dQ = dS K, dK = dS^T Q, dV = Pd^T dO
+    const int Sp = (S + 3) & ~3;
+    for (int d0 = 0; d0 < dh; d0 += DCH) {
+        __syncthreads();
+        load_chunk(Ta, qkv, ld, B, b, S, h * dh + d0, dc_full, tid);
+        load_chunk(Tb, qkv, ld, B, b, S, E + h * dh + d0, dc_full, tid);
+        load_chunk(Tc, dctx, E, B, b, S, h * dh + d0, dc_full, tid);
+        __syncthreads();
+        if (td * 4 < dc_full) {
+            float4 dq[4] = {}, dk[4] = {}, dv[4] = {};
+            rows_times_tile(Ps, Tb, Sp, ti, td, dq);
+            cols_times_tile(Ps, Ta, S, ti, td, dk);
+            cols_times_tile(Pd, Tc, S, ti, td, dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti + 16 * r;
+                if (i < S) {
+                    float* dst = dqkv + ((long)i * B + b) * ld + h * dh + d0 + td * 4;
+                    *reinterpret_cast<float4*>(dst) = dq[r];
+                    *reinterpret_cast<float4*>(dst + E) = dk[r];
+                    *reinterpret_cast<float4*>(dst + 2 * E) = dv[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cross ---
+constexpr int XDH = 256;  // max head dim
+
+__global__ __launch_bounds__(256) void attn_cross_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ kv, long ld_kv, int B, int S, int H, int dh,
+    float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr, int drop_site,
+    const unsigned long long* __restrict__ rng) {
+    __shared__ __attribute__((aligned(16))) float qs[4][XDH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh % H, E = H * dh;
+    for (int d = lane; d < dh; d += 64) qs[wave][d] = q[(long)b * E + h * dh + d];
+    __builtin_amdgcn_wave_barrier();
+    float sc = -INFINITY;
+    if (lane < S) {
+        const float* kr = kv + ((long)lane * B + b) * ld_kv + h * dh;
+        float a = 0.f;
+        for (int d = 0; d < dh; d += 4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kr + d);
+            const float4 q4 = *reinterpret_cast<const float4*>(&qs[wave][d]);
+            a += k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w;
+        }
+        sc = a * rsqrtf((float)dh);
+    }
+    const float m = wave_max(sc);
+    const float e = expf(sc - m);
+    const float p = e / wave_sum(e);
+    float pd = 0.f;
+    if (lane < S) {
+        probs[(long)bh * S + lane] = p;
+        pd = p;
+        if (drop_p > 0.f) pd = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)lane, drop_thr) ? p / (1.f - drop_p) : 0.f;
+    }
+    for (int d0 = 0; d0 < dh; d0 += 64) {  // wave-uniform trip count: __shfl needs every lane active
+        const int d = d0 + lane;
+        const bool act = d < dh;
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float pj = __shfl(pd, j, 64);
+            if (act) a += pj * kv[((long)j * B + b) * ld_kv + E + h * dh + d];
+        }
+        if (act) ctx[(long)b * E + h * dh + d] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ kv, long ld_kv, const float* __restrict__ probs,
+    const float* __restrict__ dctx, int B, int S, int H, int dh, float* __restrict__ dq, float* __restrict__ dkv,
+    long ld_dkv, float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* __restrict__ rng) {
+    __shared__ __attribute__((aligned(16))) float gs[4][XDH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh % H, E = H * dh;
+    for (int d = lane; d < dh; d += 64) gs[wave][d] = dctx[(long)b * E + h * dh + d];
+    __builtin_amdgcn_wave_barrier();
+    float p = 0.f, pd = 0.f, dp = 0.f;
+    if (lane < S) {
+        p = probs[(long)bh * S + lane];
+        const float* vr = kv + ((long)lane * B + b) * ld_kv + E + h * dh;
+        float a = 0.f;
+        for (int d = 0; d < dh; d += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(vr + d);
+            const float4 g4 = *reinterpret_cast<const float4*>(&gs[wave][d]);
+            a += v4.x * g4.x + v4.y * g4.y + v4.z * g4.z + v4.w * g4.w;
+        }
+        dp = a;
+        pd = p;
+        if (drop_p > 0.f) {
+            const bool keep = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)lane, drop_thr);
+            const float ik = 1.f / (1.f - drop_p);
+            pd = keep ? p * ik : 0.f;
+            dp = keep ? dp * ik : 0.f;
+        }
+    }
+    const float s = wave_sum(dp * p);
+    const float ds = p * (dp - s) * rsqrtf((float)dh);
+    for (int d0 = 0; d0 < dh; d0 += 64) {  // wave-uniform trip count: __shfl needs every lane active
+        const int d = d0 + lane;
+        const bool act = d < dh;
+        const float qd = act ? q[(long)b * E + h * dh + d] : 0.f, gd = act ? gs[wave][d] : 0.f;
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float dsj = __shfl(ds, j, 64), pdj = __shfl(pd, j, 64);
+            const long row = ((long)j * B + b);
+            if (act) {
+                a += dsj * kv[row * ld_kv + h * dh + d];
+                dkv[row * ld_dkv + h * dh + d] = dsj * qd;
+                dkv[row * ld_dkv + E + h * dh + d] = pdj * gd;
+            }
+        }
+        if (act) dq[(long)b * E + h * dh + d] = a;
+    }
+}
+
+// Decoder self-attention with a single key: softmax == 1, but in train mode
+// nn.MultiheadAttention still applies dropout to that weight, i.e. each
+// (row, head) slice of the value projection is scaled by keep/(1-p).
+// Site tensor is [rows*H, 1].  Self-inverse in backward (same mask on dv).
+__global__ void head_dropout_kernel(float* __restrict__ x, int rows, int H, int dh, float ik, unsigned thr, int site,
+                                    const unsigned long long* __restrict__ rng) {
+    const long total = (long)rows * H * dh;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned rh = (unsigned)(i / dh);
+        x[i] = dropout_keep(rng, site, rh, 0u, thr) ? x[i] * ik : 0.f;
+    }
+}
+
+int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site, const unsigned long long* rng,
+                 hipStream_t st) {
+    SLNLP_CHECK_ARG(x && rng && rows > 0 && H > 0 && dh > 0 && drop_p > 0.f && drop_p < 1.f, "head_dropout: bad args");
+    int grid = ceil_div((long)rows * H * dh, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(head_dropout_kernel, dim3(grid), dim3(256), 0, st, x, rows, H, dh, 1.f / (1.f - drop_p),
+                       dropout_threshold(drop_p), drop_site, rng);
+    SLNLP_CHECK_LAUNCH("head_dropout");
+    return 0;
+}
+
+constexpr size_t ATTN_BWD_LDS = 5 * SMAX * TLD * sizeof(float);  // 87 040 B of dynamic LDS (> 64 KiB default cap)
+
+// one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
+int attn_init() {
+    static int state = 0;  // 0 = not yet, 1 = ok
+    if (state == 1) return 0;
+    if (hipFuncSetAttribute((const void*)attn_self_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ATTN_BWD_LDS) != hipSuccess) {
+        set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    state = 1;
+    return 0;
+}
+
+static int check_attn(const char* who, int B, int S, int H, int dh) {
+    SLNLP_CHECK_ARG(B > 0 && H > 0, "%s: bad B=%d H=%d", who, B, H);
+    SLNLP_CHECK_ARG(S > 0 && S <= SMAX, "%s: S=%d outside 1..%d (single-tile kernel)", who, S, SMAX);
+    SLNLP_CHECK_ARG(dh > 0 && dh % 4 == 0 && dh <= XDH && (dh <= DCH || dh % DCH == 0),
+                    "%s: head_dim %d unsupported (need multiple of 4, <= %d, and a multiple of %d above it)", who,
+                    dh, XDH, DCH);
+    return 0;
+}
+
+int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
+                  int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
+                  const unsigned long long* rng, hipStream_t st) {
+    SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
+    SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
+    hipLaunchKernelGGL(attn_self_fwd_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
+                       (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site,
+                       rng);
+    SLNLP_CHECK_LAUNCH("attn_self_fwd");
+    return 0;
+}
+
+int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
+                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st) {
+    SLNLP_TRY(check_attn("attn_self_bwd", B, S, H, dh));
+    SLNLP_CHECK_ARG(qkv && probs && dctx && dqkv, "attn_self_bwd: null pointer");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
+    const size_t lds = ATTN_BWD_LDS;
+    SLNLP_TRY(attn_init());
+    hipLaunchKernelGGL(attn_self_bwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, probs, dctx, B, S, H, dh, dqkv,
+                       drop_p, dropout_threshold(drop_p), drop_site, rng);
+    SLNLP_CHECK_LAUNCH("attn_self_bwd");
+    return 0;
+}
+
+int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
+                   float* probs, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st) {
+    SLNLP_TRY(check_attn("attn_cross_fwd", B, S, H, dh));
+    SLNLP_CHECK_ARG(q && kv && ctx && probs, "attn_cross_fwd: null pointer");
+    SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh, "attn_cross_fwd: ld_kv=%ld", (long)ld_kv);
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_fwd: bad dropout args");
+    hipLaunchKernelGGL(attn_cross_fwd_kernel, dim3(ceil_div(B * H, 4)), dim3(256), 0, st, q, kv, (long)ld_kv, B, S, H,
+                       dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng);
+    SLNLP_CHECK_LAUNCH("attn_cross_fwd");
+    return 0;
+}
+
+int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
+                   int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
+                   const unsigned long long* rng, hipStream_t st) {
+    SLNLP_TRY(check_attn("attn_cross_bwd", B, S, H, dh));
+    SLNLP_CHECK_ARG(q && kv && probs && dctx && dq && dkv, "attn_cross_bwd: null pointer");
+    SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh && ld_dkv >= 2L * H * dh, "attn_cross_bwd: bad ld");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_bwd: bad dropout args");
+    hipLaunchKernelGGL(attn_cross_bwd_kernel, dim3(ceil_div(B * H, 4)), dim3(256), 0, st, q, kv, (long)ld_kv, probs,
+                       dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng);
+    SLNLP_CHECK_LAUNCH("attn_cross_bwd");
+    return 0;
+}
+
+}  // namespace slnlp
+
+extern "C" {
+int slnlp_attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B,
+                        int S, int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
+                        const unsigned long long* rng, void* stream) {
+    return slnlp::attn_self_fwd(qkv, ids, ld_ids, pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, drop_site, rng,
+                                (hipStream_t)stream);
+}
+int slnlp_attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh,
+                        float* dqkv, float drop_p, int drop_site, const unsigned long long* rng, void* stream) {
+    return slnlp::attn_self_bwd(qkv, probs, dctx, B, S, H, dh, dqkv, drop_p, drop_site, rng, (hipStream_t)stream);
+}
+int slnlp_attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
+                         float* probs, float drop_p, int drop_site, const unsigned long long* rng, void* stream) {
+    return slnlp::attn_cross_fwd(q, kv, ld_kv, B, S, H, dh, ctx, probs, drop_p, drop_site, rng, (hipStream_t)stream);
+}
+int slnlp_attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx,
+                         int B, int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p,
+                         int drop_site, const unsigned long long* rng, void* stream) {
+    return slnlp::attn_cross_bwd(q, kv, ld_kv, probs, dctx, B, S, H, dh, dq, dkv, ld_dkv, drop_p, drop_site, rng,
+                                 (hipStream_t)stream);
+}
+}

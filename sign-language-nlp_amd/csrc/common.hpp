@@ -1,0 +1,138 @@
+// Shared device/host helpers for the slnlp gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/slnlp.h"
+
+namespace slnlp {
+
+// ---------------------------------------------------------------- errors ----
+// Thread-local last-error string; entry points return a non-zero code and
+// never abort ("returns a code -- never aborts").
+void set_error(const char* fmt, ...);
+
+#define SLNLP_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            ::slnlp::set_error(__VA_ARGS__);       \
+            return SLNLP_ERR_INVALID_ARG;          \
+        }                                          \
+    } while (0)
+
+#define SLNLP_CHECK_LAUNCH(what)                                              \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            ::slnlp::set_error("%s: %s", what, hipGetErrorString(e__));       \
+            return SLNLP_ERR_LAUNCH;                                          \
+        }                                                                     \
+    } while (0)
+
+#define SLNLP_TRY(expr)            \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------- dropout ------
+// Counter-based Philox4x32-10.  A dropout site is a logical [R, C] tensor;
+// element (r, c) takes word (r & 3) of philox(counter = {c, r >> 2, site, 0},
+// key = {seed + step}).  One call therefore serves the 4 consecutive rows one
+// lane owns in a 16x16 MFMA accumulator column.  Masks are never stored: the
+// backward kernels regenerate them from (seed, step, site, r, c).
+struct RngState {
+    unsigned long long seed;
+    unsigned long long step;
+};
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const unsigned W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        unsigned hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        unsigned hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+
+__device__ __forceinline__ uint4 dropout_bits4(const unsigned long long* rng, int site,
+                                               unsigned r4, unsigned c) {
+    unsigned long long k = rng[0] + 0x9E3779B97F4A7C15ull * rng[1];
+    return philox4x32_10(make_uint4(c, r4, (unsigned)site, 0u),
+                         make_uint2((unsigned)k, (unsigned)(k >> 32)));
+}
+
+// keep-threshold: keep iff bits >= thr  (P[drop] = thr / 2^32 = p)
+__host__ __device__ __forceinline__ unsigned dropout_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}
+
+__device__ __forceinline__ unsigned pick_word(const uint4& v, int i) {
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// single-element form (non-MFMA kernels)
+__device__ __forceinline__ bool dropout_keep(const unsigned long long* rng, int site,
+                                             unsigned r, unsigned c, unsigned thr) {
+    uint4 b = dropout_bits4(rng, site, r >> 2, c);
+    return pick_word(b, r & 3) >= thr;
+}
+
+// ------------------------------------------------------------- wave ops -----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace slnlp
+
+// ------------------------------------------------- internal kernel launchers
+namespace slnlp {
+int gemm(const slnlp_gemm_args& a, hipStream_t s);
+int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
+              float* out, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx, hipStream_t st);
+int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
+              float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
+                  int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
+                  const unsigned long long* rng, hipStream_t st);
+int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
+                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
+                   float* probs, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
+                   int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
+                   const unsigned long long* rng, hipStream_t st);
+int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site, const unsigned long long* rng,
+                 hipStream_t st);
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
+                  float* stats, hipStream_t st);
+int ln_bwd_blocks(int rows);
+int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
+                  const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
+                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st);
+int attn_init();
+int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st);
+int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
+            float* loss, float* dlogits, int64_t ld_dlogits, hipStream_t st);
+int lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits, hipStream_t st);
+int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                  float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
+                  hipStream_t st);
+}  // namespace slnlp

@@ -1,0 +1,511 @@
+// elementwise.hip -- HBM-bound pieces of the step: embedding gather + positional
+// add, LayerNorm, log-softmax / NLL criterion, grad-norm clip + SGD-momentum.
+// All fp32, 16-B vector accesses, one wave per row for the row-wise reductions.
+#include "common.hpp"
+
+namespace slnlp {
+
+// ===================================================================== embed
+// /root/reference/model/transformer.py:106-109 + component/positional_encoding.py:48-49
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__ ids, long ld_ids, int B, int S,
+                                                        int E, int V, const float* __restrict__ table,
+                                                        const float* __restrict__ pe, float* __restrict__ out,
+                                                        float scale, float drop_p, unsigned drop_thr, int drop_site,
+                                                        const unsigned long long* __restrict__ rng, long nan_idx) {
+    const int e4 = E >> 2;
+    const long total = (long)B * S * e4;
+    const float ik = 1.f / (1.f - drop_p);
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / e4), c = (int)(idx % e4) * 4;
+        const int s = m / B, b = m % B;
+        const long id = ids[(long)b * ld_ids + s];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && id < V) v = *reinterpret_cast<const float4*>(table + id * E + c);
+        const float4 p = *reinterpret_cast<const float4*>(pe + (long)s * E + c);
+        v.x = v.x * scale + p.x; v.y = v.y * scale + p.y; v.z = v.z * scale + p.z; v.w = v.w * scale + p.w;
+        if (drop_p > 0.f) {
+            v.x = dropout_keep(rng, drop_site, m, c + 0, drop_thr) ? v.x * ik : 0.f;
+            v.y = dropout_keep(rng, drop_site, m, c + 1, drop_thr) ? v.y * ik : 0.f;
+            v.z = dropout_keep(rng, drop_site, m, c + 2, drop_thr) ? v.z * ik : 0.f;
+            v.w = dropout_keep(rng, drop_site, m, c + 3, drop_thr) ? v.w * ik : 0.f;
+        }
+        // decoder input token == <pad>: its single self-attention key is masked
+        // (transformer.py:72-73) -> softmax over an empty set -> NaN row in torch.
+        if (id == nan_idx) v = make_float4(NAN, NAN, NAN, NAN);
+        *reinterpret_cast<float4*>(out + (long)m * E + c) = v;
+    }
+}
+
+// One workgroup per token m.  The first occurrence of an id (no m' < m with the
+// same id) sums every occurrence m'' >= m in increasing order and writes the
+// table row: deterministic, no atomics.  Untouched rows were zeroed by a memset.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, long ld_ids, int B, int S,
+                                                        int E, int V, const float* __restrict__ dx,
+                                                        float* __restrict__ dtable, float scale, float drop_p,
+                                                        unsigned drop_thr, int drop_site,
+                                                        const unsigned long long* __restrict__ rng) {
+    __shared__ unsigned long long match[4];
+    const int m = blockIdx.x, M = B * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long id = ids[(long)(m % B) * ld_ids + (m / B)];
+    if (id < 0 || id >= V) return;
+    int dup = 0;
+    for (int mm = tid; mm < m; mm += 256) dup |= (ids[(long)(mm % B) * ld_ids + (mm / B)] == id);
+    if (__syncthreads_or(dup)) return;
+    const float ik = 1.f / (1.f - drop_p);
+    for (int c0 = 0; c0 < E; c0 += 1024) {
+        const int c = c0 + tid * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = m; base < M; base += 256) {
+            const int mm = base + tid;
+            const bool hit = mm < M && ids[(long)(mm % B) * ld_ids + (mm / B)] == id;
+            const unsigned long long bal = __ballot(hit);
+            __syncthreads();
+            if (lane == 0) match[wave] = bal;
+            __syncthreads();
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long bits = match[w];
+                while (bits) {
+                    const int k = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const int t = base + w * 64 + k;
+                    if (c < E) {
+                        float4 g = *reinterpret_cast<const float4*>(dx + (long)t * E + c);
+                        if (drop_p > 0.f) {
+                            g.x = dropout_keep(rng, drop_site, t, c + 0, drop_thr) ? g.x * ik : 0.f;
+                            g.y = dropout_keep(rng, drop_site, t, c + 1, drop_thr) ? g.y * ik : 0.f;
+                            g.z = dropout_keep(rng, drop_site, t, c + 2, drop_thr) ? g.z * ik : 0.f;
+                            g.w = dropout_keep(rng, drop_site, t, c + 3, drop_thr) ? g.w * ik : 0.f;
+                        }
+                        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+                    }
+                }
+            }
+        }
+        if (c < E) {
+            acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+            *reinterpret_cast<float4*>(dtable + id * E + c) = acc;
+        }
+    }
+}
+
+int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
+              float* out, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx, hipStream_t st) {
+    SLNLP_CHECK_ARG(ids && table && pe && out, "embed_fwd: null pointer");
+    SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_fwd: bad shape B=%d S=%d E=%d V=%d", B, S, E, V);
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_fwd: bad dropout args");
+    const long total = (long)B * S * (E / 4);
+    int grid = ceil_div(total, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V,
+                       table, pe, out, sqrtf((float)E), drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx);
+    SLNLP_CHECK_LAUNCH("embed_fwd");
+    return 0;
+}
+
+int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
+              float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st) {
+    SLNLP_CHECK_ARG(ids && dx && dtable, "embed_bwd: null pointer");
+    SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_bwd: bad shape");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_bwd: bad dropout args");
+    if (hipMemsetAsync(dtable, 0, (size_t)V * E * sizeof(float), st) != hipSuccess) {
+        set_error("embed_bwd: memset failed");
+        return SLNLP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * S), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V, dx,
+                       dtable, sqrtf((float)E), drop_p, dropout_threshold(drop_p), drop_site, rng);
+    SLNLP_CHECK_LAUNCH("embed_bwd");
+    return 0;
+}
+
+// ================================================================= layernorm
+constexpr int LN_MAXU = 4;  // float4 per lane -> E <= 1024 in the backward (register-resident columns)
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int rows, int E,
+                                                            float eps, float* __restrict__ y,
+                                                            float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* xr = x + (long)row * E;
+    float s = 0.f;
+    for (int c = lane * 4; c < E; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        s += v.x + v.y + v.z + v.w;
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+    for (int c = lane * 4; c < E; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)E + eps);
+    for (int c = lane * 4; c < E; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 b = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = (v.x - mean) * rstd * g.x + b.x; o.y = (v.y - mean) * rstd * g.y + b.y;
+        o.z = (v.z - mean) * rstd * g.z + b.z; o.w = (v.w - mean) * rstd * g.w + b.w;
+        *reinterpret_cast<float4*>(y + (long)row * E + c) = o;
+    }
+    if (lane == 0 && stats) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
+    float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
+    const unsigned long long* __restrict__ rng, float* __restrict__ partial) {
+    __shared__ float red[4][2][LN_MAXU * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 dg[LN_MAXU], db[LN_MAXU];
+#pragma unroll
+    for (int u = 0; u < LN_MAXU; ++u) dg[u] = db[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const float* xr = x + (long)row * E;
+        const float* gr = dy + (long)row * E;
+        float s1 = 0.f, s2 = 0.f;
+        float4 gv[LN_MAXU], xh[LN_MAXU];
+#pragma unroll
+        for (int u = 0; u < LN_MAXU; ++u) {
+            const int c = lane * 4 + u * 256;
+            if (c < E) {
+                const float4 d = *reinterpret_cast<const float4*>(gr + c);
+                const float4 v = *reinterpret_cast<const float4*>(xr + c);
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                xh[u] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+                gv[u] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                s1 += gv[u].x + gv[u].y + gv[u].z + gv[u].w;
+                s2 += gv[u].x * xh[u].x + gv[u].y * xh[u].y + gv[u].z * xh[u].z + gv[u].w * xh[u].w;
+                dg[u].x += d.x * xh[u].x; dg[u].y += d.y * xh[u].y; dg[u].z += d.z * xh[u].z; dg[u].w += d.w * xh[u].w;
+                db[u].x += d.x; db[u].y += d.y; db[u].z += d.z; db[u].w += d.w;
+            }
+        }
+        s1 = wave_sum(s1) * invE;
+        s2 = wave_sum(s2) * invE;
+#pragma unroll
+        for (int u = 0; u < LN_MAXU; ++u) {
+            const int c = lane * 4 + u * 256;
+            if (c < E) {
+                float4 o;
+                o.x = rstd * (gv[u].x - s1 - xh[u].x * s2); o.y = rstd * (gv[u].y - s1 - xh[u].y * s2);
+                o.z = rstd * (gv[u].z - s1 - xh[u].z * s2); o.w = rstd * (gv[u].w - s1 - xh[u].w * s2);
+                if (add_to_dx) {
+                    const float4 a = *reinterpret_cast<const float4*>(add_to_dx + (long)row * E + c);
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
+                *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
+                if (dx_drop) {
+                    if (drop_p > 0.f) {
+                        o.x = dropout_keep(rng, drop_site, row, c + 0, drop_thr) ? o.x * ik : 0.f;
+                        o.y = dropout_keep(rng, drop_site, row, c + 1, drop_thr) ? o.y * ik : 0.f;
+                        o.z = dropout_keep(rng, drop_site, row, c + 2, drop_thr) ? o.z * ik : 0.f;
+                        o.w = dropout_keep(rng, drop_site, row, c + 3, drop_thr) ? o.w * ik : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
+                }
+            }
+        }
+    }
+    // combine the block's 4 waves, write this block's partial (dgamma | dbeta)
+#pragma unroll
+    for (int u = 0; u < LN_MAXU; ++u) {
+        const int c = lane * 4 + u * 256;
+        *reinterpret_cast<float4*>(&red[wave][0][c]) = dg[u];
+        *reinterpret_cast<float4*>(&red[wave][1][c]) = db[u];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += 256) {
+        partial[((long)blockIdx.x * 2 + 0) * E + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        partial[((long)blockIdx.x * 2 + 1) * E + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_reduce_entry* __restrict__ table) {
+    const slnlp_ln_reduce_entry e = table[blockIdx.x];
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= e.E) return;
+    float g = 0.f, b = 0.f;
+    for (int k = 0; k < e.nblk; ++k) {
+        g += e.partial[((long)k * 2 + 0) * e.E + c];
+        b += e.partial[((long)k * 2 + 1) * e.E + c];
+    }
+    e.dgamma[c] = g;
+    e.dbeta[c] = b;
+}
+
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
+                  float* stats, hipStream_t st) {
+    SLNLP_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0, "layernorm_fwd: bad shape rows=%d E=%d", rows, E);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, gamma, beta, rows, E, eps, y,
+                       stats);
+    SLNLP_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+int ln_bwd_blocks(int rows) {
+    int n = ceil_div(rows, 4);
+    return n > SLNLP_LN_MAX_PARTIALS ? SLNLP_LN_MAX_PARTIALS : n;
+}
+
+int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
+                  const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
+                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st) {
+    SLNLP_CHECK_ARG(dy && x && gamma && stats && dx && partial, "layernorm_bwd: null pointer");
+    SLNLP_CHECK_ARG(nblk_force >= 0 && nblk_force <= SLNLP_LN_MAX_PARTIALS, "layernorm_bwd: nblk_force %d", nblk_force);
+    SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "layernorm_bwd: need E %% 4 == 0 and E <= %d, got %d", LN_MAXU * 256, E);
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "layernorm_bwd: bad dropout args");
+    // nblk_force: a plan whose reduce table was built for the full batch launches that many
+    // blocks for smaller batches too; blocks without rows write zero partials.
+    const int nblk = nblk_force ? nblk_force : ln_bwd_blocks(rows);
+    if (nblk_out) *nblk_out = nblk;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, x, gamma, stats, rows, E, add_to_dx, dx,
+                       dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial);
+    SLNLP_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+}
+
+int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st) {
+    SLNLP_CHECK_ARG(table_dev && n > 0 && max_E > 0, "ln_param_reduce: bad args");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(n, ceil_div(max_E, 256)), dim3(256), 0, st, table_dev);
+    SLNLP_CHECK_LAUNCH("ln_param_reduce");
+    return 0;
+}
+
+// ====================================================================== loss
+// log_softmax (transformer.py:88-89) + CrossEntropyLoss(ignore_index) applied to
+// the log-probs (helper.py:61-70).  One workgroup; one wave per row.
+constexpr int LOSS_MAXB = 1024;
+
+__global__ __launch_bounds__(256) void lsm_nll_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ y,
+                                                      int B, int V, long ignore, float* __restrict__ logp,
+                                                      float* __restrict__ loss, float* __restrict__ dlogits, long ldd) {
+    __shared__ float lse2_s[LOSS_MAXB];
+    __shared__ float nll_s[LOSS_MAXB];
+    __shared__ float red[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 4) {
+        const float* xr = logits + (long)b * ld;
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, xr[v]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int v = lane; v < V; v += 64) s += expf(xr[v] - m);
+        const float lse = m + logf(wave_sum(s));
+        // second log_softmax (the criterion's), over the log-probs
+        float m2 = -INFINITY;
+        for (int v = lane; v < V; v += 64) {
+            const float lp = xr[v] - lse;
+            logp[(long)b * V + v] = lp;
+            m2 = fmaxf(m2, lp);
+        }
+        m2 = wave_max(m2);
+        float s2 = 0.f;
+        for (int v = lane; v < V; v += 64) s2 += expf((xr[v] - lse) - m2);
+        const float lse2 = m2 + logf(wave_sum(s2));
+        if (lane == 0) {
+            const long t = y[b];
+            const bool valid = (t != ignore) && t >= 0 && t < V;
+            lse2_s[b] = lse2;
+            nll_s[b] = valid ? -((xr[t] - lse) - lse2) : NAN;  // NaN marks "ignored"
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f, n = 0.f;
+        for (int b = 0; b < B; ++b)
+            if (nll_s[b] == nll_s[b]) { tot += nll_s[b]; n += 1.f; }
+        red[0] = tot / n;  // 0/0 = NaN when every target is ignored, as torch
+        red[1] = n;
+        loss[0] = red[0];
+    }
+    __syncthreads();
+    if (!dlogits) return;
+    const float invn = 1.f / red[1];
+    for (int b = wave; b < B; b += 4) {
+        const bool valid = nll_s[b] == nll_s[b];
+        const float w = valid ? invn : 0.f;
+        const long t = y[b];
+        const float lse2 = lse2_s[b];
+        // d loss / d logp = w * (softmax(logp) - onehot); then back through the model's log_softmax
+        float sum = 0.f;
+        for (int v = lane; v < V; v += 64) {
+            const float lp = logp[(long)b * V + v];
+            sum += w * (expf(lp - lse2) - (v == t ? 1.f : 0.f));
+        }
+        sum = wave_sum(sum);
+        for (int v = lane; v < V; v += 64) {
+            const float lp = logp[(long)b * V + v];
+            const float dlp = w * (expf(lp - lse2) - (v == t ? 1.f : 0.f));
+            dlogits[(long)b * ldd + v] = dlp - expf(lp) * sum;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp, int B,
+                                                      int V, float* __restrict__ dlogits, long ldd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += dlogp[(long)b * V + v];
+    sum = wave_sum(sum);
+    for (int v = lane; v < V; v += 64)
+        dlogits[(long)b * ldd + v] = dlogp[(long)b * V + v] - expf(logp[(long)b * V + v]) * sum;
+}
+
+int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
+            float* loss, float* dlogits, int64_t ld_dlogits, hipStream_t st) {
+    SLNLP_CHECK_ARG(logits && y && logp && loss, "lsm_nll: null pointer");
+    SLNLP_CHECK_ARG(B > 0 && B <= LOSS_MAXB && V > 0 && ld_logits >= V, "lsm_nll: bad shape B=%d V=%d", B, V);
+    SLNLP_CHECK_ARG(!dlogits || ld_dlogits >= V, "lsm_nll: ld_dlogits too small");
+    hipLaunchKernelGGL(lsm_nll_kernel, dim3(1), dim3(256), 0, st, logits, (long)ld_logits, (const long*)y, B, V,
+                       (long)ignore_index, logp, loss, dlogits, (long)ld_dlogits);
+    SLNLP_CHECK_LAUNCH("lsm_nll");
+    return 0;
+}
+
+int lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits, hipStream_t st) {
+    SLNLP_CHECK_ARG(logp && dlogp && dlogits && B > 0 && V > 0 && ld_dlogits >= V, "lsm_bwd: bad args");
+    hipLaunchKernelGGL(lsm_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, logp, dlogp, B, V, dlogits,
+                       (long)ld_dlogits);
+    SLNLP_CHECK_LAUNCH("lsm_bwd");
+    return 0;
+}
+
+// ================================================================= optimizer
+// clip_grad_norm_(max_norm) + torch.optim.SGD(momentum) over one flat arena.
+constexpr int OPT_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)OPT_BLOCKS * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long n4, const float* __restrict__ lr_dev, float momentum,
+                                                  float max_norm, const float* __restrict__ partials,
+                                                  float* __restrict__ norm_out, unsigned long long* __restrict__ rng) {
+    __shared__ float red[4];
+    // every block re-derives the total in the same fixed order: deterministic, no third launch
+    float s = 0.f;
+    for (int i = threadIdx.x; i < OPT_BLOCKS; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    const float lr = lr_dev[0];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 b = reinterpret_cast<float4*>(buf)[i];
+        float4 w = reinterpret_cast<float4*>(p)[i];
+        b.x = momentum * b.x + gv.x * coef; b.y = momentum * b.y + gv.y * coef;
+        b.z = momentum * b.z + gv.z * coef; b.w = momentum * b.w + gv.w * coef;
+        w.x -= lr * b.x; w.y -= lr * b.y; w.z -= lr * b.z; w.w -= lr * b.w;
+        reinterpret_cast<float4*>(buf)[i] = b;
+        reinterpret_cast<float4*>(p)[i] = w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (norm_out) norm_out[0] = norm;
+        if (rng) rng[1] += 1ull;
+    }
+}
+
+int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                  float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
+                  hipStream_t st) {
+    SLNLP_CHECK_ARG(params && grads && momentum_buf && lr_dev && partials, "clip_sgd_step: null pointer");
+    SLNLP_CHECK_ARG(n > 0 && n % 4 == 0, "clip_sgd_step: n=%ld must be a positive multiple of 4", (long)n);
+    SLNLP_CHECK_ARG(((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0 && ((uintptr_t)momentum_buf & 15) == 0,
+                    "clip_sgd_step: arenas must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, (long)(n / 4), partials);
+    SLNLP_CHECK_LAUNCH("sumsq");
+    int grid = ceil_div(n / 4, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, st, params, grads, momentum_buf, (long)(n / 4), lr_dev,
+                       momentum, max_norm, partials, norm_out, rng);
+    SLNLP_CHECK_LAUNCH("sgd");
+    return 0;
+}
+
+// ============================================================== dropout mask
+__global__ void dropout_mask_kernel(float* out, int R, int C, unsigned thr, int site, const unsigned long long* rng) {
+    const long total = (long)R * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned r = (unsigned)(i / C), c = (unsigned)(i % C);
+        out[i] = dropout_keep(rng, site, r, c, thr) ? 1.f : 0.f;
+    }
+}
+
+}  // namespace slnlp
+
+extern "C" {
+int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table,
+                    const float* pe, float* out, float drop_p, int drop_site, const unsigned long long* rng,
+                    int64_t nan_idx, void* stream) {
+    return slnlp::embed_fwd(ids, ld_ids, B, S, E, V, table, pe, out, drop_p, drop_site, rng, nan_idx, (hipStream_t)stream);
+}
+int slnlp_embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
+                    float drop_p, int drop_site, const unsigned long long* rng, void* stream) {
+    return slnlp::embed_bwd(ids, ld_ids, B, S, E, V, dx, dtable, drop_p, drop_site, rng, (hipStream_t)stream);
+}
+int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
+                        float* stats, void* stream) {
+    return slnlp::layernorm_fwd(x, gamma, beta, rows, E, eps, y, stats, (hipStream_t)stream);
+}
+int slnlp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
+                        const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
+                        const unsigned long long* rng, float* partial, int* nblk_out, void* stream) {
+    return slnlp::layernorm_bwd(dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, drop_site, rng, partial,
+                                nblk_out, 0, (hipStream_t)stream);
+}
+int slnlp_ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, void* stream) {
+    return slnlp::ln_param_reduce(table_dev, n, max_E, (hipStream_t)stream);
+}
+int slnlp_lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index,
+                  float* logp, float* loss, float* dlogits, int64_t ld_dlogits, void* stream) {
+    return slnlp::lsm_nll(logits, ld_logits, y, B, V, ignore_index, logp, loss, dlogits, ld_dlogits,
+                          (hipStream_t)stream);
+}
+int slnlp_lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits,
+                  void* stream) {
+    return slnlp::lsm_bwd(logp, dlogp, B, V, dlogits, ld_dlogits, (hipStream_t)stream);
+}
+int slnlp_clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
+                        float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
+                        void* stream) {
+    return slnlp::clip_sgd_step(params, grads, momentum_buf, n, lr_dev, momentum, max_norm, partials, norm_out, rng,
+                                (hipStream_t)stream);
+}
+int slnlp_dropout_mask(float* out, int R, int C, float p, int site, const unsigned long long* rng, void* stream) {
+    if (!out || !rng || R <= 0 || C <= 0 || p < 0.f || p >= 1.f) {
+        slnlp::set_error("slnlp_dropout_mask: bad args");
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    long total = (long)R * C;
+    int grid = slnlp::ceil_div(total, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(slnlp::dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, R, C,
+                       slnlp::dropout_threshold(p), site, rng);
+    return hipGetLastError() == hipSuccess ? 0 : SLNLP_ERR_LAUNCH;
+}
+}

@@ -1,0 +1,621 @@
+// tf_plan.hip -- host-side plan for the whole model.Transformer step.
+//
+// Drop-in target: /root/reference/model/transformer.py:10-109 (constructor
+// defines the parameter set, forward :60-90 defines the arithmetic) driven by
+// the skorch step zero_grad -> forward -> CrossEntropyLoss(ignore_index) ->
+// backward -> clip_grad_norm_ -> SGD.
+//
+// The plan owns (a) the layout of the flat fp32 parameter arena (names/shapes =
+// reference state_dict), (b) the layout of the activation workspace and (c) the
+// launch sequence.  Nothing here allocates device memory: the caller hands in
+// arena / workspace pointers.  Every launch goes to the caller's stream, so the
+// whole step can be captured into one hipGraph (slnlp_tf_graph_*).
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace slnlp {
+
+static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+struct ParamEnt {
+    std::string name;
+    int64_t shape[2];
+    int ndim;
+    int64_t off, numel;
+};
+struct EncP { long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b; };
+struct DecP {
+    long sin_w, sin_b, sout_w, sout_b, cin_w, cin_b, cout_w, cout_b, l1_w, l1_b, l2_w, l2_b;
+    long n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
+};
+struct Layout {
+    std::vector<ParamEnt> ents;
+    long src_emb, tgt_emb, encn_w, encn_b, decn_w, decn_b, lin_w, lin_b, total;
+    std::vector<EncP> enc;
+    std::vector<DecP> dec;
+};
+
+// Reference state_dict order (transformer.py:32-47 construction order; the
+// *_pos_encoding.pe buffers are not parameters and live outside the arena).
+// Every tensor starts on a 16-byte boundary so float4 access is always legal.
+static Layout build_layout(const slnlp_tf_config& c) {
+    Layout L;
+    long cur = 0;
+    auto add = [&](const std::string& n, long d0, long d1) -> long {
+        ParamEnt e;
+        e.name = n;
+        e.shape[0] = d0;
+        e.shape[1] = d1;
+        e.ndim = d1 > 0 ? 2 : 1;
+        e.numel = d1 > 0 ? d0 * d1 : d0;
+        e.off = cur;
+        cur = align_up(cur + e.numel, 4);
+        L.ents.push_back(e);
+        return e.off;
+    };
+    const long E = c.E, F = c.F;
+    L.src_emb = add("src_embedding.weight", c.Vs, E);
+    L.tgt_emb = add("tgt_embedding.weight", c.Vt, E);
+    for (int i = 0; i < c.N; ++i) {
+        const std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+        EncP e;
+        e.in_w = add(p + "self_attn.in_proj_weight", 3 * E, E);
+        e.in_b = add(p + "self_attn.in_proj_bias", 3 * E, 0);
+        e.out_w = add(p + "self_attn.out_proj.weight", E, E);
+        e.out_b = add(p + "self_attn.out_proj.bias", E, 0);
+        e.l1_w = add(p + "linear1.weight", F, E);
+        e.l1_b = add(p + "linear1.bias", F, 0);
+        e.l2_w = add(p + "linear2.weight", E, F);
+        e.l2_b = add(p + "linear2.bias", E, 0);
+        e.n1_w = add(p + "norm1.weight", E, 0);
+        e.n1_b = add(p + "norm1.bias", E, 0);
+        e.n2_w = add(p + "norm2.weight", E, 0);
+        e.n2_b = add(p + "norm2.bias", E, 0);
+        L.enc.push_back(e);
+    }
+    L.encn_w = add("transformer.encoder.norm.weight", E, 0);
+    L.encn_b = add("transformer.encoder.norm.bias", E, 0);
+    for (int i = 0; i < c.N; ++i) {
+        const std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+        DecP d;
+        d.sin_w = add(p + "self_attn.in_proj_weight", 3 * E, E);
+        d.sin_b = add(p + "self_attn.in_proj_bias", 3 * E, 0);
+        d.sout_w = add(p + "self_attn.out_proj.weight", E, E);
+        d.sout_b = add(p + "self_attn.out_proj.bias", E, 0);
+        d.cin_w = add(p + "multihead_attn.in_proj_weight", 3 * E, E);
+        d.cin_b = add(p + "multihead_attn.in_proj_bias", 3 * E, 0);
+        d.cout_w = add(p + "multihead_attn.out_proj.weight", E, E);
+        d.cout_b = add(p + "multihead_attn.out_proj.bias", E, 0);
+        d.l1_w = add(p + "linear1.weight", F, E);
+        d.l1_b = add(p + "linear1.bias", F, 0);
+        d.l2_w = add(p + "linear2.weight", E, F);
+        d.l2_b = add(p + "linear2.bias", E, 0);
+        d.n1_w = add(p + "norm1.weight", E, 0);
+        d.n1_b = add(p + "norm1.bias", E, 0);
+        d.n2_w = add(p + "norm2.weight", E, 0);
+        d.n2_b = add(p + "norm2.bias", E, 0);
+        d.n3_w = add(p + "norm3.weight", E, 0);
+        d.n3_b = add(p + "norm3.bias", E, 0);
+        L.dec.push_back(d);
+    }
+    L.decn_w = add("transformer.decoder.norm.weight", E, 0);
+    L.decn_b = add("transformer.decoder.norm.bias", E, 0);
+    L.lin_w = add("linear.weight", c.Vt, E);
+    L.lin_b = add("linear.bias", c.Vt, 0);
+    L.total = cur;
+    return L;
+}
+
+static int check_cfg(const slnlp_tf_config* c) {
+    SLNLP_CHECK_ARG(c, "tf: null config");
+    SLNLP_CHECK_ARG(c->E > 0 && c->H > 0 && c->E % c->H == 0, "tf: E=%d not divisible by H=%d", c->E, c->H);
+    const int dh = c->E / c->H;
+    SLNLP_CHECK_ARG(c->E % 4 == 0 && c->E <= 1024, "tf: E=%d must be a multiple of 4 and <= 1024", c->E);
+    SLNLP_CHECK_ARG(dh % 4 == 0 && dh <= 256 && (dh <= 64 || dh % 64 == 0), "tf: head_dim %d unsupported", dh);
+    SLNLP_CHECK_ARG(c->F > 0 && c->F % 4 == 0, "tf: hidden_size %d must be a multiple of 4", c->F);
+    SLNLP_CHECK_ARG(c->N > 0 && c->Vs > 1 && c->Vt > 1, "tf: bad N/vocab");
+    SLNLP_CHECK_ARG(c->B > 0 && c->B <= 1024, "tf: batch %d outside 1..1024", c->B);
+    SLNLP_CHECK_ARG(c->S > 0 && c->S <= 64, "tf: seq_len %d outside 1..64 (single-tile attention)", c->S);
+    SLNLP_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "tf: dropout %f", c->dropout);
+    SLNLP_CHECK_ARG(c->precision == 1 || c->precision == 3, "tf: precision %d", c->precision);
+    return 0;
+}
+
+// ------------------------------------------------------------- workspace ----
+struct Bump {
+    char* base;
+    size_t cur = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t n) {
+        cur = (cur + 255) & ~(size_t)255;
+        T* p = (T*)(base + cur);
+        cur += n * sizeof(T);
+        return p;
+    }
+};
+
+struct EncA { float *qkv, *probs, *ctx, *y1, *st1, *x1, *h, *y2, *st2, *x2, *lnp1, *lnp2; };
+struct DecA {
+    float *v, *y1, *st1, *t1, *q, *kv, *xprobs, *xctx, *y2, *st2, *t2, *h, *y3, *st3, *t3, *lnp1, *lnp2, *lnp3;
+};
+struct Ws {
+    float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp;
+    std::vector<EncA> enc;
+    std::vector<DecA> dec;
+    float *d0, *d1, *d2, *dqkv, *dh, *dctx, *dmem;          // encoder-sized grads
+    float *e0, *e1, *e2, *dq, *dxctx, *dv, *dhd, *dkv;      // decoder-sized grads (+ dkv [M,2E])
+    float* opt_partials;
+    slnlp_ln_reduce_entry* ln_table;
+    size_t bytes;
+};
+
+static Ws carve(const slnlp_tf_config& c, void* base) {
+    Ws w;
+    Bump b(base);
+    const size_t B = c.B, S = c.S, E = c.E, F = c.F, H = c.H, M = B * S, Vp = align_up(c.Vt, 4);
+    const size_t lnp = (size_t)SLNLP_LN_MAX_PARTIALS * 2 * E;
+    w.x0 = b.take<float>(M * E);
+    w.t0 = b.take<float>(B * E);
+    for (int i = 0; i < c.N; ++i) {
+        EncA a;
+        a.qkv = b.take<float>(M * 3 * E);
+        a.probs = b.take<float>(B * H * S * S);
+        a.ctx = b.take<float>(M * E);
+        a.y1 = b.take<float>(M * E);
+        a.st1 = b.take<float>(M * 2);
+        a.x1 = b.take<float>(M * E);
+        a.h = b.take<float>(M * F);
+        a.y2 = b.take<float>(M * E);
+        a.st2 = b.take<float>(M * 2);
+        a.x2 = b.take<float>(M * E);
+        a.lnp1 = b.take<float>(lnp);
+        a.lnp2 = b.take<float>(lnp);
+        w.enc.push_back(a);
+    }
+    w.mem = b.take<float>(M * E);
+    w.st_mem = b.take<float>(M * 2);
+    w.lnp_mem = b.take<float>(lnp);
+    for (int i = 0; i < c.N; ++i) {
+        DecA a;
+        a.v = b.take<float>(B * E);
+        a.y1 = b.take<float>(B * E);
+        a.st1 = b.take<float>(B * 2);
+        a.t1 = b.take<float>(B * E);
+        a.q = b.take<float>(B * E);
+        a.kv = b.take<float>(M * 2 * E);
+        a.xprobs = b.take<float>(B * H * S);
+        a.xctx = b.take<float>(B * E);
+        a.y2 = b.take<float>(B * E);
+        a.st2 = b.take<float>(B * 2);
+        a.t2 = b.take<float>(B * E);
+        a.h = b.take<float>(B * F);
+        a.y3 = b.take<float>(B * E);
+        a.st3 = b.take<float>(B * 2);
+        a.t3 = b.take<float>(B * E);
+        a.lnp1 = b.take<float>(lnp);
+        a.lnp2 = b.take<float>(lnp);
+        a.lnp3 = b.take<float>(lnp);
+        w.dec.push_back(a);
+    }
+    w.tfin = b.take<float>(B * E);
+    w.st_fin = b.take<float>(B * 2);
+    w.lnp_fin = b.take<float>(lnp);
+    w.logits = b.take<float>(B * Vp);
+    w.dlogits = b.take<float>(B * Vp);
+    w.logp = b.take<float>(B * c.Vt);
+    w.d0 = b.take<float>(M * E);
+    w.d1 = b.take<float>(M * E);
+    w.d2 = b.take<float>(M * E);
+    w.dqkv = b.take<float>(M * 3 * E);
+    w.dh = b.take<float>(M * F);
+    w.dctx = b.take<float>(M * E);
+    w.dmem = b.take<float>(M * E);
+    w.e0 = b.take<float>(B * E);
+    w.e1 = b.take<float>(B * E);
+    w.e2 = b.take<float>(B * E);
+    w.dq = b.take<float>(B * E);
+    w.dxctx = b.take<float>(B * E);
+    w.dv = b.take<float>(B * E);
+    w.dhd = b.take<float>(B * F);
+    w.dkv = b.take<float>(M * 2 * E);
+    w.opt_partials = b.take<float>(1024);
+    w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
+    w.bytes = (b.cur + 255) & ~(size_t)255;
+    return w;
+}
+
+}  // namespace slnlp
+
+using namespace slnlp;
+
+// dropout site ids
+enum { SITE_SRC_EMB = 1, SITE_TGT_EMB = 2, SITE_LAYER0 = 16, SITE_PER_LAYER = 8 };
+
+struct slnlp_tf_plan {
+    slnlp_tf_config cfg;
+    slnlp_tf_buffers buf;
+    Layout L;
+    Ws w;
+    int last_B = 0;       // batch of the last forward
+    float last_p = 0.f;   // dropout used by the last forward (0 in eval)
+    const int64_t* last_X = nullptr;
+    const int64_t* last_y = nullptr;
+    hipGraphExec_t graph = nullptr;
+    int nbE = 0, nbD = 0;  // LN-backward block counts of the FULL batch (fixed: the reduce table is static)
+
+    float* P(long off) const { return buf.params + off; }
+    float* G(long off) const { return buf.grads + off; }
+    int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
+    int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
+
+    // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
+    int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
+               float p, int site, const float* resid, hipStream_t st) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A = x; a.lda = K; a.a_kmajor = 1;
+        a.B = W; a.ldb = K; a.b_kmajor = 1;
+        a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+        a.bias = bias; a.relu = relu;
+        a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
+        a.resid = resid; a.ldr = ldy;
+        a.precision = cfg.precision;
+        return gemm(a, st);
+    }
+    // dx[M,Kin] = dy[M,Nout] W[Nout,Kin]  (*gate) (+resid)
+    int dgrad(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx, const float* gate,
+              float gate_scale, const float* resid, hipStream_t st) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A = dy; a.lda = ldy; a.a_kmajor = 1;
+        a.B = W; a.ldb = Kin; a.b_kmajor = 0;
+        a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
+        a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
+        a.resid = resid; a.ldr = Kin;
+        a.precision = cfg.precision;
+        return gemm(a, st);
+    }
+    // dW[Nout,Kin] = dy[T,Nout]^T x[T,Kin];  db[Nout] = colsum(dy)
+    int wgrad(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db,
+              hipStream_t st) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A = dy; a.lda = ldy; a.a_kmajor = 0;
+        a.B = x; a.ldb = Kin; a.b_kmajor = 0;
+        a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
+        a.rowsum_a = db;
+        a.precision = cfg.precision;
+        return gemm(a, st);
+    }
+};
+
+extern "C" {
+
+int slnlp_tf_num_params(const slnlp_tf_config* cfg) {
+    if (check_cfg(cfg)) return -1;
+    return (int)build_layout(*cfg).ents.size();
+}
+
+int slnlp_tf_param_info(const slnlp_tf_config* cfg, int i, char* name, int64_t shape[2], int* ndim, int64_t* offset) {
+    SLNLP_TRY(check_cfg(cfg));
+    Layout L = build_layout(*cfg);
+    SLNLP_CHECK_ARG(i >= 0 && i < (int)L.ents.size(), "tf_param_info: index %d out of range", i);
+    const ParamEnt& e = L.ents[i];
+    if (name) {
+        strncpy(name, e.name.c_str(), 127);
+        name[127] = 0;
+    }
+    if (shape) {
+        shape[0] = e.shape[0];
+        shape[1] = e.shape[1];
+    }
+    if (ndim) *ndim = e.ndim;
+    if (offset) *offset = e.off;
+    return 0;
+}
+
+int64_t slnlp_tf_arena_floats(const slnlp_tf_config* cfg) {
+    if (check_cfg(cfg)) return -1;
+    return build_layout(*cfg).total;
+}
+
+int64_t slnlp_tf_workspace_bytes(const slnlp_tf_config* cfg) {
+    if (check_cfg(cfg)) return -1;
+    return (int64_t)carve(*cfg, nullptr).bytes;
+}
+
+int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, slnlp_tf_plan** out) {
+    SLNLP_TRY(check_cfg(cfg));
+    SLNLP_CHECK_ARG(buf && out, "tf_create: null argument");
+    SLNLP_CHECK_ARG(buf->params && buf->grads && buf->momentum && buf->pe && buf->workspace && buf->rng && buf->lr &&
+                        buf->scalars,
+                    "tf_create: every buffer pointer is required");
+    SLNLP_CHECK_ARG((((uintptr_t)buf->params | (uintptr_t)buf->grads | (uintptr_t)buf->momentum |
+                      (uintptr_t)buf->workspace | (uintptr_t)buf->pe) & 255) == 0,
+                    "tf_create: arenas / workspace / pe must be 256-byte aligned");
+    slnlp_tf_plan* p = new slnlp_tf_plan();
+    p->cfg = *cfg;
+    p->buf = *buf;
+    p->L = build_layout(*cfg);
+    p->w = carve(*cfg, buf->workspace);
+    // LN (dgamma, dbeta) reduction table: one entry per LayerNorm, uploaded once.
+    std::vector<slnlp_ln_reduce_entry> tab;
+    const int nbE = p->nbE = ln_bwd_blocks(cfg->B * cfg->S), nbD = p->nbD = ln_bwd_blocks(cfg->B);
+    auto ent = [&](const float* part, long gw, long gb, int nblk) {
+        slnlp_ln_reduce_entry e;
+        e.partial = part; e.dgamma = p->G(gw); e.dbeta = p->G(gb); e.nblk = nblk; e.E = cfg->E;
+        tab.push_back(e);
+    };
+    for (int i = 0; i < cfg->N; ++i) {
+        ent(p->w.enc[i].lnp1, p->L.enc[i].n1_w, p->L.enc[i].n1_b, nbE);
+        ent(p->w.enc[i].lnp2, p->L.enc[i].n2_w, p->L.enc[i].n2_b, nbE);
+    }
+    ent(p->w.lnp_mem, p->L.encn_w, p->L.encn_b, nbE);
+    for (int i = 0; i < cfg->N; ++i) {
+        ent(p->w.dec[i].lnp1, p->L.dec[i].n1_w, p->L.dec[i].n1_b, nbD);
+        ent(p->w.dec[i].lnp2, p->L.dec[i].n2_w, p->L.dec[i].n2_b, nbD);
+        ent(p->w.dec[i].lnp3, p->L.dec[i].n3_w, p->L.dec[i].n3_b, nbD);
+    }
+    ent(p->w.lnp_fin, p->L.decn_w, p->L.decn_b, nbD);
+    // nblk in the table is the FULL batch's block count; smaller batches launch the same
+    // number of LN-backward blocks (nblk_force), so every slot the reduce reads is rewritten.
+    if (attn_init() != 0) {
+        delete p;
+        return SLNLP_ERR_LAUNCH;
+    }
+    if (hipMemcpy(p->w.ln_table, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess) {
+        set_error("tf_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+        delete p;
+        return SLNLP_ERR_LAUNCH;
+    }
+    *out = p;
+    return 0;
+}
+
+void slnlp_tf_destroy(slnlp_tf_plan* plan) {
+    if (!plan) return;
+    if (plan->graph) hipGraphExecDestroy(plan->graph);
+    delete plan;
+}
+
+int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, int train, float* logp_out,
+                     void* stream) {
+    SLNLP_CHECK_ARG(pl && X && y, "tf_forward: `X` and `y` are required parameters");  // transformer.py:61-62
+    SLNLP_CHECK_ARG(B > 0 && B <= pl->cfg.B, "tf_forward: batch %d outside 1..%d", B, pl->cfg.B);
+    hipStream_t st = (hipStream_t)stream;
+    const slnlp_tf_config& c = pl->cfg;
+    const Ws& w = pl->w;
+    const Layout& L = pl->L;
+    const int E = c.E, F = c.F, H = c.H, S = c.S, dh = E / H, M = S * B, Vp = (int)align_up(c.Vt, 4);
+    const float p = train ? c.dropout : 0.f;
+    const unsigned long long* rng = pl->buf.rng;
+    pl->last_B = B; pl->last_p = p; pl->last_X = X; pl->last_y = y;
+
+    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, p, SITE_SRC_EMB, rng, -1, st));
+    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, p, SITE_TGT_EMB, rng, c.pad_tgt, st));
+
+    const float* x = w.x0;
+    for (int l = 0; l < c.N; ++l) {
+        const EncP& q = L.enc[l];
+        const EncA& a = w.enc[l];
+        SLNLP_TRY(pl->linear(x, M, E, pl->P(q.in_w), 3 * E, pl->P(q.in_b), a.qkv, 3 * E, 0, 0.f, 0, nullptr, st));
+        SLNLP_TRY(attn_self_fwd(a.qkv, X, S, c.pad_src, 1, B, S, H, dh, a.ctx, a.probs, p, pl->enc_site(l, 0), rng, st));
+        SLNLP_TRY(pl->linear(a.ctx, M, E, pl->P(q.out_w), E, pl->P(q.out_b), a.y1, E, 0, p, pl->enc_site(l, 1), x, st));
+        SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), M, E, 1e-5f, a.x1, a.st1, st));
+        SLNLP_TRY(pl->linear(a.x1, M, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->enc_site(l, 2), nullptr, st));
+        SLNLP_TRY(pl->linear(a.h, M, F, pl->P(q.l2_w), E, pl->P(q.l2_b), a.y2, E, 0, p, pl->enc_site(l, 3), a.x1, st));
+        SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), M, E, 1e-5f, a.x2, a.st2, st));
+        x = a.x2;
+    }
+    SLNLP_TRY(layernorm_fwd(x, pl->P(L.encn_w), pl->P(L.encn_b), M, E, 1e-5f, w.mem, w.st_mem, st));
+
+    const float* t = w.t0;
+    for (int l = 0; l < c.N; ++l) {
+        const DecP& q = L.dec[l];
+        const DecA& a = w.dec[l];
+        // self-attention over ONE key: softmax == 1 -> out_proj(v_proj(t)); q/k rows of in_proj are dead
+        SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, 0.f, 0, nullptr, st));
+        if (p > 0.f) SLNLP_TRY(head_dropout(a.v, B, H, dh, p, pl->dec_site(l, 0), rng, st));
+        SLNLP_TRY(pl->linear(a.v, B, E, pl->P(q.sout_w), E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, st));
+        SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
+        // cross-attention: q from tgt, k|v from memory, no masks (transformer.py:82-87)
+        SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st));
+        SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, a.kv, 2 * E, 0, 0.f, 0, nullptr, st));
+        SLNLP_TRY(attn_cross_fwd(a.q, a.kv, 2 * E, B, S, H, dh, a.xctx, a.xprobs, p, pl->dec_site(l, 2), rng, st));
+        SLNLP_TRY(pl->linear(a.xctx, B, E, pl->P(q.cout_w), E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, st));
+        SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st));
+        SLNLP_TRY(pl->linear(a.t2, B, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, st));
+        SLNLP_TRY(pl->linear(a.h, B, F, pl->P(q.l2_w), E, pl->P(q.l2_b), a.y3, E, 0, p, pl->dec_site(l, 5), a.t2, st));
+        SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st));
+        t = a.t3;
+    }
+    SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
+    SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
+    // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70)
+    SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp, st));
+    if (logp_out &&
+        hipMemcpyAsync(logp_out, w.logp, (size_t)B * c.Vt * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("tf_forward: copy of log-probs failed");
+        return SLNLP_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
+    SLNLP_CHECK_ARG(pl && dlogp && pl->last_B > 0, "tf_seed_dlogp: needs a prior forward");
+    return lsm_bwd(pl->w.logp, dlogp, pl->last_B, pl->cfg.Vt, pl->w.dlogits, align_up(pl->cfg.Vt, 4), (hipStream_t)stream);
+}
+
+int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
+    SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
+    hipStream_t st = (hipStream_t)stream;
+    const slnlp_tf_config& c = pl->cfg;
+    const Ws& w = pl->w;
+    const Layout& L = pl->L;
+    const int B = pl->last_B, E = c.E, F = c.F, H = c.H, S = c.S, dh = E / H, M = S * B, Vp = (int)align_up(c.Vt, 4);
+    const float p = pl->last_p, ik = 1.f / (1.f - p);
+    const unsigned long long* rng = pl->buf.rng;
+    const int64_t *X = pl->last_X, *y = pl->last_y;
+    int nb;
+
+    // generator: logits = tfin lin_w^T + lin_b
+    SLNLP_TRY(pl->wgrad(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b), st));
+    SLNLP_TRY(pl->dgrad(w.dlogits, Vp, B, c.Vt, pl->P(L.lin_w), E, w.e0, nullptr, 0.f, nullptr, st));
+    const float* t_last = w.dec[c.N - 1].t3;
+    SLNLP_TRY(layernorm_bwd(w.e0, t_last, pl->P(L.decn_w), w.st_fin, B, E, nullptr, w.e1, nullptr, 0.f, 0, rng, w.lnp_fin, &nb, pl->nbD, st));
+    float *dt = w.e1, *dA = w.e0, *dB = w.e2;  // rotating [B,E] buffers: dt = incoming grad
+    for (int l = c.N - 1; l >= 0; --l) {
+        const DecP& q = L.dec[l];
+        const DecA& a = w.dec[l];
+        const float* t_in = l > 0 ? w.dec[l - 1].t3 : w.t0;
+        float* dBr = p > 0.f ? dB : nullptr;                 // masked copy only when dropout is on
+        // norm3 / FFN
+        SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, dA, dBr, p, pl->dec_site(l, 5), rng, a.lnp3, &nb, pl->nbD, st));
+        const float* dbr = p > 0.f ? dB : dA;
+        SLNLP_TRY(pl->wgrad(dbr, E, B, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), st));
+        SLNLP_TRY(pl->dgrad(dbr, E, B, E, pl->P(q.l2_w), F, w.dhd, a.h, ik, nullptr, st));
+        SLNLP_TRY(pl->wgrad(w.dhd, F, B, F, a.t2, E, pl->G(q.l1_w), pl->G(q.l1_b), st));
+        SLNLP_TRY(pl->dgrad(w.dhd, F, B, F, pl->P(q.l1_w), E, dt, nullptr, 0.f, dA, st));
+        // norm2 / cross-attention
+        SLNLP_TRY(layernorm_bwd(dt, a.y2, pl->P(q.n2_w), a.st2, B, E, nullptr, dA, dBr, p, pl->dec_site(l, 3), rng, a.lnp2, &nb, pl->nbD, st));
+        SLNLP_TRY(pl->wgrad(dbr, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b), st));
+        SLNLP_TRY(pl->dgrad(dbr, E, B, E, pl->P(q.cout_w), E, w.dxctx, nullptr, 0.f, nullptr, st));
+        SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, w.dxctx, B, S, H, dh, w.dq, w.dkv, 2 * E, p, pl->dec_site(l, 2), rng, st));
+        SLNLP_TRY(pl->wgrad(w.dq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b), st));
+        SLNLP_TRY(pl->wgrad(w.dkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, st));
+        SLNLP_TRY(pl->dgrad(w.dkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.dmem, nullptr, 0.f,
+                            l == c.N - 1 ? nullptr : w.dmem, st));
+        SLNLP_TRY(pl->dgrad(w.dq, E, B, E, pl->P(q.cin_w), E, dt, nullptr, 0.f, dA, st));
+        // norm1 / self-attention (single key)
+        SLNLP_TRY(layernorm_bwd(dt, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, dA, dBr, p, pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, st));
+        SLNLP_TRY(pl->wgrad(dbr, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b), st));
+        SLNLP_TRY(pl->dgrad(dbr, E, B, E, pl->P(q.sout_w), E, w.dv, nullptr, 0.f, nullptr, st));
+        if (p > 0.f) SLNLP_TRY(head_dropout(w.dv, B, H, dh, p, pl->dec_site(l, 0), rng, st));
+        // softmax over one element has zero gradient: q/k rows of in_proj get exactly 0
+        if (hipMemsetAsync(pl->G(q.sin_w), 0, 2L * E * E * sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(pl->G(q.sin_b), 0, 2L * E * sizeof(float), st) != hipSuccess) {
+            set_error("tf_backward: memset failed");
+            return SLNLP_ERR_LAUNCH;
+        }
+        SLNLP_TRY(pl->wgrad(w.dv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E, st));
+        SLNLP_TRY(pl->dgrad(w.dv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, dt, nullptr, 0.f, dA, st));
+    }
+    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), p, SITE_TGT_EMB, rng, st));
+
+    // encoder
+    const float* x_last = w.enc[c.N - 1].x2;
+    SLNLP_TRY(layernorm_bwd(w.dmem, x_last, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.d0, nullptr, 0.f, 0, rng, w.lnp_mem, &nb, pl->nbE, st));
+    float *dx = w.d0, *eA = w.d1, *eB = w.d2;
+    for (int l = c.N - 1; l >= 0; --l) {
+        const EncP& q = L.enc[l];
+        const EncA& a = w.enc[l];
+        const float* x_in = l > 0 ? w.enc[l - 1].x2 : w.x0;
+        float* eBr = p > 0.f ? eB : nullptr;
+        SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, eA, eBr, p, pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st));
+        const float* ebr = p > 0.f ? eB : eA;
+        SLNLP_TRY(pl->wgrad(ebr, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), st));
+        SLNLP_TRY(pl->dgrad(ebr, E, M, E, pl->P(q.l2_w), F, w.dh, a.h, ik, nullptr, st));
+        SLNLP_TRY(pl->wgrad(w.dh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b), st));
+        SLNLP_TRY(pl->dgrad(w.dh, F, M, F, pl->P(q.l1_w), E, dx, nullptr, 0.f, eA, st));
+        SLNLP_TRY(layernorm_bwd(dx, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, eA, eBr, p, pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st));
+        SLNLP_TRY(pl->wgrad(ebr, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), st));
+        SLNLP_TRY(pl->dgrad(ebr, E, M, E, pl->P(q.out_w), E, w.dctx, nullptr, 0.f, nullptr, st));
+        SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, w.dctx, B, S, H, dh, w.dqkv, p, pl->enc_site(l, 0), rng, st));
+        SLNLP_TRY(pl->wgrad(w.dqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b), st));
+        SLNLP_TRY(pl->dgrad(w.dqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, dx, nullptr, 0.f, eA, st));
+    }
+    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), p, SITE_SRC_EMB, rng, st));
+    SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
+    return 0;
+}
+
+int slnlp_tf_optim(slnlp_tf_plan* pl, float momentum, float max_norm, void* stream) {
+    SLNLP_CHECK_ARG(pl, "tf_optim: null plan");
+    return clip_sgd_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, pl->L.total, pl->buf.lr, momentum, max_norm,
+                         pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, (hipStream_t)stream);
+}
+
+int slnlp_tf_train_step(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, float momentum, float max_norm,
+                        float* logp, void* stream) {
+    SLNLP_TRY(slnlp_tf_forward(pl, X, y, B, 1, logp, stream));
+    SLNLP_TRY(slnlp_tf_backward(pl, stream));
+    return slnlp_tf_optim(pl, momentum, max_norm, stream);
+}
+
+// Capture one train step (fixed X / y / logp device buffers and batch size) into
+// a hipGraph and keep the executable graph in the plan; replay with
+// slnlp_tf_graph_launch.  lr, rng step and the data are read from device memory,
+// so the same graph serves every step of a fit.
+int slnlp_tf_graph_capture_train(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, float momentum,
+                                 float max_norm, float* logp, void* stream) {
+    SLNLP_CHECK_ARG(pl && stream, "tf_graph_capture_train: needs a plan and a non-default stream");
+    hipStream_t st = (hipStream_t)stream;
+    if (pl->graph) {
+        hipGraphExecDestroy(pl->graph);
+        pl->graph = nullptr;
+    }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        set_error("tf_graph_capture_train: begin capture failed: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    int rc = slnlp_tf_train_step(pl, X, y, B, momentum, max_norm, logp, stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != 0) {
+        if (g) hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) {
+        set_error("tf_graph_capture_train: end capture failed: %s", hipGetErrorString(e));
+        return SLNLP_ERR_LAUNCH;
+    }
+    e = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        set_error("tf_graph_capture_train: instantiate failed: %s", hipGetErrorString(e));
+        pl->graph = nullptr;
+        return SLNLP_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+int slnlp_tf_graph_launch(slnlp_tf_plan* pl, void* stream) {
+    SLNLP_CHECK_ARG(pl && pl->graph, "tf_graph_launch: no captured graph");
+    if (hipGraphLaunch(pl->graph, (hipStream_t)stream) != hipSuccess) {
+        set_error("tf_graph_launch: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+int slnlp_tf_tap(slnlp_tf_plan* pl, const char* name, float* out, int64_t max_floats, int64_t* n_out, void* stream) {
+    SLNLP_CHECK_ARG(pl && name && out && pl->last_B > 0, "tf_tap: bad args / no forward yet");
+    const slnlp_tf_config& c = pl->cfg;
+    const int B = pl->last_B, M = B * c.S, E = c.E, Vp = (int)align_up(c.Vt, 4);
+    const std::string n(name);
+    const float* src = nullptr;
+    int64_t rows = 0, cols = E, ld = E;
+    if (n == "src_embed") { src = pl->w.x0; rows = M; }
+    else if (n == "tgt_embed") { src = pl->w.t0; rows = B; }
+    else if (n == "memory") { src = pl->w.mem; rows = M; }
+    else if (n == "logits") { src = pl->w.logits; rows = B; cols = c.Vt; ld = Vp; }
+    else if (n == "dlogits") { src = pl->w.dlogits; rows = B; cols = c.Vt; ld = Vp; }
+    else if (n.rfind("enc", 0) == 0) { int l = atoi(name + 3); SLNLP_CHECK_ARG(l >= 0 && l < c.N, "tf_tap: %s", name); src = pl->w.enc[l].x2; rows = M; }
+    else if (n.rfind("dec", 0) == 0) { int l = atoi(name + 3); SLNLP_CHECK_ARG(l >= 0 && l < c.N, "tf_tap: %s", name); src = pl->w.dec[l].t3; rows = B; }
+    SLNLP_CHECK_ARG(src, "tf_tap: unknown tap '%s'", name);
+    SLNLP_CHECK_ARG(rows * cols <= max_floats, "tf_tap: buffer too small (%ld needed)", (long)(rows * cols));
+    if (hipMemcpy2DAsync(out, cols * sizeof(float), src, ld * sizeof(float), cols * sizeof(float), rows,
+                         hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+        set_error("tf_tap: copy failed");
+        return SLNLP_ERR_LAUNCH;
+    }
+    if (n_out) *n_out = rows * cols;
+    return 0;
+}
+
+}  // extern "C"

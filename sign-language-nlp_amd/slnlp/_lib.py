@@ -1,0 +1,119 @@
+"""ctypes binding of libslnlp.so (C ABI in include/slnlp.h).
+
+The library is the product path: there is NO CPU fallback.  Loading works
+without a GPU (symbols / layout queries only); any compute entry point needs a
+MI355X and raises ``RuntimeError`` with ``slnlp_last_error()`` on failure.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libslnlp.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("a_kmajor", i32),
+                ("B", vp), ("ldb", i64), ("b_kmajor", i32),
+                ("C", vp), ("ldc", i64),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("bias", vp), ("relu", i32),
+                ("gate", vp), ("ldg", i64), ("gate_scale", f32),
+                ("drop_p", f32), ("drop_site", i32), ("rng", vp),
+                ("resid", vp), ("ldr", i64),
+                ("rowsum_a", vp), ("precision", i32)]
+
+
+class TfConfig(C.Structure):
+    _fields_ = [("E", i32), ("H", i32), ("N", i32), ("F", i32), ("Vs", i32), ("Vt", i32),
+                ("B", i32), ("S", i32), ("pad_src", i32), ("pad_tgt", i32),
+                ("dropout", f32), ("precision", i32)]
+
+
+class TfBuffers(C.Structure):
+    _fields_ = [("params", vp), ("grads", vp), ("momentum", vp), ("pe", vp), ("workspace", vp),
+                ("rng", vp), ("lr", vp), ("scalars", vp)]
+
+
+class LnReduceEntry(C.Structure):
+    _fields_ = [("partial", vp), ("dgamma", vp), ("dbeta", vp), ("nblk", i32), ("E", i32)]
+
+
+# name -> (restype, argtypes).  Every symbol include/slnlp.h declares is listed;
+# tests/test_abi.py checks the header and this table agree.
+SIGNATURES = {
+    "slnlp_last_error": (C.c_char_p, []),
+    "slnlp_abi_version": (i32, []),
+    "slnlp_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "slnlp_embed_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp, i64, vp]),
+    "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    "slnlp_attn_self_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    "slnlp_attn_self_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, f32, i32, vp, vp]),
+    "slnlp_attn_cross_fwd": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    "slnlp_attn_cross_bwd": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, i64, f32, i32, vp, vp]),
+    "slnlp_layernorm_fwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),
+    "slnlp_layernorm_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, i32, vp, vp, C.POINTER(i32), vp]),
+    "slnlp_ln_param_reduce": (i32, [vp, i32, i32, vp]),
+    "slnlp_lsm_nll": (i32, [vp, i64, vp, i32, i32, i64, vp, vp, vp, i64, vp]),
+    "slnlp_lsm_bwd": (i32, [vp, vp, i32, i32, vp, i64, vp]),
+    "slnlp_clip_sgd_step": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp]),
+    "slnlp_dropout_mask": (i32, [vp, i32, i32, f32, i32, vp, vp]),
+    "slnlp_tf_num_params": (i32, [C.POINTER(TfConfig)]),
+    "slnlp_tf_param_info": (i32, [C.POINTER(TfConfig), i32, C.c_char_p, C.POINTER(i64 * 2), C.POINTER(i32),
+                                  C.POINTER(i64)]),
+    "slnlp_tf_arena_floats": (i64, [C.POINTER(TfConfig)]),
+    "slnlp_tf_workspace_bytes": (i64, [C.POINTER(TfConfig)]),
+    "slnlp_tf_create": (i32, [C.POINTER(TfConfig), C.POINTER(TfBuffers), C.POINTER(vp)]),
+    "slnlp_tf_destroy": (None, [vp]),
+    "slnlp_tf_forward": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "slnlp_tf_seed_dlogp": (i32, [vp, vp, vp]),
+    "slnlp_tf_backward": (i32, [vp, vp]),
+    "slnlp_tf_optim": (i32, [vp, f32, f32, vp]),
+    "slnlp_tf_train_step": (i32, [vp, vp, vp, i32, f32, f32, vp, vp]),
+    "slnlp_tf_graph_capture_train": (i32, [vp, vp, vp, i32, f32, f32, vp, vp]),
+    "slnlp_tf_graph_launch": (i32, [vp, vp]),
+    "slnlp_tf_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libslnlp.so (once).  Raises if the in-tree build is missing --
+    run ``python -c 'import __graft_entry__ as g; g.build()'`` or ``make`` in
+    sign-language-nlp_amd/."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"libslnlp.so not built at {LIB_PATH}: the HIP extension is the "
+                               "only compute path (no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().slnlp_last_error().decode(errors="replace")
+        raise RuntimeError(f"libslnlp {what} failed (code {rc}): {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("slnlp: no MI355X visible -- the HIP path is the only compute path "
+                           "(there is deliberately no CPU fallback)")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,160 @@
+"""Thin torch-tensor front-ends of the granular C-ABI kernels (used by the
+parity tests and by the RNN host code).  Every function launches on torch's
+current stream and fails loudly without a GPU / without the built library."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check, load, ptr, stream_ptr
+
+
+def make_rng(seed=0, step=0, device="cuda"):
+    """Dropout state {seed, step} as int64[2] on the device (read as uint64)."""
+    return torch.tensor([seed, step], dtype=torch.int64, device=device)
+
+
+def gemm(A, B, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=None, out=None, ldc=None,
+         bias=None, relu=False, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, rng=None,
+         resid=None, rowsum_a=None, precision=3):
+    _lib.require_gpu()
+    lda = lda if lda is not None else (K if a_kmajor else M)
+    ldb = ldb if ldb is not None else (K if b_kmajor else N)
+    ldc = ldc if ldc is not None else N
+    if out is None:
+        out = torch.empty(M, ldc, dtype=torch.float32, device=A.device)
+    a = GemmArgs()
+    a.A, a.lda, a.a_kmajor = ptr(A), lda, int(a_kmajor)
+    a.B, a.ldb, a.b_kmajor = ptr(B), ldb, int(b_kmajor)
+    a.C, a.ldc, a.M, a.N, a.K = ptr(out), ldc, M, N, K
+    a.bias, a.relu = ptr(bias), int(relu)
+    a.gate, a.ldg, a.gate_scale = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale
+    a.drop_p, a.drop_site, a.rng = drop_p, drop_site, ptr(rng)
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    a.rowsum_a, a.precision = ptr(rowsum_a), precision
+    check(load().slnlp_gemm(C.byref(a), stream_ptr()), "gemm")
+    return out
+
+
+def embed_fwd(ids, table, pe, *, B, S, drop_p=0.0, drop_site=0, rng=None, nan_idx=-1):
+    _lib.require_gpu()
+    V, E = table.shape
+    out = torch.empty(S * B, E, dtype=torch.float32, device=table.device)
+    check(load().slnlp_embed_fwd(ptr(ids), ids.stride(0) if ids.ndim == 2 else 1, B, S, E, V, ptr(table), ptr(pe),
+                                 ptr(out), drop_p, drop_site, ptr(rng), nan_idx, stream_ptr()), "embed_fwd")
+    return out
+
+
+def embed_bwd(ids, dx, *, B, S, V, drop_p=0.0, drop_site=0, rng=None):
+    _lib.require_gpu()
+    E = dx.shape[1]
+    dt = torch.empty(V, E, dtype=torch.float32, device=dx.device)
+    check(load().slnlp_embed_bwd(ptr(ids), ids.stride(0) if ids.ndim == 2 else 1, B, S, E, V, ptr(dx), ptr(dt),
+                                 drop_p, drop_site, ptr(rng), stream_ptr()), "embed_bwd")
+    return dt
+
+
+def attn_self_fwd(qkv, ids, pad_idx, *, B, S, H, dh, causal=True, drop_p=0.0, drop_site=0, rng=None):
+    _lib.require_gpu()
+    E = H * dh
+    ctx = torch.empty(S * B, E, dtype=torch.float32, device=qkv.device)
+    probs = torch.empty(B, H, S, S, dtype=torch.float32, device=qkv.device)
+    check(load().slnlp_attn_self_fwd(ptr(qkv), ptr(ids), ids.stride(0) if ids is not None else 0, pad_idx,
+                                     int(causal), B, S, H, dh, ptr(ctx), ptr(probs), drop_p, drop_site, ptr(rng),
+                                     stream_ptr()), "attn_self_fwd")
+    return ctx, probs
+
+
+def attn_self_bwd(qkv, probs, dctx, *, B, S, H, dh, drop_p=0.0, drop_site=0, rng=None):
+    _lib.require_gpu()
+    dqkv = torch.empty_like(qkv)
+    check(load().slnlp_attn_self_bwd(ptr(qkv), ptr(probs), ptr(dctx), B, S, H, dh, ptr(dqkv), drop_p, drop_site,
+                                     ptr(rng), stream_ptr()), "attn_self_bwd")
+    return dqkv
+
+
+def attn_cross_fwd(q, kv, *, B, S, H, dh, drop_p=0.0, drop_site=0, rng=None):
+    _lib.require_gpu()
+    E = H * dh
+    ctx = torch.empty(B, E, dtype=torch.float32, device=q.device)
+    probs = torch.empty(B, H, S, dtype=torch.float32, device=q.device)
+    check(load().slnlp_attn_cross_fwd(ptr(q), ptr(kv), kv.stride(0), B, S, H, dh, ptr(ctx), ptr(probs), drop_p,
+                                      drop_site, ptr(rng), stream_ptr()), "attn_cross_fwd")
+    return ctx, probs
+
+
+def attn_cross_bwd(q, kv, probs, dctx, *, B, S, H, dh, drop_p=0.0, drop_site=0, rng=None):
+    _lib.require_gpu()
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    check(load().slnlp_attn_cross_bwd(ptr(q), ptr(kv), kv.stride(0), ptr(probs), ptr(dctx), B, S, H, dh, ptr(dq),
+                                      ptr(dkv), dkv.stride(0), drop_p, drop_site, ptr(rng), stream_ptr()),
+          "attn_cross_bwd")
+    return dq, dkv
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    _lib.require_gpu()
+    rows, E = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    check(load().slnlp_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), rows, E, eps, ptr(y), ptr(stats), stream_ptr()),
+          "layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy, x, gamma, stats, *, add_to_dx=None, want_drop=False, drop_p=0.0, drop_site=0, rng=None):
+    """-> (dx, dx_drop | None, dgamma, dbeta)"""
+    _lib.require_gpu()
+    rows, E = x.shape
+    dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if want_drop else None
+    partial = torch.empty(64, 2, E, dtype=torch.float32, device=x.device)
+    nblk = C.c_int32(0)
+    check(load().slnlp_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(stats), rows, E, ptr(add_to_dx), ptr(dx),
+                                     ptr(dxd), drop_p, drop_site, ptr(rng), ptr(partial), C.byref(nblk),
+                                     stream_ptr()), "layernorm_bwd")
+    dg = torch.empty(E, dtype=torch.float32, device=x.device)
+    db = torch.empty(E, dtype=torch.float32, device=x.device)
+    ent = _lib.LnReduceEntry(ptr(partial), ptr(dg), ptr(db), nblk.value, E)
+    table = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).to(x.device)
+    check(load().slnlp_ln_param_reduce(ptr(table), 1, E, stream_ptr()), "ln_param_reduce")
+    torch.cuda.current_stream().synchronize()  # `table` must outlive the launch
+    return dx, dxd, dg, db
+
+
+def lsm_nll(logits, y, ignore_index, *, want_grad=True):
+    """-> (logp [B,V], loss [1], dlogits [B,V] | None)"""
+    _lib.require_gpu()
+    B, V = logits.shape
+    logp = torch.empty(B, V, dtype=torch.float32, device=logits.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_grad else None
+    check(load().slnlp_lsm_nll(ptr(logits), logits.stride(0), ptr(y), B, V, ignore_index, ptr(logp), ptr(loss),
+                               ptr(dl), V, stream_ptr()), "lsm_nll")
+    return logp, loss, dl
+
+
+def lsm_bwd(logp, dlogp):
+    _lib.require_gpu()
+    B, V = logp.shape
+    out = torch.empty_like(logp)
+    check(load().slnlp_lsm_bwd(ptr(logp), ptr(dlogp), B, V, ptr(out), V, stream_ptr()), "lsm_bwd")
+    return out
+
+
+def clip_sgd_step(params, grads, buf, lr_dev, *, momentum=0.9, max_norm=0.5, rng=None):
+    """In-place update of flat fp32 arenas; returns the pre-clip norm tensor [1]."""
+    _lib.require_gpu()
+    partials = torch.empty(1024, dtype=torch.float32, device=params.device)
+    norm = torch.empty(1, dtype=torch.float32, device=params.device)
+    check(load().slnlp_clip_sgd_step(ptr(params), ptr(grads), ptr(buf), params.numel(), ptr(lr_dev), momentum,
+                                     max_norm, ptr(partials), ptr(norm), ptr(rng), stream_ptr()), "clip_sgd_step")
+    return norm
+
+
+def dropout_mask(R, C_, p, site, rng):
+    _lib.require_gpu()
+    out = torch.empty(R, C_, dtype=torch.float32, device=rng.device)
+    check(load().slnlp_dropout_mask(ptr(out), R, C_, p, site, ptr(rng), stream_ptr()), "dropout_mask")
+    return out

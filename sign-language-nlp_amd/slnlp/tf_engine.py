@@ -1,0 +1,173 @@
+"""Host-side owner of one Transformer plan (libslnlp ``slnlp_tf_*``).
+
+PyTorch is plumbing here: it allocates the flat parameter / gradient / momentum
+arenas and the activation workspace in HBM and provides the stream; the layout,
+the launch sequence and all arithmetic live in the HIP library.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import TfBuffers, TfConfig, check, load, ptr, stream_ptr
+
+
+def positional_table(max_len, d_model):
+    """Sinusoidal table, same arithmetic (torch fp32 ops) as
+    /root/reference/model/component/positional_encoding.py:27-35 -> bit-identical
+    to the reference's ``pe`` buffer.  Shape [max_len, d_model]."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def make_config(E, H, N, F, Vs, Vt, B, S, pad_src=1, pad_tgt=1, dropout=0.0, precision=3):
+    return TfConfig(E, H, N, F, Vs, Vt, B, S, pad_src, pad_tgt, float(dropout), precision)
+
+
+def layout(cfg):
+    """[(name, shape tuple, offset in floats)] in reference state_dict order + arena size.
+    Pure host query: works without a GPU."""
+    lib = load()
+    n = lib.slnlp_tf_num_params(C.byref(cfg))
+    if n < 0:
+        check(1, "tf_num_params")
+    out = []
+    for i in range(n):
+        name = C.create_string_buffer(128)
+        shape = (C.c_int64 * 2)()
+        ndim, off = C.c_int32(0), C.c_int64(0)
+        check(lib.slnlp_tf_param_info(C.byref(cfg), i, name, C.byref(shape), C.byref(ndim), C.byref(off)),
+              "tf_param_info")
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value)), int(off.value)))
+    return out, int(lib.slnlp_tf_arena_floats(C.byref(cfg)))
+
+
+class TransformerEngine:
+    """One plan = one (config, max batch) on one GPU / one stream."""
+
+    def __init__(self, cfg, device="cuda", seed=0, max_len=5000):
+        _lib.require_gpu()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.entries, self.arena_floats = layout(cfg)
+        dev = self.device
+        self.params = torch.zeros(self.arena_floats, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.momentum = torch.zeros_like(self.params)
+        self.pe = positional_table(max_len, cfg.E).to(dev)          # [max_len, E]
+        ws = int(load().slnlp_tf_workspace_bytes(C.byref(cfg)))
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+        self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.logp = torch.empty(cfg.B, cfg.Vt, dtype=torch.float32, device=dev)
+        bufs = TfBuffers(ptr(self.params), ptr(self.grads), ptr(self.momentum), ptr(self.pe), ptr(self.workspace),
+                         ptr(self.rng), ptr(self.lr), ptr(self.scalars))
+        handle = C.c_void_p()
+        check(load().slnlp_tf_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "tf_create")
+        self.handle = handle
+        self._graph_key = None
+        self._xbuf = self._ybuf = None
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                load().slnlp_tf_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    # ---- parameter access ------------------------------------------------
+    def views(self, arena=None):
+        """name -> tensor view into ``arena`` (default: the parameter arena)."""
+        arena = self.params if arena is None else arena
+        out = {}
+        for name, shape, off in self.entries:
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = arena[off:off + n].view(*shape)
+        return out
+
+    def load_state(self, sd):
+        v = self.views()
+        for k, t in v.items():
+            t.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32))
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    # ---- compute -----------------------------------------------------------
+    def forward(self, X, y, train=False):
+        """X int64 [B,S], y int64 [B] on the device -> log-probs [B,Vt] (a view
+        of the engine's output buffer, valid until the next call)."""
+        B = X.shape[0]
+        X = X.contiguous()
+        y = y.contiguous()
+        self._keep = (X, y)  # backward reads the ids again
+        check(load().slnlp_tf_forward(self.handle, ptr(X), ptr(y), B, int(train), ptr(self.logp), stream_ptr()),
+              "tf_forward")
+        return self.logp[:B]
+
+    def seed_dlogp(self, dlogp):
+        check(load().slnlp_tf_seed_dlogp(self.handle, ptr(dlogp.contiguous()), stream_ptr()), "tf_seed_dlogp")
+
+    def backward(self):
+        check(load().slnlp_tf_backward(self.handle, stream_ptr()), "tf_backward")
+
+    def optim(self, momentum=0.9, max_norm=0.5):
+        check(load().slnlp_tf_optim(self.handle, momentum, max_norm, stream_ptr()), "tf_optim")
+
+    def train_step(self, X, y, momentum=0.9, max_norm=0.5):
+        """Eager fwd + criterion + bwd + clip + SGD; returns log-probs view.
+        loss / grad-norm stay on the device in ``scalars[0:2]``."""
+        B = X.shape[0]
+        X = X.contiguous()
+        y = y.contiguous()
+        self._keep = (X, y)
+        check(load().slnlp_tf_train_step(self.handle, ptr(X), ptr(y), B, momentum, max_norm, ptr(self.logp),
+                                         stream_ptr()), "tf_train_step")
+        return self.logp[:B]
+
+    def train_step_graph(self, X, y, momentum=0.9, max_norm=0.5):
+        """Same step replayed from a captured hipGraph (one per batch size):
+        the batch is copied into fixed staging buffers, then one graph launch."""
+        B = X.shape[0]
+        key = (B, float(momentum), float(max_norm))
+        if self._xbuf is None:
+            self._xbuf = torch.empty(self.cfg.B, self.cfg.S, dtype=torch.int64, device=self.device)
+            self._ybuf = torch.empty(self.cfg.B, dtype=torch.int64, device=self.device)
+        xb, yb = self._xbuf[:B], self._ybuf[:B]
+        xb.copy_(X)
+        yb.copy_(y)
+        st = stream_ptr()
+        if st == 0:
+            raise RuntimeError("train_step_graph needs a non-default stream (use torch.cuda.stream(...))")
+        if self._graph_key != key:
+            check(load().slnlp_tf_graph_capture_train(self.handle, ptr(xb), ptr(yb), B, momentum, max_norm,
+                                                      ptr(self.logp), st), "tf_graph_capture_train")
+            self._graph_key = key
+        check(load().slnlp_tf_graph_launch(self.handle, st), "tf_graph_launch")
+        return self.logp[:B]
+
+    def tap(self, name, rows, cols):
+        out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
+        n = C.c_int64(0)
+        check(load().slnlp_tf_tap(self.handle, name.encode(), ptr(out), out.numel(), C.byref(n), stream_ptr()),
+              "tf_tap")
+        assert n.value == rows * cols, (name, n.value, rows, cols)
+        return out
+
+    @property
+    def loss(self):
+        return float(self.scalars[0])
+
+    @property
+    def grad_norm(self):
+        return float(self.scalars[1])

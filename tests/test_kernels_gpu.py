@@ -1,0 +1,263 @@
+"""GPU parity of each HIP kernel, called through the C ABI (slnlp.ops ->
+libslnlp.so), against fp64 / plain-torch fp32 references on the same seeded
+inputs.  Tolerances: precision 3 (split-bf16 MFMA) 5e-5 of the tensor scale;
+precision 1 (single bf16 pass) 2e-2; exact-fp32 kernels 2e-5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from slnlp import ops as o
+    return o
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+TOL = {3: 5e-5, 1: 2e-2}
+
+GEMM_SHAPES = [(2400, 512, 512), (50, 202, 512), (50, 512, 202), (64, 64, 32), (7, 5, 3), (130, 70, 100),
+               (2400, 1536, 512), (202, 512, 50)]
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_layouts(ops, layout, M, N, K, prec):
+    # logical: C[m,n] = sum_k A(m,k) B(n,k)
+    Al, Bl = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = (Al.double() @ Bl.double().T)
+    a_k = layout in ("fwd", "dgrad")
+    b_k = layout == "fwd"
+    A = (Al if a_k else Al.T.contiguous()).cuda()
+    B = (Bl if b_k else Bl.T.contiguous()).cuda()
+    out = ops.gemm(A, B, M=M, N=N, K=K, a_kmajor=a_k, b_kmajor=b_k, precision=prec)
+    assert rel(out, ref) < TOL[prec] * max(1.0, math.sqrt(K / 64))
+
+
+def test_gemm_padded_ld_and_views(ops):
+    # generator backward shapes: dlogits [B, Vp=204] with V=202 valid columns, garbage (NaN) in the pad
+    Bt, V, Vp, E = 50, 202, 204, 512
+    dl = torch.full((Bt, Vp), float("nan"))
+    dl[:, :V] = rnd(Bt, V, seed=3)
+    W, x = rnd(V, E, seed=4), rnd(Bt, E, seed=5)
+    dlc, Wc, xc = dl.cuda(), W.cuda(), x.cuda()
+    dx = ops.gemm(dlc, Wc, M=Bt, N=E, K=V, a_kmajor=True, b_kmajor=False, lda=Vp, ldb=E)
+    assert rel(dx, dl[:, :V].double() @ W.double()) < 1e-4
+    db = torch.empty(V, device="cuda")
+    dW = ops.gemm(dlc, xc, M=V, N=E, K=Bt, a_kmajor=False, b_kmajor=False, lda=Vp, ldb=E, rowsum_a=db)
+    assert rel(dW, dl[:, :V].double().T @ x.double()) < 1e-4
+    assert rel(db, dl[:, :V].double().sum(0)) < 1e-4
+    # weight-row slice as B operand (decoder v-projection: rows 2E..3E of in_proj)
+    Win, t = rnd(3 * E, E, seed=6).cuda(), rnd(Bt, E, seed=7).cuda()
+    v = ops.gemm(t, Win[2 * E:], M=Bt, N=E, K=E)
+    assert rel(v, t.double().cpu() @ Win[2 * E:].double().cpu().T) < 1e-4
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 300, 200, 96
+    A, B, bias, R, G = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    base = A.double() @ B.double().T
+    Ac, Bc = A.cuda(), B.cuda()
+    out = ops.gemm(Ac, Bc, M=M, N=N, K=K, bias=bias.cuda(), relu=True, resid=R.cuda())
+    assert rel(out, torch.relu(base + bias.double()) + R.double()) < 1e-4
+    out = ops.gemm(Ac, Bc, M=M, N=N, K=K, gate=G.cuda(), gate_scale=1.25)
+    assert rel(out, base * (G.double() > 0) * 1.25) < 1e-4
+    # in-place residual (resid aliases C), as the dmem accumulation uses it
+    Cbuf = R.cuda().clone()
+    ops.gemm(Ac, Bc, M=M, N=N, K=K, out=Cbuf, resid=Cbuf)
+    assert rel(Cbuf, base + R.double()) < 1e-4
+    # dropout epilogue reproduces the mask the dump kernel reports
+    rng = ops.make_rng(seed=1234, step=7)
+    p = 0.3
+    mask = ops.dropout_mask(M, N, p, 5, rng).cpu().double()
+    out = ops.gemm(Ac, Bc, M=M, N=N, K=K, bias=bias.cuda(), drop_p=p, drop_site=5, rng=rng, resid=R.cuda())
+    assert rel(out, (base + bias.double()) * mask / (1 - p) + R.double()) < 1e-4
+    assert abs(float(mask.mean()) - (1 - p)) < 0.01
+
+
+def test_dropout_mask_statistics(ops):
+    rng = ops.make_rng(seed=99, step=0)
+    m = ops.dropout_mask(2048, 512, 0.1, 3, rng)
+    assert abs(float(m.mean()) - 0.9) < 2e-3
+    m2 = ops.dropout_mask(2048, 512, 0.1, 4, rng)          # different site -> different mask
+    assert float((m != m2).float().mean()) > 0.1
+    rng2 = ops.make_rng(seed=99, step=1)                   # next step -> different mask
+    assert float((m != ops.dropout_mask(2048, 512, 0.1, 3, rng2)).float().mean()) > 0.1
+    assert torch.equal(m, ops.dropout_mask(2048, 512, 0.1, 3, rng))   # deterministic
+
+
+def _mha_ref(qkv, ids, pad, B, S, H, dh, causal, mask=None, p=0.0):
+    E = H * dh
+    x = qkv.view(S, B, 3, H, dh)
+    q, k, v = [x[:, :, i].permute(1, 2, 0, 3) for i in range(3)]           # [B,H,S,dh]
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    blocked = torch.zeros(B, 1, S, S, dtype=torch.bool)
+    if causal:
+        blocked = blocked | torch.triu(torch.ones(S, S, dtype=torch.bool), 1)
+    if ids is not None:
+        blocked = blocked | (ids == pad).view(B, 1, 1, S)
+    pr = torch.softmax(sc.masked_fill(blocked, float("-inf")), -1)
+    pd = pr if mask is None else pr * mask / (1 - p)
+    ctx = (pd @ v).permute(2, 0, 1, 3).reshape(S * B, E)
+    return ctx, pr
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(50, 48, 8, 64), (4, 12, 4, 8), (50, 48, 4, 32), (9, 64, 4, 256), (50, 48, 8, 16),
+                                      (3, 37, 2, 128)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attn_self(ops, B, S, H, dh, p):
+    E = H * dh
+    qkv = rnd(S * B, 3 * E, seed=1).double().requires_grad_(True)
+    lengths = torch.randint(max(1, S // 6), S + 1, (B,), generator=torch.Generator().manual_seed(3))
+    ids = torch.full((B, S), 5, dtype=torch.long)
+    ids[torch.arange(S)[None, :] >= lengths[:, None]] = 1
+    rng = ops.make_rng(seed=5, step=2)
+    mask = ops.dropout_mask(B * H * S, S, p, 17, rng).cpu().double().view(B, H, S, S) if p > 0 else None
+    ctx_ref, pr_ref = _mha_ref(qkv, ids, 1, B, S, H, dh, True, mask, p)
+    dctx = rnd(S * B, E, seed=2)
+    ctx_ref.backward(dctx.double())
+    qc = qkv.detach().float().cuda()
+    ctx, probs = ops.attn_self_fwd(qc, ids.cuda(), 1, B=B, S=S, H=H, dh=dh, causal=True, drop_p=p, drop_site=17, rng=rng)
+    assert rel(probs, pr_ref) < 2e-5
+    assert rel(ctx, ctx_ref) < 2e-5
+    dqkv = ops.attn_self_bwd(qc, probs, dctx.cuda(), B=B, S=S, H=H, dh=dh, drop_p=p, drop_site=17, rng=rng)
+    assert rel(dqkv, qkv.grad) < 5e-5
+
+
+def test_attn_self_fully_masked_row_is_nan(ops):
+    # a sequence whose first key is <pad>: query 0 has no visible key -> NaN like torch
+    B, S, H, dh = 2, 8, 2, 8
+    qkv = rnd(S * B, 3 * H * dh, seed=1).cuda()
+    ids = torch.full((B, S), 5, dtype=torch.long)
+    ids[1, 0] = 1
+    ctx, probs = ops.attn_self_fwd(qkv, ids.cuda(), 1, B=B, S=S, H=H, dh=dh)
+    assert torch.isnan(probs[1, :, 0]).all() and not torch.isnan(probs[0]).any()
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(50, 48, 8, 64), (4, 12, 4, 8), (7, 64, 4, 256), (50, 48, 8, 16)])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_attn_cross(ops, B, S, H, dh, p):
+    E = H * dh
+    q = rnd(B, E, seed=1).double().requires_grad_(True)
+    kv = rnd(S * B, 2 * E, seed=2).double().requires_grad_(True)
+    rng = ops.make_rng(seed=8, step=1)
+    mask = ops.dropout_mask(B * H, S, p, 9, rng).cpu().double().view(B, H, 1, S) if p > 0 else None
+    qh = q.view(B, H, 1, dh)
+    k = kv[:, :E].reshape(S, B, H, dh).permute(1, 2, 0, 3)
+    v = kv[:, E:].reshape(S, B, H, dh).permute(1, 2, 0, 3)
+    pr = torch.softmax(qh @ k.transpose(-1, -2) / math.sqrt(dh), -1)       # [B,H,1,S]
+    pd = pr if mask is None else pr * mask / (1 - p)
+    ctx_ref = (pd @ v).reshape(B, E)
+    dctx = rnd(B, E, seed=3)
+    ctx_ref.backward(dctx.double())
+    qc, kvc = q.detach().float().cuda(), kv.detach().float().cuda()
+    ctx, probs = ops.attn_cross_fwd(qc, kvc, B=B, S=S, H=H, dh=dh, drop_p=p, drop_site=9, rng=rng)
+    assert rel(probs.view(B, H, 1, S), pr) < 2e-5
+    assert rel(ctx, ctx_ref) < 2e-5
+    dq, dkv = ops.attn_cross_bwd(qc, kvc, probs, dctx.cuda(), B=B, S=S, H=H, dh=dh, drop_p=p, drop_site=9, rng=rng)
+    assert rel(dq, q.grad) < 5e-5
+    assert rel(dkv, kv.grad) < 5e-5
+
+
+@pytest.mark.parametrize("rows,E", [(2400, 512), (50, 128), (4, 32), (2400, 1024), (257, 260)])
+def test_layernorm(ops, rows, E):
+    x = rnd(rows, E, seed=1, scale=3.0).double().requires_grad_(True)
+    g = (1 + 0.1 * rnd(E, seed=2)).double().requires_grad_(True)
+    b = (0.1 * rnd(E, seed=3)).double().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(x, (E,), g, b, 1e-5)
+    dy, add = rnd(rows, E, seed=4), rnd(rows, E, seed=5)
+    y_ref.backward(dy.double())
+    y, stats = ops.layernorm_fwd(x.detach().float().cuda(), g.detach().float().cuda(), b.detach().float().cuda())
+    assert rel(y, y_ref) < 2e-5
+    rng = ops.make_rng(seed=3, step=3)
+    p = 0.2
+    dx, dxd, dg, db = ops.layernorm_bwd(dy.cuda(), x.detach().float().cuda(), g.detach().float().cuda(), stats,
+                                        add_to_dx=add.cuda(), want_drop=True, drop_p=p, drop_site=11, rng=rng)
+    assert rel(dx, x.grad + add.double()) < 5e-5
+    assert rel(dg, g.grad) < 5e-5 and rel(db, b.grad) < 5e-5
+    mask = ops.dropout_mask(rows, E, p, 11, rng).cpu().double()
+    assert rel(dxd, (x.grad + add.double()) * mask / (1 - p)) < 5e-5
+
+
+def test_embed(ops):
+    B, S, E, V = 50, 48, 128, 300
+    from slnlp.tf_engine import positional_table
+    table = rnd(V, E, seed=1).double().requires_grad_(True)
+    pe = positional_table(64, E)
+    ids = torch.randint(0, 40, (B, S), generator=torch.Generator().manual_seed(2))   # many duplicates
+    ref = table[ids.T] * math.sqrt(E) + pe[:S].double().unsqueeze(1)                 # [S,B,E]
+    dx = rnd(S * B, E, seed=3)
+    ref.reshape(S * B, E).backward(dx.double())
+    out = ops.embed_fwd(ids.cuda(), table.detach().float().cuda(), pe.cuda(), B=B, S=S)
+    assert rel(out, ref.reshape(S * B, E)) < 1e-6
+    dt = ops.embed_bwd(ids.cuda(), dx.cuda(), B=B, S=S, V=V)
+    assert rel(dt, table.grad) < 1e-5
+    assert float(dt[40:].abs().max()) == 0.0                # untouched rows are exactly zero
+    dt2 = ops.embed_bwd(ids.cuda(), dx.cuda(), B=B, S=S, V=V)
+    assert torch.equal(dt, dt2)                             # deterministic (no atomics)
+    # dropout path + <pad>-target NaN row
+    rng = ops.make_rng(seed=4, step=0)
+    p = 0.1
+    mask = ops.dropout_mask(S * B, E, p, 1, rng).cpu().double()
+    out = ops.embed_fwd(ids.cuda(), table.detach().float().cuda(), pe.cuda(), B=B, S=S, drop_p=p, drop_site=1, rng=rng)
+    assert rel(out, ref.reshape(S * B, E).detach() * mask / (1 - p)) < 1e-6
+    y = torch.tensor([5, 1, 7])
+    t0 = ops.embed_fwd(y.cuda(), table.detach().float().cuda(), pe.cuda(), B=3, S=1, nan_idx=1)
+    assert torch.isnan(t0[1]).all() and not torch.isnan(t0[[0, 2]]).any()
+
+
+def test_lsm_nll(ops):
+    from oracle import train_ref
+    B, V = 50, 202
+    logits = rnd(B, V, seed=1, scale=2.0).double().requires_grad_(True)
+    y = torch.randint(2, V, (B,), generator=torch.Generator().manual_seed(2))
+    y[3] = 1
+    y[17] = 1                                                # ignored targets (== pad)
+    logp_ref = torch.log_softmax(logits, -1)
+    loss_ref = train_ref.cross_entropy_on_logprobs(logp_ref, y, 1)
+    loss_ref.backward()
+    logp, loss, dl = ops.lsm_nll(logits.detach().float().cuda(), y.cuda(), 1)
+    assert rel(logp, logp_ref) < 1e-6
+    assert abs(float(loss) - float(loss_ref)) < 1e-6 * abs(float(loss_ref))
+    assert rel(dl, logits.grad) < 1e-5
+    # external-criterion path: d logits from d logp
+    dlogp = rnd(B, V, seed=5)
+    lp = logp_ref.detach().clone().requires_grad_(True)
+    lg = logits.detach().clone().requires_grad_(True)
+    torch.log_softmax(lg, -1).backward(dlogp.double())
+    assert rel(ops.lsm_bwd(logp, dlogp.cuda()), lg.grad) < 1e-5
+
+
+def test_clip_sgd(ops):
+    from oracle import train_ref
+    n = 1 << 20
+    p0, g, buf0 = rnd(n, seed=1), rnd(n, seed=2, scale=1e-3), rnd(n, seed=3, scale=1e-3)
+    for max_norm in (0.5, 1e9, 0.0):
+        P, G, Bf = p0.cuda().clone(), g.cuda().clone(), buf0.cuda().clone()
+        lr = torch.tensor([0.01], device="cuda")
+        rng = ops.make_rng(1, 41)
+        norm = ops.clip_sgd_step(P, G, Bf, lr, momentum=0.9, max_norm=max_norm, rng=rng)
+        gg = [g.clone()]
+        total = torch.sqrt((g.double() ** 2).sum()).float()
+        if max_norm > 0:
+            train_ref.clip_grad_norm(gg, max_norm)
+        params, bufs = {"w": p0.clone()}, {"w": buf0.clone()}
+        train_ref.sgd_momentum_step(params, {"w": gg[0]}, bufs, 0.01, 0.9)
+        assert abs(float(norm) - float(total)) < 1e-5 * float(total)
+        assert rel(P, params["w"]) < 1e-6 and rel(Bf, bufs["w"]) < 1e-6
+        assert int(rng[1]) == 42                            # dropout step counter advanced
