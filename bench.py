@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- train seq/s of the Transformer hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+
+One "step" = one full training step (forward + CrossEntropyLoss + backward +
+clip_grad_norm_(0.5) + SGD-momentum) of BASELINE.json configs[1]
+(Transformer d_model=512, 6 layers, 8 heads, dim_feedforward=512, batch=50,
+len=48, |src|=3000, |tgt|=202, dropout 0.1) on one batch of synthetic ASL-Phono
+token ids that is already resident in HBM, replayed from a captured hipGraph.
+N>1: one process per GPU, each running its own independent fit (the reference's
+only parallelism is the embarrassingly parallel (candidate x fold) grid,
+SURVEY.md section 8e) -> weak scaling, no data-path collective.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1] -- the config `metric` is quoted on
+    "cfg2": dict(E=512, H=8, N=6, F=512, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
+    # configs[0] -- the reference's own CPU-runnable debug case (.vscode/launch.json:26)
+    "cfg1": dict(E=128, H=4, N=2, F=256, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
+    "e1024": dict(E=1024, H=8, N=6, F=512, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
+}
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+MOMENTUM, MAX_NORM, LR = 0.9, 0.5, 0.01
+
+
+def fwd_flops_per_seq(c):
+    """SURVEY.md section 8d contract: 2mnk per GEMM, attention dense, T=1."""
+    E, F, N, S, V = c["E"], c["F"], c["N"], c["S"], c["Vt"]
+    enc = N * S * (8 * E * E + 4 * S * E + 4 * E * F)
+    dec = N * (12 * E * E + 4 * E + 4 * S * E * E + 4 * S * E + 4 * E * F)
+    return enc + dec + 2 * E * V
+
+
+def build_sd(c, seed):
+    from slnlp import synth, tf_engine as te
+    cfg = te.make_config(c["E"], c["H"], c["N"], c["F"], c["Vs"], c["Vt"], c["B"], c["S"], 1, 1, c["dropout"],
+                         c.get("precision", 3))
+    ents, _ = te.layout(cfg)
+    w = synth.make_weights([(n, s) for n, s, _ in ents], seed=seed)
+    return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
+
+
+def cpu_baseline(c, sd, X, y, budget_s=20.0):
+    """The oracle (CPU port of the reference step) timed on this host's cores on a bounded sample."""
+    from oracle import train_ref, transformer_ref as tr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    masks = None  # dropout-free arithmetic: the reference's bernoulli cost is not charged to the CPU side
+    fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=c["H"], num_layers=c["N"], p_drop=0.0, masks=masks)
+    trn = train_ref.Trainer(sd, fwd, pad_tgt=1, lr=LR, momentum=MOMENTUM, max_norm=MAX_NORM)
+    B = c["B"]
+    trn.step(X[:B], y[:B], None)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        i = (n % (X.shape[0] // B)) * B
+        trn.step(X[i:i + B], y[i:i + B], None)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": round(n * B / dt, 2), "unit": "seq/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of batch {B} ({dt:.1f} s), torch fp32, {cores} threads, dropout off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", type=int, default=3, choices=[1, 3])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only compute path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from slnlp import synth, tf_engine as te
+    c = dict(WORKLOADS[args.workload], precision=args.precision)
+    B, S = c["B"], c["S"]
+    cfg, sd = build_sd(c, seed=1 + rank)
+    eng = te.TransformerEngine(cfg, device=dev, seed=1 + rank)
+    eng.load_state(sd)
+    eng.set_lr(LR)
+    # synthetic dataset, resident in HBM before the timed region (SURVEY.md section 8d recipe)
+    n_batches = 200
+    Xn, Ln, yn = synth.make_batch(n_batches * B, S, c["Vs"], c["Vt"], seed=1 + rank)
+    Xd, yd = torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev)
+
+    stream = torch.cuda.Stream(device=dev)
+    step_fn = eng.train_step if args.eager else eng.train_step_graph
+
+    def run(k0, k):
+        for i in range(k0, k0 + k):
+            j = (i % n_batches) * B
+            step_fn(Xd[j:j + B], yd[j:j + B], MOMENTUM, MAX_NORM)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        run(0, args.warmup)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(args.warmup, args.steps)
+        ev1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    loss_end = eng.loss
+    if world > 1:
+        t = torch.tensor([wall], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t)
+
+    out = None
+    if rank == 0:
+        seqs = world * B * args.steps
+        step_flops = 3.0 * fwd_flops_per_seq(c) * B
+        ms_event = ev_ms / args.steps           # HIP events on the launch stream, rank 0
+        achieved = step_flops / (ms_event * 1e-3) / 1e12
+        # parity on a held-out batch (eval mode) against the CPU oracle
+        from oracle import transformer_ref as tr
+        cfg0, sd0 = build_sd(c, seed=1)
+        e2 = te.TransformerEngine(cfg0, device=dev)
+        e2.load_state(sd0)
+        Xe, ye = torch.from_numpy(Xn[:B]), torch.from_numpy(yn[:B])
+        lp = e2.forward(Xe.to(dev), ye.to(dev)).cpu()
+        lo = tr.forward(sd0, Xe, ye, num_heads=c["H"], num_layers=c["N"])
+        parity = {"argmax_agree": float((lp.argmax(-1) == lo.argmax(-1)).float().mean()),
+                  "logp_rel_err": float((lp - lo).abs().max() / lo.abs().max())}
+        out = {
+            "metric": "train seq/s (batch=50,len=48)", "value": round(seqs / wall, 1), "unit": "seq/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
+            "data": "synthetic (numpy seed recipe: ids, lengths, labels; seed-recipe weights)",
+            "config": {"workload": f"{args.workload}: Transformer train step E{c['E']} H{c['H']} N{c['N']} F{c['F']} "
+                                   f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
+                                   "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
+                       "launch": "eager" if args.eager else "hipGraph replay", "per_gpu": "independent fit (grid shard)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": None,
+                         "launch": "one graph replay = one train step", "flops_per_launch": step_flops,
+                         "ms_per_launch_hip_events": round(ms_event, 4)},
+            "parity": parity, "final_loss": round(loss_end, 5),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn))
+            out["gpu_over_cpu"] = round(out["value"] / world / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
