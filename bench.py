@@ -59,7 +59,8 @@ def build_sd(c, seed):
 def cpu_baseline(c, sd, X, y, budget_s=20.0):
     """The oracle (CPU port of the reference step) timed on this host's cores on a bounded sample."""
     from oracle import train_ref, transformer_ref as tr
-    cores = os.cpu_count() or 1
+    # the GPU box gives this process a CPU share (16 cores per GPU), not the whole host
+    cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     masks = None  # dropout-free arithmetic: the reference's bernoulli cost is not charged to the CPU side
     fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=c["H"], num_layers=c["N"], p_drop=0.0, masks=masks)

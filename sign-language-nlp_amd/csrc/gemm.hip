@@ -4,14 +4,21 @@
 //
 // All tensors are fp32 in HBM.  Tiles are converted to bf16 on the way into
 // LDS; with precision 3 each fp32 value x is split into hi = bf16(x) and
-// lo = bf16(x - hi) and the product is accumulated as Ahi*Bhi + Ahi*Blo +
-// Alo*Bhi on v_mfma_f32_16x16x32_bf16 with fp32 accumulators (~2e-5 relative
-// error: what the 1e-3 logits bar of the reference parity needs; single-pass
-// bf16 measures 5e-3 and flips argmaxes).
+// lo = bf16(x - hi) and the product is accumulated as Alo*Bhi + Ahi*Blo +
+// Ahi*Bhi on v_mfma_f32_16x16x32_bf16 with fp32 accumulators (~2e-5 relative
+// error: what the reference-parity bar of 1e-3 on logits needs; a single bf16
+// pass measures 5e-3 and flips argmaxes).
 //
-// Block = 256 threads = 4 waves (2x2), tile 64x64, K-step 32; each wave owns a
-// 32x32 quadrant = 2x2 MFMA tiles.  Next K-tile is fetched into registers
-// while the current one is consumed from LDS.
+// Shapes here are small (M = 2400 or 50 tokens, K,N <= 1536) and every launch
+// sits on a dependent chain, so the kernel is built for per-block LATENCY:
+//  * 64 x BN tile (BN = 64, or 16 to spread a skinny problem over more CUs),
+//    K-step 64: K = 512 is 8 steps;
+//  * the fp32 tiles of steps t+1 AND t+2 are in flight in registers while step
+//    t is consumed from LDS (HBM/L2 latency is ~1 us, a step's MFMA work ~0.1 us);
+//  * k-major operands are stored [row][k] and read as 16-byte fragments;
+//    m-major operands (dgrad's W, both wgrad operands) are stored [k][row]
+//    with 8-byte vector writes and read with ds_read_b64_tr_b16, the CDNA4
+//    transposing LDS read -- no 2-byte scatter, no transposed copies in HBM.
 //
 // Replaces the matmuls inside nn.Linear / MultiheadAttention in/out
 // projections / nn.LSTM / nn.GRU that the reference reaches at
@@ -22,10 +29,12 @@
 namespace slnlp {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BM = 64, BN = 64, BKT = 32;
-constexpr int LDS_LD = 40;  // bf16 elements per LDS row (32 + 8 pad -> 80 B, keeps 16 B alignment)
+constexpr int BM = 64, BKT = 64;
+constexpr int KLD = BKT + 8;  // [row][k] image: 72 bf16 = 144 B rows (16-B aligned fragments)
 
 struct GemmParams {
     slnlp_gemm_args a;
@@ -38,173 +47,230 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     __bf16 b = (__bf16)x;
     return __builtin_bit_cast(unsigned short, b);
 }
-__device__ __forceinline__ float bf2f(unsigned short h) {
-    return __uint_as_float(((unsigned)h) << 16);
-}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
-// Fetch this thread's two float4 of one operand's K-tile into registers.
-//  KMAJOR: tile is [64 rows][32 k], float4 runs along k.
-// !KMAJOR: tile is [32 k][64 rows], float4 runs along the row index.
-template <bool KMAJOR>
-__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, long ld, int vec_ok, int row0,
-                                           int nrows, int k0, int K, int tid, float4 (&r)[2]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int idx = tid + 256 * u;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KMAJOR) {
-            int row = row0 + (idx >> 3), k = k0 + ((idx & 7) << 2);
-            if (row < nrows && k < K) {
-                const float* src = P + (long)row * ld + k;
-                if (vec_ok) {
-                    v = *reinterpret_cast<const float4*>(src);
-                    if (k + 1 >= K) v.y = 0.f;
-                    if (k + 2 >= K) v.z = 0.f;
-                    if (k + 3 >= K) v.w = 0.f;
-                } else {
-                    v.x = src[0];
-                    if (k + 1 < K) v.y = src[1];
-                    if (k + 2 < K) v.z = src[2];
-                    if (k + 3 < K) v.w = src[3];
-                }
-            }
-        } else {
-            int k = k0 + (idx >> 4), row = row0 + ((idx & 15) << 2);
-            if (k < K && row < nrows) {
-                const float* src = P + (long)k * ld + row;
-                if (vec_ok) {
-                    v = *reinterpret_cast<const float4*>(src);
-                    if (row + 1 >= nrows) v.y = 0.f;
-                    if (row + 2 >= nrows) v.z = 0.f;
-                    if (row + 3 >= nrows) v.w = 0.f;
-                } else {
-                    v.x = src[0];
-                    if (row + 1 < nrows) v.y = src[1];
-                    if (row + 2 < nrows) v.z = src[2];
-                    if (row + 3 < nrows) v.w = src[3];
-                }
-            }
-        }
-        r[u] = v;
+// One operand tile = ROWS x 64(k) fp32.  NV float4 per thread.
+//  KMAJOR: element (row,k) at P + row*ld + k; float4 runs along k; 16 float4 per row.
+// !KMAJOR: element (row,k) at P + k*ld + row; float4 runs along row; ROWS/4 float4 per k.
+template <bool KMAJOR, int ROWS>
+struct TileIO {
+    static constexpr int NV = ROWS * BKT / 4 / 256;       // 4 (ROWS=64) or 1 (ROWS=16)
+    static constexpr int MLD = ROWS + 8;                  // [k][row] image row stride (bf16)
+    static constexpr int PLANE = KMAJOR ? ROWS * KLD : BKT * MLD;
+
+    __device__ static __forceinline__ void coords(int idx, int& row, int& k) {
+        if (KMAJOR) { row = idx >> 4; k = (idx & 15) << 2; }
+        else { k = idx / (ROWS / 4); row = (idx % (ROWS / 4)) << 2; }
     }
-}
 
-// Convert + store the fetched registers into the [plane][row][k] bf16 LDS image.
-template <int NSPLIT, bool KMAJOR>
-__device__ __forceinline__ void stash_tile(unsigned short* __restrict__ T, int tid, const float4 (&r)[2]) {
-    constexpr int PLANE = 64 * LDS_LD;
+    // Issue the loads of one K-tile.  Branch-free and with NO use of the loaded values: any use here
+    // (even zeroing a tail lane) makes hipcc wait vmcnt(0) right behind each load and serialises the
+    // whole prefetch.  Out-of-range coordinates are clamped to a valid address; stash() zeroes them.
+    template <bool VEC>
+    __device__ static __forceinline__ void fetch(const float* __restrict__ P, long ld, int row0, int nrows,
+                                                 int k0, int K, int tid, float4 (&r)[NV]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int idx = tid + 256 * u;
-        float x[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
-        unsigned short hi[4], lo[4];
+        for (int u = 0; u < NV; ++u) {
+            int row, k;
+            coords(tid + 256 * u, row, k);
+            row += row0;
+            k += k0;
+            if (VEC) {   // compile-time: the hot kernel has no control flow around its loads
+                const int rc = row < nrows ? row : 0, kc = k < K ? k : 0;
+                r[u] = *reinterpret_cast<const float4*>(KMAJOR ? P + (long)rc * ld + kc : P + (long)kc * ld + rc);
+            } else {
+                float x[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = f2bf(x[e]);
-            if (NSPLIT == 3) lo[e] = f2bf(x[e] - bf2f(hi[e]));
+                for (int e = 0; e < 4; ++e) {
+                    int rr = KMAJOR ? row : row + e, kk = KMAJOR ? k + e : k;
+                    rr = rr < nrows ? rr : 0;
+                    kk = kk < K ? kk : 0;
+                    x[e] = KMAJOR ? P[(long)rr * ld + kk] : P[(long)kk * ld + rr];
+                }
+                r[u] = make_float4(x[0], x[1], x[2], x[3]);
+            }
         }
-        if (KMAJOR) {
-            int row = idx >> 3, k = (idx & 7) << 2;
+    }
+
+    template <int NSPLIT>
+    __device__ static __forceinline__ void stash(unsigned short* __restrict__ T, int tid, const float4 (&r)[NV],
+                                                 int row0, int nrows, int k0, int K) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            int row, k;
+            coords(tid + 256 * u, row, k);
+            float x[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = row0 + (KMAJOR ? row : row + e), kk = k0 + (KMAJOR ? k + e : k);
+                if (!(rr < nrows && kk < K)) x[e] = 0.f;      // edge / K-tail zero fill (v_cndmask)
+                hi[e] = f2bf(x[e]);
+                if (NSPLIT == 3) lo[e] = f2bf(x[e] - bf2f(hi[e]));
+            }
+            const int off = KMAJOR ? row * KLD + k : k * MLD + row;   // both 8-B aligned
             uint2 w;
             w.x = hi[0] | ((unsigned)hi[1] << 16);
             w.y = hi[2] | ((unsigned)hi[3] << 16);
-            *reinterpret_cast<uint2*>(T + row * LDS_LD + k) = w;
+            *reinterpret_cast<uint2*>(T + off) = w;
             if (NSPLIT == 3) {
                 w.x = lo[0] | ((unsigned)lo[1] << 16);
                 w.y = lo[2] | ((unsigned)lo[3] << 16);
-                *reinterpret_cast<uint2*>(T + PLANE + row * LDS_LD + k) = w;
-            }
-        } else {
-            int k = idx >> 4, row = (idx & 15) << 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                T[(row + e) * LDS_LD + k] = hi[e];
-                if (NSPLIT == 3) T[PLANE + (row + e) * LDS_LD + k] = lo[e];
+                *reinterpret_cast<uint2*>(T + PLANE + off) = w;
             }
         }
     }
+
+    // MFMA 16x16x32 operand fragment of tile rows [r0, r0+16), k in [kk*32, kk*32+32):
+    // lane l holds (row r0 + (l&15), k = kk*32 + 8*(l>>4) + j), j = 0..7.
+    __device__ static __forceinline__ bf16x8 frag(const unsigned short* __restrict__ T, int r0, int kk, int lane) {
+        if (KMAJOR) {
+            return *reinterpret_cast<const bf16x8*>(T + (r0 + (lane & 15)) * KLD + kk * 32 + ((lane >> 4) << 3));
+        } else {
+            // transposing read: lane (i = l&15; q = i>>2, p = i&3) addresses k-row q, columns 4p..4p+3 of a
+            // 4(k) x 16(row) block and receives the 4 k-values of column i.
+            const int i = lane & 15, kb = kk * 32 + ((lane >> 4) << 3) + (i >> 2);
+            const unsigned short* p0 = T + kb * MLD + r0 + ((i & 3) << 2);
+            typedef __attribute__((address_space(3))) s16x4* lds_p;
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + 4 * MLD));
+            const s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    // bf16(hi)+bf16(lo) value of tile element (row, k) -- for the fused bias-gradient row sums
+    template <int NSPLIT>
+    __device__ static __forceinline__ float value(const unsigned short* __restrict__ T, int row, int k) {
+        const int off = KMAJOR ? row * KLD + k : k * MLD + row;
+        float v = bf2f(T[off]);
+        if (NSPLIT == 3) v += bf2f(T[PLANE + off]);
+        return v;
+    }
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0),
+// which would drain the register prefetch of the next two K-tiles at every step.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
-template <int NSPLIT, bool AK, bool BK>
+template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-    constexpr int PLANE = 64 * LDS_LD;
+    using TA = TileIO<AK, BM>;
+    using TB = TileIO<BK, BNT>;
     constexpr int NP = (NSPLIT == 3) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned short As[NP * PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP * PLANE];
+    constexpr int MT = (BNT == 64) ? 2 : 1;  // 16x16 tiles per wave along M
+    constexpr int NT = (BNT == 64) ? 2 : 1;  // ... along N
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP * TA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP * TB::PLANE];
+    __shared__ float rsum[4][BM];
 
     const slnlp_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    // BNT=64: waves 2x2, each 32x32.  BNT=16: waves 4x1, each 16x16.
+    const int wm0 = (BNT == 64) ? (wave >> 1) * 32 : wave * 16;
+    const int wn0 = (BNT == 64) ? (wave & 1) * 32 : 0;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each);
+    // remap so each XCD owns a contiguous run of tiles (all column blocks of a few row blocks): its
+    // L2 then holds the whole B operand plus a few A panels instead of every panel of both.
+    int bx, by;
+    {
+        const int nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        by = t / gridDim.x;
+        bx = t - by * gridDim.x;
+    }
+    const int bm0 = by * BM, bn0 = bx * BNT;
     const int M = g.M, N = g.N, K = g.K;
 
-    f32x4 acc[2][2];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bool do_rowsum = (g.rowsum_a != nullptr) && (blockIdx.x == 0);
+    const bool do_rowsum = (g.rowsum_a != nullptr) && (bx == 0);
     float rowsum = 0.f;
 
-    float4 ra[2], rb[2];
-    fetch_tile<AK>(g.A, g.lda, p.a_vec, bm0, M, 0, K, tid, ra);
-    fetch_tile<BK>(g.B, g.ldb, p.b_vec, bn0, N, 0, K, tid, rb);
-
     const int ktiles = (K + BKT - 1) / BKT;
-    const int frow = lane & 15, fk = (lane >> 4) << 3;
-    for (int kt = 0; kt < ktiles; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-        stash_tile<NSPLIT, AK>(As, tid, ra);
-        stash_tile<NSPLIT, BK>(Bs, tid, rb);
-        __syncthreads();
-        if (kt + 1 < ktiles) {  // prefetch next K-tile behind the MFMAs
-            fetch_tile<AK>(g.A, g.lda, p.a_vec, bm0, M, (kt + 1) * BKT, K, tid, ra);
-            fetch_tile<BK>(g.B, g.ldb, p.b_vec, bn0, N, (kt + 1) * BKT, K, tid, rb);
-        }
-        bf16x8 ah[2], bh[2], al[2], bl[2];
+    float4 ra0[TA::NV], ra1[TA::NV], rb0[TB::NV], rb1[TB::NV];
+    TA::template fetch<VEC>(g.A, g.lda, bm0, M, 0, K, tid, ra0);
+    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, 0, K, tid, rb0);
+    // prefetches are UNCONDITIONAL (past-the-end tiles read a clamped, valid address and are never
+    // stashed): a guard would add a join point and make hipcc fall back to conservative vmcnt counts.
+    TA::template fetch<VEC>(g.A, g.lda, bm0, M, BKT, K, tid, ra1);
+    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, BKT, K, tid, rb1);
+
+    auto consume = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned short* pa = As + (wr * 32 + i * 16 + frow) * LDS_LD + fk;
-            const unsigned short* pb = Bs + (wc * 32 + i * 16 + frow) * LDS_LD + fk;
-            ah[i] = *reinterpret_cast<const bf16x8*>(pa);
-            bh[i] = *reinterpret_cast<const bf16x8*>(pb);
-            if (NSPLIT == 3) {
-                al[i] = *reinterpret_cast<const bf16x8*>(pa + PLANE);
-                bl[i] = *reinterpret_cast<const bf16x8*>(pb + PLANE);
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = TA::frag(As, wm0 + 16 * i, kk, lane);
+                if (NSPLIT == 3) al[i] = TA::frag(As + TA::PLANE, wm0 + 16 * i, kk, lane);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = TB::frag(Bs, wn0 + 16 * j, kk, lane);
+                if (NSPLIT == 3) bl[j] = TB::frag(Bs + TB::PLANE, wn0 + 16 * j, kk, lane);
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (NSPLIT == 3) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (NSPLIT == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-        if (do_rowsum && tid < 64) {
-            const unsigned short* pr = As + tid * LDS_LD;
+        }
+        if (do_rowsum) {  // thread owns row (tid & 63), k-quarter (tid >> 6)
+            const int row = tid & 63, kq = (tid >> 6) * 16;
             float s = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < BKT; ++k) {
-                s += bf2f(pr[k]);
-                if (NSPLIT == 3) s += bf2f(pr[PLANE + k]);
-            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += TA::template value<NSPLIT>(As, row, kq + k);
             rowsum += s;
         }
+    };
+
+    // two K-steps per trip so the prefetch registers keep compile-time names
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        lds_barrier();
+        TA::template stash<NSPLIT>(As, tid, ra0, bm0, M, kt * BKT, K);
+        TB::template stash<NSPLIT>(Bs, tid, rb0, bn0, N, kt * BKT, K);
+        lds_barrier();
+        TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 2) * BKT, K, tid, ra0);
+        TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 2) * BKT, K, tid, rb0);
+        consume();
+        if (kt + 1 >= ktiles) break;
+        lds_barrier();
+        TA::template stash<NSPLIT>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
+        TB::template stash<NSPLIT>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
+        lds_barrier();
+        TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 3) * BKT, K, tid, ra1);
+        TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 3) * BKT, K, tid, rb1);
+        consume();
     }
-    if (do_rowsum && tid < 64 && bm0 + tid < M) g.rowsum_a[bm0 + tid] = rowsum;
+    if (do_rowsum) {
+        rsum[tid >> 6][tid & 63] = rowsum;
+        __syncthreads();
+        if (tid < 64 && bm0 + tid < M) g.rowsum_a[bm0 + tid] = rsum[0][tid] + rsum[1][tid] + rsum[2][tid] + rsum[3][tid];
+    }
 
     // ---- epilogue: +bias -> relu -> gate -> dropout -> +resid
     const int crow = (lane >> 4) << 2, ccol = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gm0 = bm0 + wr * 32 + i * 16 + crow;
-            const int gn = bn0 + wc * 32 + j * 16 + ccol;
+        for (int j = 0; j < NT; ++j) {
+            const int gm0 = bm0 + wm0 + i * 16 + crow;
+            const int gn = bn0 + wn0 + j * 16 + ccol;
             if (gn >= N || gm0 >= M) continue;
             const float bias = g.bias ? g.bias[gn] : 0.f;
             uint4 bits = make_uint4(0, 0, 0, 0);
@@ -223,10 +289,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
 }
 
+template <int NSPLIT, bool AK, bool BK, bool VEC>
+static void launch2(const GemmParams& p, hipStream_t s) {
+    // Skinny problems (one row-block) get 16-column tiles: 4x the workgroups, so a
+    // [50 x 512] x [512 x 512] decoder GEMM runs on 32 CUs instead of 8.
+    const bool narrow = p.a.M <= BM && p.a.rowsum_a == nullptr;
+    if (narrow) {
+        dim3 grid(ceil_div(p.a.N, 16), ceil_div(p.a.M, BM));
+        hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 16, VEC>), grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid(ceil_div(p.a.N, 64), ceil_div(p.a.M, BM));
+        hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 64, VEC>), grid, dim3(256), 0, s, p);
+    }
+}
+
 template <int NSPLIT, bool AK, bool BK>
 static void launch(const GemmParams& p, hipStream_t s) {
-    dim3 grid(ceil_div(p.a.N, BN), ceil_div(p.a.M, BM));
-    hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK>), grid, dim3(256), 0, s, p);
+    // 16-byte vector loads need both operands 16-B aligned with ld % 4 == 0; anything else
+    // (e.g. an unpadded [B, 202] matrix) takes the scalar-load build of the same kernel.
+    if (p.a_vec && p.b_vec) launch2<NSPLIT, AK, BK, true>(p, s);
+    else launch2<NSPLIT, AK, BK, false>(p, s);
 }
 
 static bool vec_ok(const float* ptr, long ld) {
