@@ -78,10 +78,13 @@ int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int
                     float drop_p, int drop_site, const unsigned long long* rng,
                     int64_t nan_idx /* id whose rows become NaN (decoder <pad> target), or -1 */, void* stream);
 /* dtable[v,:] = sqrt(E) * sum_{tokens with id v} dropout_bwd(dx[token,:]);
- * rows with no token are zeroed.  Deterministic (fixed token order). */
+ * rows with no token are zeroed.  Deterministic (fixed summation tree, no
+ * float atomics).  scratch: slnlp_embed_bwd_scratch_bytes(B,S,E) bytes. */
+int64_t slnlp_embed_bwd_scratch_bytes(int B, int S, int E);
 int slnlp_embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V,
                     const float* dx, float* dtable,
-                    float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+                    float drop_p, int drop_site, const unsigned long long* rng,
+                    void* scratch, void* stream);
 
 /* -------------------------------------------------------- self attention --
  * Encoder self-attention core for one layer, all (b,h) pairs: scores =
@@ -120,7 +123,7 @@ int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, i
  * drop_site for the sub-layer branch; partial [nblk,2,E] per-block partial
  * (dgamma, dbeta) sums, reduced later by slnlp_ln_param_reduce. nblk is
  * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS). */
-#define SLNLP_LN_MAX_PARTIALS 64
+#define SLNLP_LN_MAX_PARTIALS 256
 int slnlp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
                         int rows, int E, const float* add_to_dx, float* dx, float* dx_drop,
                         float drop_p, int drop_site, const unsigned long long* rng,
@@ -138,7 +141,7 @@ int slnlp_ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max
  * Writes logp [B,V] (ld = V), loss[0], and (if dlogits) d loss / d logits. */
 int slnlp_lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V,
                   int64_t ignore_index, float* logp, float* loss, float* dlogits, int64_t ld_dlogits,
-                  void* stream);
+                  float* row_scratch /* [B] */, void* stream);
 /* backward of log_softmax alone, for callers that own the criterion (torch
  * autograd): dlogits = dlogp - exp(logp) * rowsum(dlogp). */
 int slnlp_lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits,

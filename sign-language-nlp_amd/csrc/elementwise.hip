@@ -36,55 +36,119 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
     }
 }
 
-// One workgroup per token m.  The first occurrence of an id (no m' < m with the
-// same id) sums every occurrence m'' >= m in increasing order and writes the
-// table row: deterministic, no atomics.  Untouched rows were zeroed by a memset.
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, long ld_ids, int B, int S,
-                                                        int E, int V, const float* __restrict__ dx,
-                                                        float* __restrict__ dtable, float scale, float drop_p,
-                                                        unsigned drop_thr, int drop_site,
-                                                        const unsigned long long* __restrict__ rng) {
-    __shared__ unsigned long long match[4];
-    const int m = blockIdx.x, M = B * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long id = ids[(long)(m % B) * ld_ids + (m / B)];
-    if (id < 0 || id >= V) return;
-    int dup = 0;
-    for (int mm = tid; mm < m; mm += 256) dup |= (ids[(long)(mm % B) * ld_ids + (mm / B)] == id);
-    if (__syncthreads_or(dup)) return;
+// Embedding backward = segmented sum of dx rows by token id, deterministic (fixed order, no float
+// atomics), in two levels so that a hot id (the <pad> row takes ~40 % of all tokens) is never one
+// long serial chain of dependent loads:
+//  level 1: tokens are cut into chunks of 64 consecutive positions m = s*B+b; inside a chunk the first
+//           occurrence of an id sums the chunk's occurrences in increasing m -> partial[m], pid[m] = id;
+//  level 2: the first chunk-partial of an id sums the (<= #chunks) partials of that id in increasing m
+//           and writes the table row.  Rows of ids that do not occur were zeroed by a memset.
+__device__ __forceinline__ float4 load_dx_row(const float* __restrict__ dx, int t, int E, int c, float drop_p,
+                                              float ik, unsigned thr, int site,
+                                              const unsigned long long* __restrict__ rng) {
+    float4 g = *reinterpret_cast<const float4*>(dx + (long)t * E + c);
+    if (drop_p > 0.f) {
+        g.x = dropout_keep(rng, site, t, c + 0, thr) ? g.x * ik : 0.f;
+        g.y = dropout_keep(rng, site, t, c + 1, thr) ? g.y * ik : 0.f;
+        g.z = dropout_keep(rng, site, t, c + 2, thr) ? g.z * ik : 0.f;
+        g.w = dropout_keep(rng, site, t, c + 3, thr) ? g.w * ik : 0.f;
+    }
+    return g;
+}
+
+constexpr int EMB_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __restrict__ ids, long ld_ids, int B, int S,
+                                                              int E, int V, const float* __restrict__ dx,
+                                                              float* __restrict__ partial, int* __restrict__ pid,
+                                                              float drop_p, unsigned drop_thr, int drop_site,
+                                                              const unsigned long long* __restrict__ rng) {
+    const int M = B * S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * EMB_CHUNK, mine = m0 + lane;
+    int my_id = -1;                        // lane l holds the id of token m0 + l (or -1)
+    if (mine < M) {
+        const long v = ids[(long)(mine % B) * ld_ids + (mine / B)];
+        my_id = (v < 0 || v >= V) ? -1 : (int)v;
+    }
     const float ik = 1.f / (1.f - drop_p);
-    for (int c0 = 0; c0 < E; c0 += 1024) {
-        const int c = c0 + tid * 4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int base = m; base < M; base += 256) {
-            const int mm = base + tid;
-            const bool hit = mm < M && ids[(long)(mm % B) * ld_ids + (mm / B)] == id;
-            const unsigned long long bal = __ballot(hit);
-            __syncthreads();
-            if (lane == 0) match[wave] = bal;
-            __syncthreads();
+    for (int t = wave; t < EMB_CHUNK && m0 + t < M; t += 4) {      // wave-uniform trip count
+        const int id = __shfl(my_id, t, 64);
+        unsigned long long mask = __ballot(my_id == id && id >= 0);
+        const bool first = id >= 0 && (mask & ((1ull << t) - 1ull)) == 0ull;
+        if (lane == 0) pid[m0 + t] = first ? id : -1;
+        if (!first) continue;
+        for (int c = lane * 4; c < E; c += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned long long bits = mask;
+            while (bits) {                 // 4 independent loads in flight, summed in increasing-m order
+                int k[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    k[u] = bits ? __ffsll((long long)bits) - 1 : -1;
+                    bits &= bits - 1;      // 0 & anything stays 0
+                }
+                float4 g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+            }
+            *reinterpret_cast<float4*>(partial + (long)(m0 + t) * E + c) = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __restrict__ pid, int M, int E,
+                                                                const float* __restrict__ partial,
+                                                                float* __restrict__ dtable, float scale) {
+    __shared__ int list[1024];             // slots holding a partial of this id, increasing (<= #chunks)
+    __shared__ int nlist;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int id = pid[m];
+    if (id < 0) return;
+    int dup = 0;
+    for (int mm = tid; mm < m; mm += 256) dup |= (pid[mm] == id);
+    if (__syncthreads_or(dup)) return;     // an earlier chunk owns this id
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    // later chunk-firsts of the same id: at most one per chunk -> probe only slots >= m, chunk by chunk
+    for (int base = m; base < M; base += 256) {
+        const int mm = base + tid;
+        const bool hit = mm < M && pid[mm] == id;
+        const unsigned long long bal = __ballot(hit);
+        __shared__ unsigned long long match[4];
+        __syncthreads();
+        if ((tid & 63) == 0) match[tid >> 6] = bal;
+        __syncthreads();
+        if (tid == 0) {
+            int n = nlist;
             for (int w = 0; w < 4; ++w) {
                 unsigned long long bits = match[w];
-                while (bits) {
-                    const int k = __ffsll((long long)bits) - 1;
+                while (bits && n < 1024) {
+                    list[n++] = base + w * 64 + __ffsll((long long)bits) - 1;
                     bits &= bits - 1;
-                    const int t = base + w * 64 + k;
-                    if (c < E) {
-                        float4 g = *reinterpret_cast<const float4*>(dx + (long)t * E + c);
-                        if (drop_p > 0.f) {
-                            g.x = dropout_keep(rng, drop_site, t, c + 0, drop_thr) ? g.x * ik : 0.f;
-                            g.y = dropout_keep(rng, drop_site, t, c + 1, drop_thr) ? g.y * ik : 0.f;
-                            g.z = dropout_keep(rng, drop_site, t, c + 2, drop_thr) ? g.z * ik : 0.f;
-                            g.w = dropout_keep(rng, drop_site, t, c + 3, drop_thr) ? g.w * ik : 0.f;
-                        }
-                        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-                    }
                 }
             }
+            nlist = n;
         }
-        if (c < E) {
-            acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
-            *reinterpret_cast<float4*>(dtable + id * E + c) = acc;
+        __syncthreads();
+    }
+    const int n = nlist;
+    for (int c = tid * 4; c < E; c += 1024) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < n; i += 4) {
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                g[u] = (i + u < n) ? *reinterpret_cast<const float4*>(partial + (long)list[i + u] * E + c)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
         }
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        *reinterpret_cast<float4*>(dtable + (long)id * E + c) = acc;
     }
 }
 
@@ -102,18 +166,29 @@ int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     return 0;
 }
 
+size_t embed_bwd_scratch_bytes(int B, int S, int E) {
+    return ((size_t)B * S * E * sizeof(float) + (size_t)B * S * sizeof(int) + 255) & ~(size_t)255;
+}
+
 int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
-              float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st) {
-    SLNLP_CHECK_ARG(ids && dx && dtable, "embed_bwd: null pointer");
+              float drop_p, int drop_site, const unsigned long long* rng, void* scratch, hipStream_t st) {
+    SLNLP_CHECK_ARG(ids && dx && dtable && scratch, "embed_bwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_bwd: bad shape");
+    SLNLP_CHECK_ARG((long)B * S <= 65536, "embed_bwd: more than 65536 tokens per batch");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_bwd: bad dropout args");
     if (hipMemsetAsync(dtable, 0, (size_t)V * E * sizeof(float), st) != hipSuccess) {
         set_error("embed_bwd: memset failed");
         return SLNLP_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * S), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V, dx,
-                       dtable, sqrtf((float)E), drop_p, dropout_threshold(drop_p), drop_site, rng);
-    SLNLP_CHECK_LAUNCH("embed_bwd");
+    const int M = B * S;
+    float* partial = (float*)scratch;
+    int* pid = (int*)(partial + (size_t)M * E);
+    hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3(ceil_div(M, EMB_CHUNK)), dim3(256), 0, st, (const long*)ids,
+                       (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng);
+    SLNLP_CHECK_LAUNCH("embed_bwd_chunk");
+    hipLaunchKernelGGL(embed_bwd_combine_kernel, dim3(M), dim3(256), 0, st, pid, M, E, partial, dtable,
+                       sqrtf((float)E));
+    SLNLP_CHECK_LAUNCH("embed_bwd_combine");
     return 0;
 }
 
@@ -229,17 +304,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     }
 }
 
+// grid (entry, ceil(E/64)); block = 64 columns x 4 partial-groups, combined through LDS in fixed order.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_reduce_entry* __restrict__ table) {
+    __shared__ float red[2][4][64];
     const slnlp_ln_reduce_entry e = table[blockIdx.x];
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= e.E) return;
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.y * 64 + col;
     float g = 0.f, b = 0.f;
-    for (int k = 0; k < e.nblk; ++k) {
-        g += e.partial[((long)k * 2 + 0) * e.E + c];
-        b += e.partial[((long)k * 2 + 1) * e.E + c];
+    if (c < e.E)
+        for (int k = grp; k < e.nblk; k += 4) {
+            g += e.partial[((long)k * 2 + 0) * e.E + c];
+            b += e.partial[((long)k * 2 + 1) * e.E + c];
+        }
+    red[0][grp][col] = g;
+    red[1][grp][col] = b;
+    __syncthreads();
+    if (grp == 0 && c < e.E) {
+        e.dgamma[c] = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+        e.dbeta[c] = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
     }
-    e.dgamma[c] = g;
-    e.dbeta[c] = b;
 }
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
@@ -276,7 +358,7 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
 
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st) {
     SLNLP_CHECK_ARG(table_dev && n > 0 && max_E > 0, "ln_param_reduce: bad args");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(n, ceil_div(max_E, 256)), dim3(256), 0, st, table_dev);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(n, ceil_div(max_E, 64)), dim3(256), 0, st, table_dev);
     SLNLP_CHECK_LAUNCH("ln_param_reduce");
     return 0;
 }
@@ -286,69 +368,61 @@ int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hi
 // the log-probs (helper.py:61-70).  One workgroup; one wave per row.
 constexpr int LOSS_MAXB = 1024;
 
-__global__ __launch_bounds__(256) void lsm_nll_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ y,
-                                                      int B, int V, long ignore, float* __restrict__ logp,
-                                                      float* __restrict__ loss, float* __restrict__ dlogits, long ldd) {
-    __shared__ float lse2_s[LOSS_MAXB];
-    __shared__ float nll_s[LOSS_MAXB];
-    __shared__ float red[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = wave; b < B; b += 4) {
-        const float* xr = logits + (long)b * ld;
-        float m = -INFINITY;
-        for (int v = lane; v < V; v += 64) m = fmaxf(m, xr[v]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int v = lane; v < V; v += 64) s += expf(xr[v] - m);
-        const float lse = m + logf(wave_sum(s));
-        // second log_softmax (the criterion's), over the log-probs
-        float m2 = -INFINITY;
-        for (int v = lane; v < V; v += 64) {
-            const float lp = xr[v] - lse;
-            logp[(long)b * V + v] = lp;
-            m2 = fmaxf(m2, lp);
-        }
-        m2 = wave_max(m2);
-        float s2 = 0.f;
-        for (int v = lane; v < V; v += 64) s2 += expf((xr[v] - lse) - m2);
-        const float lse2 = m2 + logf(wave_sum(s2));
-        if (lane == 0) {
-            const long t = y[b];
-            const bool valid = (t != ignore) && t >= 0 && t < V;
-            lse2_s[b] = lse2;
-            nll_s[b] = valid ? -((xr[t] - lse) - lse2) : NAN;  // NaN marks "ignored"
-        }
+// grid = B rows, one wave each.  n_valid (targets != ignore_index) is recomputed by every row (B <= 1024
+// compares) so d loss/d logits needs no second pass; the scalar loss is summed by lsm_loss_reduce_kernel.
+__global__ __launch_bounds__(64) void lsm_nll_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ y,
+                                                     int B, int V, long ignore, float* __restrict__ logp,
+                                                     float* __restrict__ row_nll, float* __restrict__ dlogits, long ldd) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    int cnt = 0;
+    for (int i = lane; i < B; i += 64) {
+        const long t = y[i];
+        cnt += (t != ignore && t >= 0 && t < V) ? 1 : 0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot = 0.f, n = 0.f;
-        for (int b = 0; b < B; ++b)
-            if (nll_s[b] == nll_s[b]) { tot += nll_s[b]; n += 1.f; }
-        red[0] = tot / n;  // 0/0 = NaN when every target is ignored, as torch
-        red[1] = n;
-        loss[0] = red[0];
+    const float nvalid = wave_sum((float)cnt);
+    const float* xr = logits + (long)b * ld;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, xr[v]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(xr[v] - m);
+    const float lse = m + logf(wave_sum(s));
+    // second log_softmax (the criterion's), over the log-probs
+    float m2 = -INFINITY;
+    for (int v = lane; v < V; v += 64) {
+        const float lp = xr[v] - lse;
+        logp[(long)b * V + v] = lp;
+        m2 = fmaxf(m2, lp);
     }
-    __syncthreads();
+    m2 = wave_max(m2);
+    float s2 = 0.f;
+    for (int v = lane; v < V; v += 64) s2 += expf((xr[v] - lse) - m2);
+    const float lse2 = m2 + logf(wave_sum(s2));
+    const long t = y[b];
+    const bool valid = (t != ignore) && t >= 0 && t < V;
+    if (lane == 0) row_nll[b] = valid ? -((xr[t] - lse) - lse2) : NAN;   // NaN marks "ignored"
     if (!dlogits) return;
-    const float invn = 1.f / red[1];
-    for (int b = wave; b < B; b += 4) {
-        const bool valid = nll_s[b] == nll_s[b];
-        const float w = valid ? invn : 0.f;
-        const long t = y[b];
-        const float lse2 = lse2_s[b];
-        // d loss / d logp = w * (softmax(logp) - onehot); then back through the model's log_softmax
-        float sum = 0.f;
-        for (int v = lane; v < V; v += 64) {
-            const float lp = logp[(long)b * V + v];
-            sum += w * (expf(lp - lse2) - (v == t ? 1.f : 0.f));
-        }
-        sum = wave_sum(sum);
-        for (int v = lane; v < V; v += 64) {
-            const float lp = logp[(long)b * V + v];
-            const float dlp = w * (expf(lp - lse2) - (v == t ? 1.f : 0.f));
-            dlogits[(long)b * ldd + v] = dlp - expf(lp) * sum;
-        }
+    // d loss / d logp = w * (softmax(logp) - onehot); then back through the model's log_softmax
+    const float w = valid ? 1.f / nvalid : 0.f;
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += w * (expf((xr[v] - lse) - lse2) - (v == t ? 1.f : 0.f));
+    sum = wave_sum(sum);
+    for (int v = lane; v < V; v += 64) {
+        const float lp = xr[v] - lse;
+        const float dlp = w * (expf(lp - lse2) - (v == t ? 1.f : 0.f));
+        dlogits[(long)b * ldd + v] = dlp - expf(lp) * sum;
     }
+}
+
+__global__ __launch_bounds__(64) void lsm_loss_reduce_kernel(const float* __restrict__ row_nll, int B, float* __restrict__ loss) {
+    float tot = 0.f, n = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const float v = row_nll[b];
+        if (v == v) { tot += v; n += 1.f; }
+    }
+    tot = wave_sum(tot);
+    n = wave_sum(n);
+    if (threadIdx.x == 0) loss[0] = tot / n;   // 0/0 = NaN when every target is ignored, as torch
 }
 
 __global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp, int B,
@@ -364,13 +438,15 @@ __global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ 
 }
 
 int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
-            float* loss, float* dlogits, int64_t ld_dlogits, hipStream_t st) {
-    SLNLP_CHECK_ARG(logits && y && logp && loss, "lsm_nll: null pointer");
+            float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st) {
+    SLNLP_CHECK_ARG(logits && y && logp && loss && row_scratch, "lsm_nll: null pointer");
     SLNLP_CHECK_ARG(B > 0 && B <= LOSS_MAXB && V > 0 && ld_logits >= V, "lsm_nll: bad shape B=%d V=%d", B, V);
     SLNLP_CHECK_ARG(!dlogits || ld_dlogits >= V, "lsm_nll: ld_dlogits too small");
-    hipLaunchKernelGGL(lsm_nll_kernel, dim3(1), dim3(256), 0, st, logits, (long)ld_logits, (const long*)y, B, V,
-                       (long)ignore_index, logp, loss, dlogits, (long)ld_dlogits);
+    hipLaunchKernelGGL(lsm_nll_kernel, dim3(B), dim3(64), 0, st, logits, (long)ld_logits, (const long*)y, B, V,
+                       (long)ignore_index, logp, row_scratch, dlogits, (long)ld_dlogits);
     SLNLP_CHECK_LAUNCH("lsm_nll");
+    hipLaunchKernelGGL(lsm_loss_reduce_kernel, dim3(1), dim3(64), 0, loss_st ? loss_st : st, row_scratch, B, loss);
+    SLNLP_CHECK_LAUNCH("lsm_loss_reduce");
     return 0;
 }
 
@@ -464,9 +540,10 @@ int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int
                     int64_t nan_idx, void* stream) {
     return slnlp::embed_fwd(ids, ld_ids, B, S, E, V, table, pe, out, drop_p, drop_site, rng, nan_idx, (hipStream_t)stream);
 }
+int64_t slnlp_embed_bwd_scratch_bytes(int B, int S, int E) { return (int64_t)slnlp::embed_bwd_scratch_bytes(B, S, E); }
 int slnlp_embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
-                    float drop_p, int drop_site, const unsigned long long* rng, void* stream) {
-    return slnlp::embed_bwd(ids, ld_ids, B, S, E, V, dx, dtable, drop_p, drop_site, rng, (hipStream_t)stream);
+                    float drop_p, int drop_site, const unsigned long long* rng, void* scratch, void* stream) {
+    return slnlp::embed_bwd(ids, ld_ids, B, S, E, V, dx, dtable, drop_p, drop_site, rng, scratch, (hipStream_t)stream);
 }
 int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                         float* stats, void* stream) {
@@ -482,9 +559,9 @@ int slnlp_ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max
     return slnlp::ln_param_reduce(table_dev, n, max_E, (hipStream_t)stream);
 }
 int slnlp_lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index,
-                  float* logp, float* loss, float* dlogits, int64_t ld_dlogits, void* stream) {
-    return slnlp::lsm_nll(logits, ld_logits, y, B, V, ignore_index, logp, loss, dlogits, ld_dlogits,
-                          (hipStream_t)stream);
+                  float* logp, float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, void* stream) {
+    return slnlp::lsm_nll(logits, ld_logits, y, B, V, ignore_index, logp, loss, dlogits, ld_dlogits, row_scratch,
+                          (hipStream_t)stream, nullptr);
 }
 int slnlp_lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits,
                   void* stream) {

@@ -138,16 +138,23 @@ struct Bump {
     }
 };
 
-struct EncA { float *qkv, *probs, *ctx, *y1, *st1, *x1, *h, *y2, *st2, *x2, *lnp1, *lnp2; };
+// forward activations kept for backward + this layer's gradient buffers.  Every gradient buffer is
+// written exactly once per step, so work forked to a side stream (wgrads) can keep reading it while
+// the main stream moves on -- there is nothing to overwrite until the next step.
+struct EncA {
+    float *qkv, *probs, *ctx, *y1, *st1, *x1, *h, *y2, *st2, *x2, *lnp1, *lnp2;
+    float *gA2, *gB2, *gh, *gx1, *gA1, *gB1, *gctx, *gqkv, *gx0;
+};
 struct DecA {
     float *v, *y1, *st1, *t1, *q, *kv, *xprobs, *xctx, *y2, *st2, *t2, *h, *y3, *st3, *t3, *lnp1, *lnp2, *lnp3;
+    float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gkv, *gt1, *gA1, *gB1, *gv, *gt0;
 };
 struct Ws {
-    float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp;
+    float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp, *row_nll;
     std::vector<EncA> enc;
     std::vector<DecA> dec;
-    float *d0, *d1, *d2, *dqkv, *dh, *dctx, *dmem;          // encoder-sized grads
-    float *e0, *e1, *e2, *dq, *dxctx, *dv, *dhd, *dkv;      // decoder-sized grads (+ dkv [M,2E])
+    float *gfin, *gtl, *gmem, *gxl;     // d tfin, d t_last, d memory, d x_last
+    void *emb_scratch_src, *emb_scratch_tgt;
     float* opt_partials;
     slnlp_ln_reduce_entry* ln_table;
     size_t bytes;
@@ -174,6 +181,15 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.x2 = b.take<float>(M * E);
         a.lnp1 = b.take<float>(lnp);
         a.lnp2 = b.take<float>(lnp);
+        a.gA2 = b.take<float>(M * E);
+        a.gB2 = b.take<float>(M * E);
+        a.gh = b.take<float>(M * F);
+        a.gx1 = b.take<float>(M * E);
+        a.gA1 = b.take<float>(M * E);
+        a.gB1 = b.take<float>(M * E);
+        a.gctx = b.take<float>(M * E);
+        a.gqkv = b.take<float>(M * 3 * E);
+        a.gx0 = b.take<float>(M * E);
         w.enc.push_back(a);
     }
     w.mem = b.take<float>(M * E);
@@ -199,6 +215,20 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.lnp1 = b.take<float>(lnp);
         a.lnp2 = b.take<float>(lnp);
         a.lnp3 = b.take<float>(lnp);
+        a.gA3 = b.take<float>(B * E);
+        a.gB3 = b.take<float>(B * E);
+        a.gh = b.take<float>(B * F);
+        a.gt2 = b.take<float>(B * E);
+        a.gA2 = b.take<float>(B * E);
+        a.gB2 = b.take<float>(B * E);
+        a.gxctx = b.take<float>(B * E);
+        a.gq = b.take<float>(B * E);
+        a.gkv = b.take<float>(M * 2 * E);
+        a.gt1 = b.take<float>(B * E);
+        a.gA1 = b.take<float>(B * E);
+        a.gB1 = b.take<float>(B * E);
+        a.gv = b.take<float>(B * E);
+        a.gt0 = b.take<float>(B * E);
         w.dec.push_back(a);
     }
     w.tfin = b.take<float>(B * E);
@@ -207,21 +237,13 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     w.logits = b.take<float>(B * Vp);
     w.dlogits = b.take<float>(B * Vp);
     w.logp = b.take<float>(B * c.Vt);
-    w.d0 = b.take<float>(M * E);
-    w.d1 = b.take<float>(M * E);
-    w.d2 = b.take<float>(M * E);
-    w.dqkv = b.take<float>(M * 3 * E);
-    w.dh = b.take<float>(M * F);
-    w.dctx = b.take<float>(M * E);
-    w.dmem = b.take<float>(M * E);
-    w.e0 = b.take<float>(B * E);
-    w.e1 = b.take<float>(B * E);
-    w.e2 = b.take<float>(B * E);
-    w.dq = b.take<float>(B * E);
-    w.dxctx = b.take<float>(B * E);
-    w.dv = b.take<float>(B * E);
-    w.dhd = b.take<float>(B * F);
-    w.dkv = b.take<float>(M * 2 * E);
+    w.row_nll = b.take<float>(B);
+    w.gfin = b.take<float>(B * E);
+    w.gtl = b.take<float>(B * E);
+    w.gmem = b.take<float>(M * E);
+    w.gxl = b.take<float>(M * E);
+    w.emb_scratch_src = b.take<char>(embed_bwd_scratch_bytes(c.B, c.S, c.E));
+    w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
     w.opt_partials = b.take<float>(1024);
     w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
     w.bytes = (b.cur + 255) & ~(size_t)255;
@@ -235,6 +257,8 @@ using namespace slnlp;
 // dropout site ids
 enum { SITE_SRC_EMB = 1, SITE_TGT_EMB = 2, SITE_LAYER0 = 16, SITE_PER_LAYER = 8 };
 
+constexpr int NSIDE = 3;
+
 struct slnlp_tf_plan {
     slnlp_tf_config cfg;
     slnlp_tf_buffers buf;
@@ -246,11 +270,43 @@ struct slnlp_tf_plan {
     const int64_t* last_y = nullptr;
     hipGraphExec_t graph = nullptr;
     int nbE = 0, nbD = 0;  // LN-backward block counts of the FULL batch (fixed: the reduce table is static)
+    // Side streams: independent work (weight gradients, the memory K/V projections, embedding
+    // gradients, the scalar loss) is forked off the dependent chain with events and joined before the
+    // optimizer.  A single B=50 fit cannot fill 256 CUs with one kernel at a time; under stream
+    // capture the forks become parallel branches of the hipGraph.
+    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_kv;
+    bool side_dirty[NSIDE] = {false, false, false};
 
     float* P(long off) const { return buf.params + off; }
     float* G(long off) const { return buf.grads + off; }
     int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
     int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
+
+    // side[k] may start once everything enqueued on `main` so far has finished
+    int fork(hipStream_t main, int k) {
+        if (hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side[k], ev_fork, 0) != hipSuccess) {
+            set_error("tf: fork to side stream failed: %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+        side_dirty[k] = true;
+        return 0;
+    }
+    // `main` waits for everything enqueued on side[k]
+    int join(hipStream_t main, int k) {
+        if (!side_dirty[k]) return 0;
+        if (hipEventRecord(ev_join[k], side[k]) != hipSuccess || hipStreamWaitEvent(main, ev_join[k], 0) != hipSuccess) {
+            set_error("tf: join of side stream failed: %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+        side_dirty[k] = false;
+        return 0;
+    }
+    int join_all(hipStream_t main) {
+        for (int k = 0; k < NSIDE; ++k) SLNLP_TRY(join(main, k));
+        return 0;
+    }
 
     // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
     int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
@@ -291,6 +347,8 @@ struct slnlp_tf_plan {
         a.precision = cfg.precision;
         return gemm(a, st);
     }
+    int forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
+                     bool defer_join);
 };
 
 extern "C" {
@@ -328,6 +386,18 @@ int64_t slnlp_tf_workspace_bytes(const slnlp_tf_config* cfg) {
     return (int64_t)carve(*cfg, nullptr).bytes;
 }
 
+void slnlp_tf_destroy(slnlp_tf_plan* plan) {
+    if (!plan) return;
+    if (plan->graph) (void)hipGraphExecDestroy(plan->graph);
+    for (int k = 0; k < NSIDE; ++k) {
+        if (plan->side[k]) (void)hipStreamDestroy(plan->side[k]);
+        if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
+    }
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    for (hipEvent_t e : plan->ev_kv) (void)hipEventDestroy(e);
+    delete plan;
+}
+
 int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, slnlp_tf_plan** out) {
     SLNLP_TRY(check_cfg(cfg));
     SLNLP_CHECK_ARG(buf && out, "tf_create: null argument");
@@ -342,7 +412,19 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     p->buf = *buf;
     p->L = build_layout(*cfg);
     p->w = carve(*cfg, buf->workspace);
-    // LN (dgamma, dbeta) reduction table: one entry per LayerNorm, uploaded once.
+    bool ok = attn_init() == 0;
+    for (int k = 0; ok && k < NSIDE; ++k)
+        ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; ok && l < cfg->N; ++l) {
+        hipEvent_t e = nullptr;
+        ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) p->ev_kv.push_back(e);
+    }
+    // LN (dgamma, dbeta) reduction table: one entry per LayerNorm, uploaded once.  nblk is the FULL
+    // batch's block count; smaller batches launch the same number of LN-backward blocks (nblk_force),
+    // so every slot the reduce reads is rewritten each step.
     std::vector<slnlp_ln_reduce_entry> tab;
     const int nbE = p->nbE = ln_bwd_blocks(cfg->B * cfg->S), nbD = p->nbD = ln_bwd_blocks(cfg->B);
     auto ent = [&](const float* part, long gw, long gb, int nblk) {
@@ -361,36 +443,23 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
         ent(p->w.dec[i].lnp3, p->L.dec[i].n3_w, p->L.dec[i].n3_b, nbD);
     }
     ent(p->w.lnp_fin, p->L.decn_w, p->L.decn_b, nbD);
-    // nblk in the table is the FULL batch's block count; smaller batches launch the same
-    // number of LN-backward blocks (nblk_force), so every slot the reduce reads is rewritten.
-    if (attn_init() != 0) {
-        delete p;
-        return SLNLP_ERR_LAUNCH;
-    }
-    if (hipMemcpy(p->w.ln_table, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess) {
+    ok = ok && hipMemcpy(p->w.ln_table, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(buf->grads, 0, p->L.total * sizeof(float)) == hipSuccess;
+    if (!ok) {
         set_error("tf_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
-        delete p;
+        slnlp_tf_destroy(p);
         return SLNLP_ERR_LAUNCH;
     }
     *out = p;
     return 0;
 }
 
-void slnlp_tf_destroy(slnlp_tf_plan* plan) {
-    if (!plan) return;
-    if (plan->graph) hipGraphExecDestroy(plan->graph);
-    delete plan;
-}
+}  // extern "C"
 
-int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, int train, float* logp_out,
-                     void* stream) {
-    SLNLP_CHECK_ARG(pl && X && y, "tf_forward: `X` and `y` are required parameters");  // transformer.py:61-62
-    SLNLP_CHECK_ARG(B > 0 && B <= pl->cfg.B, "tf_forward: batch %d outside 1..%d", B, pl->cfg.B);
-    hipStream_t st = (hipStream_t)stream;
+int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
+                                bool defer_join) {
+    slnlp_tf_plan* pl = this;
     const slnlp_tf_config& c = pl->cfg;
-    const Ws& w = pl->w;
-    const Layout& L = pl->L;
     const int E = c.E, F = c.F, H = c.H, S = c.S, dh = E / H, M = S * B, Vp = (int)align_up(c.Vt, 4);
     const float p = train ? c.dropout : 0.f;
     const unsigned long long* rng = pl->buf.rng;
@@ -414,6 +483,19 @@ int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int 
     }
     SLNLP_TRY(layernorm_fwd(x, pl->P(L.encn_w), pl->P(L.encn_b), M, E, 1e-5f, w.mem, w.st_mem, st));
 
+    // memory K|V projections of ALL decoder layers depend only on `mem`: run them on side[0]
+    // while the main stream walks the decoder's chain of small (B-row) kernels.
+    SLNLP_TRY(fork(st, 0));
+    for (int l = 0; l < c.N; ++l) {
+        const DecP& q = L.dec[l];
+        SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0,
+                             0.f, 0, nullptr, side[0]));
+        if (hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
+            set_error("tf_forward: event record failed");
+            return SLNLP_ERR_LAUNCH;
+        }
+    }
+
     const float* t = w.t0;
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
@@ -425,7 +507,10 @@ int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int 
         SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
         // cross-attention: q from tgt, k|v from memory, no masks (transformer.py:82-87)
         SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st));
-        SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, a.kv, 2 * E, 0, 0.f, 0, nullptr, st));
+        if (hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
+            set_error("tf_forward: wait for K/V projection failed");
+            return SLNLP_ERR_LAUNCH;
+        }
         SLNLP_TRY(attn_cross_fwd(a.q, a.kv, 2 * E, B, S, H, dh, a.xctx, a.xprobs, p, pl->dec_site(l, 2), rng, st));
         SLNLP_TRY(pl->linear(a.xctx, B, E, pl->P(q.cout_w), E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, st));
         SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st));
@@ -434,16 +519,29 @@ int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int 
         SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st));
         t = a.t3;
     }
+    side_dirty[0] = false;  // every ev_kv has been waited for: side[0] is joined
     SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
     SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
-    // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70)
-    SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp, st));
+    // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70); the
+    // scalar-loss reduction is off the dependent chain (side[1])
+    SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp,
+                      w.row_nll, st, nullptr));
     if (logp_out &&
         hipMemcpyAsync(logp_out, w.logp, (size_t)B * c.Vt * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
         set_error("tf_forward: copy of log-probs failed");
         return SLNLP_ERR_LAUNCH;
     }
+    (void)defer_join;
     return 0;
+}
+
+extern "C" {
+
+int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, int train, float* logp_out,
+                     void* stream) {
+    SLNLP_CHECK_ARG(pl && X && y, "tf_forward: `X` and `y` are required parameters");  // transformer.py:61-62
+    SLNLP_CHECK_ARG(B > 0 && B <= pl->cfg.B, "tf_forward: batch %d outside 1..%d", B, pl->cfg.B);
+    return pl->forward_impl(X, y, B, train, logp_out, (hipStream_t)stream, false);
 }
 
 int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
@@ -454,6 +552,7 @@ int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
 int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
+    hipStream_t s0 = pl->side[0], s1 = pl->side[1], s2 = pl->side[2];
     const slnlp_tf_config& c = pl->cfg;
     const Ws& w = pl->w;
     const Layout& L = pl->L;
@@ -462,74 +561,101 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     const unsigned long long* rng = pl->buf.rng;
     const int64_t *X = pl->last_X, *y = pl->last_y;
     int nb;
+    // Main stream = the dependent chain (LN backward, dgrads, attention backward).
+    // side[1]/side[2] = weight gradients (they only feed the optimizer); side[0] = d memory accumulation.
 
     // generator: logits = tfin lin_w^T + lin_b
-    SLNLP_TRY(pl->wgrad(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b), st));
-    SLNLP_TRY(pl->dgrad(w.dlogits, Vp, B, c.Vt, pl->P(L.lin_w), E, w.e0, nullptr, 0.f, nullptr, st));
-    const float* t_last = w.dec[c.N - 1].t3;
-    SLNLP_TRY(layernorm_bwd(w.e0, t_last, pl->P(L.decn_w), w.st_fin, B, E, nullptr, w.e1, nullptr, 0.f, 0, rng, w.lnp_fin, &nb, pl->nbD, st));
-    float *dt = w.e1, *dA = w.e0, *dB = w.e2;  // rotating [B,E] buffers: dt = incoming grad
+    SLNLP_TRY(pl->fork(st, 1));
+    SLNLP_TRY(pl->wgrad(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b), s1));
+    SLNLP_TRY(pl->dgrad(w.dlogits, Vp, B, c.Vt, pl->P(L.lin_w), E, w.gfin, nullptr, 0.f, nullptr, st));
+    SLNLP_TRY(layernorm_bwd(w.gfin, w.dec[c.N - 1].t3, pl->P(L.decn_w), w.st_fin, B, E, nullptr, w.gtl, nullptr, 0.f, 0,
+                            rng, w.lnp_fin, &nb, pl->nbD, st));
+    const float* dt = w.gtl;  // gradient w.r.t. the current decoder layer's output
     for (int l = c.N - 1; l >= 0; --l) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
         const float* t_in = l > 0 ? w.dec[l - 1].t3 : w.t0;
-        float* dBr = p > 0.f ? dB : nullptr;                 // masked copy only when dropout is on
         // norm3 / FFN
-        SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, dA, dBr, p, pl->dec_site(l, 5), rng, a.lnp3, &nb, pl->nbD, st));
-        const float* dbr = p > 0.f ? dB : dA;
-        SLNLP_TRY(pl->wgrad(dbr, E, B, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), st));
-        SLNLP_TRY(pl->dgrad(dbr, E, B, E, pl->P(q.l2_w), F, w.dhd, a.h, ik, nullptr, st));
-        SLNLP_TRY(pl->wgrad(w.dhd, F, B, F, a.t2, E, pl->G(q.l1_w), pl->G(q.l1_b), st));
-        SLNLP_TRY(pl->dgrad(w.dhd, F, B, F, pl->P(q.l1_w), E, dt, nullptr, 0.f, dA, st));
+        SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, a.gA3, p > 0.f ? a.gB3 : nullptr, p,
+                                pl->dec_site(l, 5), rng, a.lnp3, &nb, pl->nbD, st));
+        const float* d3 = p > 0.f ? a.gB3 : a.gA3;
+        SLNLP_TRY(pl->fork(st, 1));
+        SLNLP_TRY(pl->wgrad(d3, E, B, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
+        SLNLP_TRY(pl->dgrad(d3, E, B, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
+        SLNLP_TRY(pl->fork(st, 2));
+        SLNLP_TRY(pl->wgrad(a.gh, F, B, F, a.t2, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
+        SLNLP_TRY(pl->dgrad(a.gh, F, B, F, pl->P(q.l1_w), E, a.gt2, nullptr, 0.f, a.gA3, st));
         // norm2 / cross-attention
-        SLNLP_TRY(layernorm_bwd(dt, a.y2, pl->P(q.n2_w), a.st2, B, E, nullptr, dA, dBr, p, pl->dec_site(l, 3), rng, a.lnp2, &nb, pl->nbD, st));
-        SLNLP_TRY(pl->wgrad(dbr, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b), st));
-        SLNLP_TRY(pl->dgrad(dbr, E, B, E, pl->P(q.cout_w), E, w.dxctx, nullptr, 0.f, nullptr, st));
-        SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, w.dxctx, B, S, H, dh, w.dq, w.dkv, 2 * E, p, pl->dec_site(l, 2), rng, st));
-        SLNLP_TRY(pl->wgrad(w.dq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b), st));
-        SLNLP_TRY(pl->wgrad(w.dkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, st));
-        SLNLP_TRY(pl->dgrad(w.dkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.dmem, nullptr, 0.f,
-                            l == c.N - 1 ? nullptr : w.dmem, st));
-        SLNLP_TRY(pl->dgrad(w.dq, E, B, E, pl->P(q.cin_w), E, dt, nullptr, 0.f, dA, st));
+        SLNLP_TRY(layernorm_bwd(a.gt2, a.y2, pl->P(q.n2_w), a.st2, B, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
+                                pl->dec_site(l, 3), rng, a.lnp2, &nb, pl->nbD, st));
+        const float* d2 = p > 0.f ? a.gB2 : a.gA2;
+        SLNLP_TRY(pl->fork(st, 1));
+        SLNLP_TRY(pl->wgrad(d2, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b), s1));
+        SLNLP_TRY(pl->dgrad(d2, E, B, E, pl->P(q.cout_w), E, a.gxctx, nullptr, 0.f, nullptr, st));
+        SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, a.gxctx, B, S, H, dh, a.gq, a.gkv, 2 * E, p, pl->dec_site(l, 2), rng, st));
+        SLNLP_TRY(pl->fork(st, 0));
+        SLNLP_TRY(pl->fork(st, 1));
+        SLNLP_TRY(pl->fork(st, 2));
+        // d memory accumulates over decoder layers in a fixed order on side[0]
+        SLNLP_TRY(pl->dgrad(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
+                            l == c.N - 1 ? nullptr : w.gmem, s0));
+        SLNLP_TRY(pl->wgrad(a.gkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, s1));
+        SLNLP_TRY(pl->wgrad(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b), s2));
+        SLNLP_TRY(pl->dgrad(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2, st));
         // norm1 / self-attention (single key)
-        SLNLP_TRY(layernorm_bwd(dt, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, dA, dBr, p, pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, st));
-        SLNLP_TRY(pl->wgrad(dbr, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b), st));
-        SLNLP_TRY(pl->dgrad(dbr, E, B, E, pl->P(q.sout_w), E, w.dv, nullptr, 0.f, nullptr, st));
-        if (p > 0.f) SLNLP_TRY(head_dropout(w.dv, B, H, dh, p, pl->dec_site(l, 0), rng, st));
+        SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
+                                pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, st));
+        const float* d1 = p > 0.f ? a.gB1 : a.gA1;
+        SLNLP_TRY(pl->fork(st, 2));
+        SLNLP_TRY(pl->wgrad(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b), s2));
+        SLNLP_TRY(pl->dgrad(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr, st));
+        if (p > 0.f) SLNLP_TRY(head_dropout(a.gv, B, H, dh, p, pl->dec_site(l, 0), rng, st));
+        SLNLP_TRY(pl->fork(st, 2));
         // softmax over one element has zero gradient: q/k rows of in_proj get exactly 0
-        if (hipMemsetAsync(pl->G(q.sin_w), 0, 2L * E * E * sizeof(float), st) != hipSuccess ||
-            hipMemsetAsync(pl->G(q.sin_b), 0, 2L * E * sizeof(float), st) != hipSuccess) {
+        if (hipMemsetAsync(pl->G(q.sin_w), 0, 2L * E * E * sizeof(float), s2) != hipSuccess ||
+            hipMemsetAsync(pl->G(q.sin_b), 0, 2L * E * sizeof(float), s2) != hipSuccess) {
             set_error("tf_backward: memset failed");
             return SLNLP_ERR_LAUNCH;
         }
-        SLNLP_TRY(pl->wgrad(w.dv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E, st));
-        SLNLP_TRY(pl->dgrad(w.dv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, dt, nullptr, 0.f, dA, st));
+        SLNLP_TRY(pl->wgrad(a.gv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E, s2));
+        SLNLP_TRY(pl->dgrad(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1, st));
+        dt = a.gt0;
     }
-    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), p, SITE_TGT_EMB, rng, st));
+    SLNLP_TRY(pl->fork(st, 2));
+    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s2));
 
-    // encoder
-    const float* x_last = w.enc[c.N - 1].x2;
-    SLNLP_TRY(layernorm_bwd(w.dmem, x_last, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.d0, nullptr, 0.f, 0, rng, w.lnp_mem, &nb, pl->nbE, st));
-    float *dx = w.d0, *eA = w.d1, *eB = w.d2;
+    // encoder: needs the complete d memory
+    SLNLP_TRY(pl->join(st, 0));
+    SLNLP_TRY(layernorm_bwd(w.gmem, w.enc[c.N - 1].x2, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.gxl, nullptr, 0.f, 0,
+                            rng, w.lnp_mem, &nb, pl->nbE, st));
+    const float* dx = w.gxl;
     for (int l = c.N - 1; l >= 0; --l) {
         const EncP& q = L.enc[l];
         const EncA& a = w.enc[l];
         const float* x_in = l > 0 ? w.enc[l - 1].x2 : w.x0;
-        float* eBr = p > 0.f ? eB : nullptr;
-        SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, eA, eBr, p, pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st));
-        const float* ebr = p > 0.f ? eB : eA;
-        SLNLP_TRY(pl->wgrad(ebr, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), st));
-        SLNLP_TRY(pl->dgrad(ebr, E, M, E, pl->P(q.l2_w), F, w.dh, a.h, ik, nullptr, st));
-        SLNLP_TRY(pl->wgrad(w.dh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b), st));
-        SLNLP_TRY(pl->dgrad(w.dh, F, M, F, pl->P(q.l1_w), E, dx, nullptr, 0.f, eA, st));
-        SLNLP_TRY(layernorm_bwd(dx, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, eA, eBr, p, pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st));
-        SLNLP_TRY(pl->wgrad(ebr, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), st));
-        SLNLP_TRY(pl->dgrad(ebr, E, M, E, pl->P(q.out_w), E, w.dctx, nullptr, 0.f, nullptr, st));
-        SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, w.dctx, B, S, H, dh, w.dqkv, p, pl->enc_site(l, 0), rng, st));
-        SLNLP_TRY(pl->wgrad(w.dqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b), st));
-        SLNLP_TRY(pl->dgrad(w.dqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, dx, nullptr, 0.f, eA, st));
+        SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
+                                pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st));
+        const float* d2 = p > 0.f ? a.gB2 : a.gA2;
+        SLNLP_TRY(pl->fork(st, 1));
+        SLNLP_TRY(pl->wgrad(d2, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
+        SLNLP_TRY(pl->dgrad(d2, E, M, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
+        SLNLP_TRY(pl->fork(st, 2));
+        SLNLP_TRY(pl->wgrad(a.gh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
+        SLNLP_TRY(pl->dgrad(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2, st));
+        SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
+                                pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st));
+        const float* d1 = p > 0.f ? a.gB1 : a.gA1;
+        SLNLP_TRY(pl->fork(st, 0));
+        SLNLP_TRY(pl->wgrad(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), s0));
+        SLNLP_TRY(pl->dgrad(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr, st));
+        SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st));
+        SLNLP_TRY(pl->fork(st, 1));
+        SLNLP_TRY(pl->wgrad(a.gqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b), s1));
+        SLNLP_TRY(pl->dgrad(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1, st));
+        dx = a.gx0;
     }
-    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), p, SITE_SRC_EMB, rng, st));
+    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), p, SITE_SRC_EMB, rng, w.emb_scratch_src, st));
+    SLNLP_TRY(pl->join_all(st));
     SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
     return 0;
 }

@@ -47,7 +47,8 @@ SIGNATURES = {
     "slnlp_abi_version": (i32, []),
     "slnlp_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "slnlp_embed_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp, i64, vp]),
-    "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    "slnlp_embed_bwd_scratch_bytes": (i64, [i32, i32, i32]),
+    "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp]),
     "slnlp_attn_self_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     "slnlp_attn_self_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, f32, i32, vp, vp]),
     "slnlp_attn_cross_fwd": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
@@ -55,7 +56,7 @@ SIGNATURES = {
     "slnlp_layernorm_fwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     "slnlp_layernorm_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, i32, vp, vp, C.POINTER(i32), vp]),
     "slnlp_ln_param_reduce": (i32, [vp, i32, i32, vp]),
-    "slnlp_lsm_nll": (i32, [vp, i64, vp, i32, i32, i64, vp, vp, vp, i64, vp]),
+    "slnlp_lsm_nll": (i32, [vp, i64, vp, i32, i32, i64, vp, vp, vp, i64, vp, vp]),
     "slnlp_lsm_bwd": (i32, [vp, vp, i32, i32, vp, i64, vp]),
     "slnlp_clip_sgd_step": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp]),
     "slnlp_dropout_mask": (i32, [vp, i32, i32, f32, i32, vp, vp]),

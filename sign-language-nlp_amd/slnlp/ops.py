@@ -49,8 +49,9 @@ def embed_bwd(ids, dx, *, B, S, V, drop_p=0.0, drop_site=0, rng=None):
     _lib.require_gpu()
     E = dx.shape[1]
     dt = torch.empty(V, E, dtype=torch.float32, device=dx.device)
+    scratch = torch.empty(int(load().slnlp_embed_bwd_scratch_bytes(B, S, E)), dtype=torch.uint8, device=dx.device)
     check(load().slnlp_embed_bwd(ptr(ids), ids.stride(0) if ids.ndim == 2 else 1, B, S, E, V, ptr(dx), ptr(dt),
-                                 drop_p, drop_site, ptr(rng), stream_ptr()), "embed_bwd")
+                                 drop_p, drop_site, ptr(rng), ptr(scratch), stream_ptr()), "embed_bwd")
     return dt
 
 
@@ -109,7 +110,7 @@ def layernorm_bwd(dy, x, gamma, stats, *, add_to_dx=None, want_drop=False, drop_
     rows, E = x.shape
     dx = torch.empty_like(x)
     dxd = torch.empty_like(x) if want_drop else None
-    partial = torch.empty(64, 2, E, dtype=torch.float32, device=x.device)
+    partial = torch.empty(256, 2, E, dtype=torch.float32, device=x.device)
     nblk = C.c_int32(0)
     check(load().slnlp_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(stats), rows, E, ptr(add_to_dx), ptr(dx),
                                      ptr(dxd), drop_p, drop_site, ptr(rng), ptr(partial), C.byref(nblk),
@@ -130,8 +131,9 @@ def lsm_nll(logits, y, ignore_index, *, want_grad=True):
     logp = torch.empty(B, V, dtype=torch.float32, device=logits.device)
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
     dl = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_grad else None
+    rows = torch.empty(B, dtype=torch.float32, device=logits.device)
     check(load().slnlp_lsm_nll(ptr(logits), logits.stride(0), ptr(y), B, V, ignore_index, ptr(logp), ptr(loss),
-                               ptr(dl), V, stream_ptr()), "lsm_nll")
+                               ptr(dl), V, ptr(rows), stream_ptr()), "lsm_nll")
     return logp, loss, dl
 
 
