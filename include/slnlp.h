@@ -210,14 +210,14 @@ int slnlp_tf_optim(slnlp_tf_plan* plan, float momentum, float max_norm, void* st
 /* forward(train) + loss + backward + optim in one call */
 int slnlp_tf_train_step(slnlp_tf_plan* plan, const int64_t* X, const int64_t* y, int B,
                         float momentum, float max_norm, float* logp, void* stream);
-/* Capture one train step over FIXED device buffers (X, y, logp) and batch size
- * into a hipGraph kept inside the plan; slnlp_tf_graph_launch replays it.  lr,
- * the dropout step counter and the data are read from device memory, so one
- * captured graph serves every step of a fit. `stream` must not be the null
- * stream. */
+/* Capture one train step over FIXED device buffers (X, y, logp) for batch size
+ * B into a hipGraph kept inside the plan (one per distinct B);
+ * slnlp_tf_graph_launch(B) replays it.  lr, the dropout step counter and the
+ * data are read from device memory, so one captured graph serves every step
+ * of a fit.  `stream` must not be the null stream. */
 int slnlp_tf_graph_capture_train(slnlp_tf_plan* plan, const int64_t* X, const int64_t* y, int B,
                                  float momentum, float max_norm, float* logp, void* stream);
-int slnlp_tf_graph_launch(slnlp_tf_plan* plan, void* stream);
+int slnlp_tf_graph_launch(slnlp_tf_plan* plan, int B, void* stream);
 /* test helper: copy a named activation tap ("enc0", "memory", "dec1", "logits", ...) */
 int slnlp_tf_tap(slnlp_tf_plan* plan, const char* name, float* out, int64_t max_floats,
                  int64_t* n_out, void* stream);

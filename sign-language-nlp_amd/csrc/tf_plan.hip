@@ -268,7 +268,7 @@ struct slnlp_tf_plan {
     float last_p = 0.f;   // dropout used by the last forward (0 in eval)
     const int64_t* last_X = nullptr;
     const int64_t* last_y = nullptr;
-    hipGraphExec_t graph = nullptr;
+    std::map<int, hipGraphExec_t> graphs;   // one captured train step per batch size, kept until destroy
     int nbE = 0, nbD = 0;  // LN-backward block counts of the FULL batch (fixed: the reduce table is static)
     // Side streams: independent work (weight gradients, the memory K/V projections, embedding
     // gradients, the scalar loss) is forked off the dependent chain with events and joined before the
@@ -388,7 +388,8 @@ int64_t slnlp_tf_workspace_bytes(const slnlp_tf_config* cfg) {
 
 void slnlp_tf_destroy(slnlp_tf_plan* plan) {
     if (!plan) return;
-    if (plan->graph) (void)hipGraphExecDestroy(plan->graph);
+    (void)hipDeviceSynchronize();             // nothing of this plan may still be in flight
+    for (auto& kv : plan->graphs) (void)hipGraphExecDestroy(kv.second);
     for (int k = 0; k < NSIDE; ++k) {
         if (plan->side[k]) (void)hipStreamDestroy(plan->side[k]);
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
@@ -681,9 +682,11 @@ int slnlp_tf_graph_capture_train(slnlp_tf_plan* pl, const int64_t* X, const int6
                                  float max_norm, float* logp, void* stream) {
     SLNLP_CHECK_ARG(pl && stream, "tf_graph_capture_train: needs a plan and a non-default stream");
     hipStream_t st = (hipStream_t)stream;
-    if (pl->graph) {
-        hipGraphExecDestroy(pl->graph);
-        pl->graph = nullptr;
+    auto old = pl->graphs.find(B);
+    if (old != pl->graphs.end()) {          // re-capture for this batch size: the old exec may still be running
+        (void)hipStreamSynchronize(st);
+        (void)hipGraphExecDestroy(old->second);
+        pl->graphs.erase(old);
     }
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         set_error("tf_graph_capture_train: begin capture failed: %s", hipGetErrorString(hipGetLastError()));
@@ -693,26 +696,29 @@ int slnlp_tf_graph_capture_train(slnlp_tf_plan* pl, const int64_t* X, const int6
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != 0) {
-        if (g) hipGraphDestroy(g);
+        if (g) (void)hipGraphDestroy(g);
         return rc;
     }
     if (e != hipSuccess || !g) {
         set_error("tf_graph_capture_train: end capture failed: %s", hipGetErrorString(e));
         return SLNLP_ERR_LAUNCH;
     }
-    e = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
         set_error("tf_graph_capture_train: instantiate failed: %s", hipGetErrorString(e));
-        pl->graph = nullptr;
         return SLNLP_ERR_LAUNCH;
     }
+    pl->graphs[B] = exec;
     return 0;
 }
 
-int slnlp_tf_graph_launch(slnlp_tf_plan* pl, void* stream) {
-    SLNLP_CHECK_ARG(pl && pl->graph, "tf_graph_launch: no captured graph");
-    if (hipGraphLaunch(pl->graph, (hipStream_t)stream) != hipSuccess) {
+int slnlp_tf_graph_launch(slnlp_tf_plan* pl, int B, void* stream) {
+    SLNLP_CHECK_ARG(pl, "tf_graph_launch: null plan");
+    auto it = pl->graphs.find(B);
+    SLNLP_CHECK_ARG(it != pl->graphs.end(), "tf_graph_launch: no captured graph for batch %d", B);
+    if (hipGraphLaunch(it->second, (hipStream_t)stream) != hipSuccess) {
         set_error("tf_graph_launch: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }

@@ -73,7 +73,7 @@ SIGNATURES = {
     "slnlp_tf_optim": (i32, [vp, f32, f32, vp]),
     "slnlp_tf_train_step": (i32, [vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_tf_graph_capture_train": (i32, [vp, vp, vp, i32, f32, f32, vp, vp]),
-    "slnlp_tf_graph_launch": (i32, [vp, vp]),
+    "slnlp_tf_graph_launch": (i32, [vp, i32, vp]),
     "slnlp_tf_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
 }
 

@@ -1,0 +1,319 @@
+"""skorch-shaped estimator around the HIP modules.
+
+The reference trains through ``skorch.NeuralNetClassifier(**net_params)``
+(/root/reference/main.py:44, helper.py:41-105) driven by sklearn.  skorch is
+not available here, and its Python step loop is exactly the per-batch overhead
+the hot path removes, so this class restates the pieces of skorch 0.10 the
+reference configures, with the same parameter names
+(``module__*``, ``optimizer__*``, ``criterion__*``, ``lr``, ``max_epochs``,
+``batch_size``, ``device``, ``callbacks``-level settings) and the same fit-loop
+semantics:
+
+* internal 80/20 stratified split, first fold of ``StratifiedKFold(5)`` (skorch ``CVSplit(5)``);
+* batches in dataset order (``shuffle`` is commented out, helper.py:75-76);
+* per batch: forward -> CrossEntropyLoss(ignore_index=pad) -> backward ->
+  clip_grad_norm_(gradient_clip_value) -> SGD(momentum)  == ONE hipGraph replay;
+* per epoch: valid pass, ``EpochScoring`` metrics for train/valid, ``lr`` scoring,
+  ``LRScheduler(ReduceLROnPlateau)`` on valid_loss, ``EarlyStopping`` (patience,
+  relative threshold), ``Checkpoint`` on ``valid_loss_best`` (helper.py:197-273).
+
+The compute path is HIP only; with no GPU ``fit`` / ``predict`` raise.
+"""
+import json
+import os
+import time
+from pydoc import locate
+
+import numpy as np
+import torch
+
+from .data import TokenDataset
+
+
+def _resolve(obj):
+    return locate(obj) if isinstance(obj, str) else obj
+
+
+class ScoringWrapper:
+    """helper.py:529-554: sklearn scorer by name; ``labels`` for log-loss, ``zero_division=0`` otherwise."""
+
+    def __init__(self, score_func, labels=None):
+        from sklearn.metrics import get_scorer
+        self._score_func = score_func
+        self.scorer = get_scorer(score_func)
+        if score_func == 'neg_log_loss':
+            self.scorer._kwargs["labels"] = labels
+        elif score_func == 'accuracy':
+            pass
+        else:
+            self.scorer._kwargs["zero_division"] = 0
+
+    def __call__(self, estimator, X, y_true, sample_weight=None):
+        return self.scorer(estimator, X, y_true, sample_weight)
+
+    def __repr__(self):
+        return f"{type(self).__name__}('{self._score_func}')"
+
+    @property
+    def greater_is_better(self):
+        return self.scorer._sign == 1
+
+    @property
+    def score(self):
+        return self._score_func
+
+
+from sklearn.base import BaseEstimator, ClassifierMixin  # noqa: E402  (sklearn >= 1.6 scorers require classifier tags)
+
+
+class _CachedPredictor(ClassifierMixin, BaseEstimator):
+    """What skorch's score caching gives EpochScoring: predictions already made during the epoch."""
+
+    def __init__(self, proba, classes):
+        self._proba, self.classes_ = proba, classes
+
+    def predict_proba(self, X):
+        return self._proba
+
+    def predict(self, X):
+        return self.classes_[self._proba.argmax(-1)]
+
+
+class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
+    _OWN = ("module", "criterion", "optimizer", "lr", "max_epochs", "batch_size", "device", "warm_start", "verbose",
+            "predict_nonlinearity", "scoring", "labels", "early_stopping", "gradient_clipping", "lr_scheduler",
+            "checkpoint_dir", "train_split", "use_graph", "callbacks", "dataset")
+
+    def __init__(self, module, criterion="torch.nn.CrossEntropyLoss", optimizer="torch.optim.SGD", lr=0.01,
+                 max_epochs=10, batch_size=128, device="cuda", warm_start=False, verbose=0,
+                 predict_nonlinearity="auto", scoring=None, labels=None, early_stopping=None,
+                 gradient_clipping=None, lr_scheduler=None, checkpoint_dir=None, train_split=5, use_graph=True,
+                 callbacks=None, dataset=None, **kwargs):
+        loc = locals()
+        self._params = {k: loc[k] for k in self._OWN}
+        for k, v in kwargs.items():
+            if not any(k.startswith(p) for p in ("module__", "optimizer__", "criterion__", "iterator_train__",
+                                                 "iterator_valid__", "callbacks__")):
+                raise TypeError(f"NeuralNetClassifier: unexpected argument {k!r}")
+            self._params[k] = v
+        self.initialized_ = False
+        self.history = []
+
+    # ------------------------------------------------------------ sklearn API
+    def get_params(self, deep=True):
+        return dict(self._params)
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            self._params[k] = v
+        return self
+
+    def __getattr__(self, name):
+        p = self.__dict__.get("_params", {})
+        if name in p:
+            return p[name]
+        raise AttributeError(name)
+
+    def _sub(self, prefix):
+        n = len(prefix) + 2
+        return {k[n:]: v for k, v in self._params.items() if k.startswith(prefix + "__")}
+
+    # ------------------------------------------------------------- lifecycle
+    def initialize(self):
+        dev = torch.device(self.device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("slnlp.net: device %r -- the HIP path is the only compute path (no CPU fallback)" % (self.device,))
+        kw = self._sub("module")
+        kw.setdefault("device", dev)
+        self.module_ = _resolve(self.module)(**kw).to(dev)
+        self.criterion_ = _resolve(self.criterion)(**self._sub("criterion"))
+        self._opt_cls = _resolve(self.optimizer)
+        ok = self._opt_kwargs = self._sub("optimizer")
+        self._fused = (self._opt_cls is torch.optim.SGD and isinstance(self.criterion_, torch.nn.CrossEntropyLoss)
+                       and not ok.get("nesterov", False) and not ok.get("weight_decay", 0) and not ok.get("dampening", 0)
+                       and hasattr(self.module_, "engine"))
+        if not self._fused:
+            self.optimizer_ = self._opt_cls(self.module_.parameters(), lr=self.lr, **ok)
+        self.lr_ = float(self.lr)
+        self.history = []
+        self.initialized_ = True
+        self._stream = torch.cuda.Stream(device=dev)
+        return self
+
+    # ------------------------------------------------------------------ data
+    @staticmethod
+    def _as_dataset(X, y=None):
+        if isinstance(X, TokenDataset):
+            return X
+        if isinstance(X, dict):
+            return TokenDataset(X["X"], X["lengths"], X["y"] if y is None else y)
+        raise TypeError("X must be a slnlp.data.TokenDataset (ids, lengths and labels travel together: the "
+                        "Transformer consumes y as decoder input, transformer.py:65)")
+
+    def _device_data(self, ds):
+        dev = self.module_._arena.device if hasattr(self.module_, "_arena") else torch.device(self.device)
+        return (torch.from_numpy(ds.ids).to(dev), torch.from_numpy(ds.lengths).to(dev), torch.from_numpy(ds.y).to(dev))
+
+    # ------------------------------------------------------------------- fit
+    def fit(self, X, y=None, **fit_params):
+        if not (self.warm_start and self.initialized_):
+            self.initialize()
+        return self.partial_fit(X, y, **fit_params)
+
+    def partial_fit(self, X, y=None, **fit_params):
+        if not self.initialized_:
+            self.initialize()
+        ds = self._as_dataset(X, y)
+        self.classes_ = np.arange(len(ds.vocab_y)) if ds.vocab_y is not None else np.arange(int(ds.y.max()) + 1)
+        labels = self.labels if self.labels is not None else ds.labels()
+        idx_tr, idx_va = self._train_split(ds)
+        tr, va = ds[idx_tr], (ds[idx_va] if idx_va is not None else None)
+        Xtr, Ltr, ytr = self._device_data(tr)
+        if va is not None:
+            Xva, Lva, yva = self._device_data(va)
+        wrappers = [ScoringWrapper(s, labels) for s in (self.scoring or [])]
+        es, clip, sched = self.early_stopping, self.gradient_clipping, self.lr_scheduler
+        max_norm = float(clip["gradient_clip_value"]) if clip and clip.get("gradient_clip_value") else 0.0
+        momentum = float(self._opt_kwargs.get("momentum", 0.0))
+        plateau = None
+        if sched:
+            assert sched.get("policy", "ReduceLROnPlateau") == "ReduceLROnPlateau", "only ReduceLROnPlateau is wired"
+            dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=self.lr_)
+            plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(
+                dummy, **{k: v for k, v in sched.items() if k not in ("policy", "monitor", "step_every")})
+        best_valid, misses, dyn_thr = float("inf"), 0, float("inf")
+        bs = int(self.batch_size)
+        with torch.cuda.stream(self._stream):
+            for epoch in range(len(self.history) + 1, len(self.history) + int(self.max_epochs) + 1):
+                t0 = time.time()
+                self.module_.train()
+                tr_loss, tr_logp = self._run_epoch(Xtr, Ltr, ytr, bs, True, momentum, max_norm)
+                row = {"epoch": epoch, "train_loss": tr_loss, "lr": self.lr_}
+                if va is not None:
+                    self.module_.eval()
+                    va_loss, va_logp = self._run_epoch(Xva, Lva, yva, bs, False, momentum, max_norm)
+                    row["valid_loss"] = va_loss
+                    row["valid_loss_best"] = bool(va_loss < best_valid)
+                    best_valid = min(best_valid, va_loss)
+                for wr in wrappers:                              # EpochScoring on cached predictions
+                    row[f"train_{wr.score}"] = float(wr(_CachedPredictor(np.exp(tr_logp), self.classes_), None, tr.y))
+                    if va is not None:
+                        row[f"valid_{wr.score}"] = float(wr(_CachedPredictor(np.exp(va_logp), self.classes_), None, va.y))
+                row["dur"] = time.time() - t0
+                self.history.append(row)
+                if self.verbose:
+                    print("  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in row.items()))
+                if self.checkpoint_dir and row.get("valid_loss_best"):
+                    self.save_params(self.checkpoint_dir)
+                monitor = row.get("valid_loss", tr_loss)
+                if plateau is not None:                         # LRScheduler(monitor=valid_loss, step_every=epoch)
+                    plateau.step(monitor)
+                    self._set_lr(plateau.optimizer.param_groups[0]["lr"])
+                if es:                                          # skorch EarlyStopping, lower_is_better
+                    if monitor < dyn_thr:
+                        misses = 0
+                        thr = float(es.get("threshold", 1e-4))
+                        dyn_thr = monitor - (thr * monitor if es.get("threshold_mode", "rel") == "rel" else thr)
+                    else:
+                        misses += 1
+                    if misses == int(es.get("patience", 5)):
+                        if self.verbose:
+                            print(f"Stopping since valid_loss has not improved in the last {misses} epochs.")
+                        break
+        torch.cuda.synchronize()
+        return self
+
+    def _train_split(self, ds):
+        ts = self.train_split
+        if not ts:
+            return np.arange(len(ds)), None
+        from sklearn.model_selection import KFold, StratifiedKFold
+        idx = np.arange(len(ds))
+        try:
+            tr, va = next(iter(StratifiedKFold(n_splits=int(ts)).split(idx, ds.y)))
+        except ValueError:                                   # a class with fewer members than folds
+            tr, va = next(iter(KFold(n_splits=int(ts)).split(idx)))
+        return tr, va
+
+    def _set_lr(self, lr):
+        self.lr_ = float(lr)
+        if not self._fused:
+            for g in self.optimizer_.param_groups:
+                g["lr"] = self.lr_
+
+    def _run_epoch(self, X, L, y, bs, train, momentum, max_norm):
+        """One pass in dataset order.  Returns (sample-weighted mean loss, log-probs [N,V] numpy)."""
+        n = X.shape[0]
+        losses, sizes, outs = [], [], []
+        for i in range(0, n, bs):
+            xb, lb, yb = X[i:i + bs], L[i:i + bs], y[i:i + bs]
+            if train and self._fused:
+                eng = self.module_.engine(xb.shape[0], xb.shape[1])
+                eng.set_lr(self.lr_)
+                step = eng.train_step_graph if self.use_graph else eng.train_step
+                logp = step(xb, yb, momentum, max_norm)
+                losses.append(eng.scalars[0].clone())
+            elif train:
+                self.optimizer_.zero_grad()
+                logp = self.module_(X=xb, y=yb, lengths=lb)
+                loss = self.criterion_(logp, yb)
+                loss.backward()
+                if max_norm:
+                    torch.nn.utils.clip_grad_norm_(self.module_.parameters(), max_norm)
+                self.optimizer_.step()
+                losses.append(loss.detach())
+            else:
+                with torch.no_grad():
+                    logp = self.module_(X=xb, y=yb, lengths=lb)
+                    if hasattr(self.module_, "engine") and isinstance(self.criterion_, torch.nn.CrossEntropyLoss):
+                        losses.append(self.module_.engine(xb.shape[0], xb.shape[1]).scalars[0].clone())
+                    else:
+                        losses.append(self.criterion_(logp, yb))
+            sizes.append(xb.shape[0])
+            outs.append(logp.detach().clone())
+        w = torch.tensor(sizes, dtype=torch.float32, device=X.device)
+        mean = float((torch.stack(losses).float() * w).sum() / w.sum())      # one sync per epoch
+        return mean, torch.cat(outs).cpu().numpy()
+
+    # --------------------------------------------------------------- predict
+    def predict_proba(self, X):
+        """softmax of the module output -- the module returns log-probs and skorch's
+        ``predict_nonlinearity='auto'`` applies softmax for CrossEntropyLoss."""
+        if not self.initialized_:
+            raise RuntimeError("This NeuralNetClassifier instance is not initialized yet.")
+        ds = self._as_dataset(X)
+        Xd, Ld, yd = self._device_data(ds)
+        self.module_.eval()
+        outs = []
+        with torch.cuda.stream(self._stream), torch.no_grad():
+            for i in range(0, len(ds), int(self.batch_size)):
+                lp = self.module_(X=Xd[i:i + self.batch_size], y=yd[i:i + self.batch_size], lengths=Ld[i:i + self.batch_size])
+                outs.append(torch.softmax(lp, dim=-1) if self.predict_nonlinearity == "auto" else lp)
+        torch.cuda.synchronize()
+        return torch.cat(outs).cpu().numpy()
+
+    def predict(self, X):
+        return self.classes_[self.predict_proba(X).argmax(-1)]
+
+    def score(self, X, y=None):
+        ds = self._as_dataset(X)
+        return float((self.predict(ds) == (ds.y if y is None else np.asarray(y))).mean())
+
+    # ------------------------------------------------------------ checkpoint
+    def save_params(self, dirname):
+        """skorch ``Checkpoint`` artefacts: params.pt (state_dict), optimizer.pt, history.json."""
+        os.makedirs(dirname, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.module_.state_dict().items()}, os.path.join(dirname, "params.pt"))
+        if self._fused:
+            bufs = {f"S{S}": e.momentum.detach().cpu() for S, e in self.module_._engines.items()}
+            torch.save({"momentum_arena": bufs, "lr": self.lr_}, os.path.join(dirname, "optimizer.pt"))
+        else:
+            torch.save(self.optimizer_.state_dict(), os.path.join(dirname, "optimizer.pt"))
+        with open(os.path.join(dirname, "history.json"), "w") as f:
+            json.dump(self.history, f, indent=1)
+
+    def load_params(self, dirname):
+        if not self.initialized_:
+            self.initialize()
+        self.module_.load_state_dict(torch.load(os.path.join(dirname, "params.pt")))
+        return self

@@ -50,16 +50,19 @@ def layout(cfg):
 class TransformerEngine:
     """One plan = one (config, max batch) on one GPU / one stream."""
 
-    def __init__(self, cfg, device="cuda", seed=0, max_len=5000):
+    def __init__(self, cfg, device="cuda", seed=0, max_len=5000, params=None, grads=None, momentum=None, pe=None):
+        """``params`` / ``grads`` / ``momentum`` / ``pe``: adopt arenas owned by the caller (the
+        drop-in ``model.Transformer`` keeps its nn.Parameters as views of ``params``)."""
         _lib.require_gpu()
         self.cfg = cfg
         self.device = torch.device(device)
         self.entries, self.arena_floats = layout(cfg)
         dev = self.device
-        self.params = torch.zeros(self.arena_floats, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros_like(self.params)
-        self.momentum = torch.zeros_like(self.params)
-        self.pe = positional_table(max_len, cfg.E).to(dev)          # [max_len, E]
+        mk = lambda t: torch.zeros(self.arena_floats, dtype=torch.float32, device=dev) if t is None else t
+        self.params, self.grads, self.momentum = mk(params), mk(grads), mk(momentum)
+        for t in (self.params, self.grads, self.momentum):
+            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.arena_floats and t.is_contiguous()
+        self.pe = positional_table(max_len, cfg.E).to(dev) if pe is None else pe   # [max_len, E]
         ws = int(load().slnlp_tf_workspace_bytes(C.byref(cfg)))
         self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
@@ -71,7 +74,7 @@ class TransformerEngine:
         handle = C.c_void_p()
         check(load().slnlp_tf_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "tf_create")
         self.handle = handle
-        self._graph_key = None
+        self._graph_keys = {}
         self._xbuf = self._ybuf = None
 
     def __del__(self):
@@ -149,11 +152,11 @@ class TransformerEngine:
         st = stream_ptr()
         if st == 0:
             raise RuntimeError("train_step_graph needs a non-default stream (use torch.cuda.stream(...))")
-        if self._graph_key != key:
+        if self._graph_keys.get(B) != key:       # one captured graph per batch size, kept by the plan
             check(load().slnlp_tf_graph_capture_train(self.handle, ptr(xb), ptr(yb), B, momentum, max_norm,
                                                       ptr(self.logp), st), "tf_graph_capture_train")
-            self._graph_key = key
-        check(load().slnlp_tf_graph_launch(self.handle, st), "tf_graph_launch")
+            self._graph_keys[B] = key
+        check(load().slnlp_tf_graph_launch(self.handle, B, st), "tf_graph_launch")
         return self.logp[:B]
 
     def tap(self, name, rows, cols):

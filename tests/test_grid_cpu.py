@@ -1,0 +1,82 @@
+"""CPU (gloo, world_size 2): the grid-search sharding -- dataset broadcast, task
+partition, all_gather of scores, best-candidate selection -- with the ORACLE as
+the per-task fit engine (tests may use the oracle; the product default is the
+HIP estimator).  Results must not depend on the number of ranks."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from slnlp import grid
+from slnlp.data import synthetic_dataset
+
+GRID = {"lr": [0.1, 0.01], "module__embedding_size": [16, 32], "module__num_layers": [1, 2]}
+CV = 3
+
+
+def oracle_fit_and_score(factory, params, train, test, scoring):
+    """Tiny Transformer trained for a few oracle steps on the train fold; score = -CE on the test fold."""
+    from oracle import train_ref, transformer_ref as tr
+    from slnlp import synth
+    E, N, H, F = params["module__embedding_size"], params["module__num_layers"], 2, 32
+    Vs, Vt = len(train.vocab_X), len(train.vocab_y)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(tr.param_shapes(E, H, N, F, Vs, Vt), seed=1).items()}
+    fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=H, num_layers=N)
+    trn = train_ref.Trainer(sd, fwd, lr=params["lr"])
+    X, y = torch.from_numpy(train.ids), torch.from_numpy(train.y)
+    for i in range(0, len(train), 16):
+        trn.step(X[i:i + 16], y[i:i + 16], None)
+    Xt, yt = torch.from_numpy(test.ids), torch.from_numpy(test.y)
+    with torch.no_grad():
+        return -float(train_ref.cross_entropy_on_logprobs(fwd(trn.sd, Xt, yt, None), yt, 1))
+
+
+def _run(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3) if rank == 0 else None
+    gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=oracle_fit_and_score, refit=False)
+    gs.fit(ds)
+    out[rank] = (gs.cv_results_["mean_test_score"].tolist(), gs.best_index_, gs.best_params_, sorted(gs.tasks_of_rank_))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_task_list_and_partition():
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    cands, folds, tasks, order = grid.build_tasks(GRID, ds.y, CV)
+    assert len(cands) == 8 and len(folds) == CV and len(tasks) == 24
+    from sklearn.model_selection import ParameterGrid
+    assert cands == list(ParameterGrid(GRID))                          # sklearn candidate order
+    costs = [grid.estimate_cost(cands[tasks[t][0]]) for t in order]
+    assert costs == sorted(costs, reverse=True)                        # longest first
+    for world in (1, 2, 3, 8):
+        owned = [t for r in range(world) for t in order[r::world]]
+        assert sorted(owned) == list(range(len(tasks)))                # every task exactly once
+
+
+def test_sharded_grid_world2_equals_world1():
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    single = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=oracle_fit_and_score, refit=False).fit(ds)
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        mean, best, params, mine = out[r]
+        assert np.allclose(mean, single.cv_results_["mean_test_score"], rtol=0, atol=1e-12)   # same on every rank
+        assert best == single.best_index_ and params == single.best_params_
+    assert sorted(out[0][3] + out[1][3]) == list(range(single.n_tasks_))
+    assert set(out[0][3]).isdisjoint(out[1][3])

@@ -1,0 +1,99 @@
+"""GPU: the skorch-shaped estimator (slnlp.net) on the HIP path.
+G8: a mini-fit trajectory -- same data, same initial weights, dropout 0 -- run through the
+estimator's loop must reproduce the loss trajectory of the CPU oracle stepping over the same batches."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(module__embedding_size=32, module__num_heads=4, module__num_layers=2, module__hidden_size=64)
+
+
+def make_net(ds, dropout=0.0, **kw):
+    from slnlp.net import NeuralNetClassifier
+    args = dict(module="model.Transformer", module__dropout=dropout, module__src_vocab=ds.vocab_X,
+                module__tgt_vocab=ds.vocab_y, module__batch_first=True, **CFG,
+                criterion="torch.nn.CrossEntropyLoss", criterion__ignore_index=1,
+                optimizer="torch.optim.SGD", optimizer__momentum=0.9, optimizer__nesterov=False,
+                lr=0.05, max_epochs=3, batch_size=20, device="cuda",
+                gradient_clipping={"gradient_clip_value": 0.5})
+    args.update(kw)
+    return NeuralNetClassifier(**args)
+
+
+def test_minifit_trajectory_matches_oracle():
+    from oracle import train_ref, transformer_ref as tr
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(120, seq_len=12, src_vocab=64, n_labels=6, seed=5, min_len=3)
+    torch.manual_seed(7)
+    net = make_net(ds, scoring=["neg_log_loss", "accuracy"])
+    net.initialize()
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.module_.state_dict().items() if not k.endswith(".pe")}
+    net.partial_fit(ds)
+    hist = net.history
+    assert len(hist) == 3 and {"train_loss", "valid_loss", "valid_loss_best", "lr", "dur", "train_accuracy",
+                               "valid_neg_log_loss"} <= set(hist[0])
+    # oracle over the same internal split / batch order
+    idx_tr, idx_va = net._train_split(ds)
+    tr_ds, va_ds = ds[idx_tr], ds[idx_va]
+    fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=4, num_layers=2)
+    trn = train_ref.Trainer(sd0, fwd, pad_tgt=1, lr=0.05, momentum=0.9, max_norm=0.5)
+    X, y = torch.from_numpy(tr_ds.ids), torch.from_numpy(tr_ds.y)
+    Xv, yv = torch.from_numpy(va_ds.ids), torch.from_numpy(va_ds.y)
+    for ep in range(3):
+        tot, n = 0.0, 0
+        for i in range(0, len(tr_ds), 20):
+            loss, _, _ = trn.step(X[i:i + 20], y[i:i + 20], None)
+            tot += float(loss) * len(X[i:i + 20]); n += len(X[i:i + 20])
+        with torch.no_grad():
+            vl = 0.0
+            for i in range(0, len(va_ds), 20):
+                vl += float(train_ref.cross_entropy_on_logprobs(fwd(trn.sd, Xv[i:i + 20], yv[i:i + 20], None), yv[i:i + 20], 1)) * len(Xv[i:i + 20])
+        print(f"epoch {ep}: train {hist[ep]['train_loss']:.5f} vs oracle {tot / n:.5f}; valid {hist[ep]['valid_loss']:.5f} vs {vl / len(va_ds):.5f}")
+        assert abs(hist[ep]["train_loss"] - tot / n) < 2e-3 * (tot / n)
+        assert abs(hist[ep]["valid_loss"] - vl / len(va_ds)) < 2e-3 * (vl / len(va_ds))
+    proba = net.predict_proba(ds)
+    assert proba.shape == (120, len(ds.vocab_y)) and np.allclose(proba.sum(1), 1.0, atol=1e-5)
+    assert net.predict(ds).shape == (120,)
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"]
+
+
+def test_fused_step_equals_autograd_path():
+    """The fused hipGraph step and the torch-optimizer path around the autograd Function agree."""
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(80, seq_len=12, src_vocab=64, n_labels=6, seed=6, min_len=3)
+    losses = []
+    for opt_kw in ({}, {"optimizer__nesterov": False, "optimizer__weight_decay": 1e-30}):   # 2nd: forces the generic path
+        torch.manual_seed(11)
+        net = make_net(ds, max_epochs=2, **opt_kw).fit(ds)
+        losses.append([h["train_loss"] for h in net.history])
+    assert np.allclose(losses[0], losses[1], rtol=2e-3), losses
+
+
+def test_callbacks_semantics(tmp_path):
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(100, seq_len=10, src_vocab=50, n_labels=5, seed=8, min_len=3)
+    torch.manual_seed(3)
+    net = make_net(ds, max_epochs=40, lr=1e-6, early_stopping={"patience": 3, "threshold": 1e-4, "threshold_mode": "rel"},
+                   lr_scheduler={"policy": "ReduceLROnPlateau", "factor": 0.2, "patience": 1},
+                   checkpoint_dir=str(tmp_path))
+    net.fit(ds)
+    assert len(net.history) < 40                                   # lr ~ 0: no improvement -> early stop
+    assert net.history[-1]["lr"] < 1e-6                            # plateau scheduler cut the lr
+    assert (tmp_path / "params.pt").exists() and (tmp_path / "history.json").exists()
+    sd = torch.load(tmp_path / "params.pt")
+    assert "src_pos_encoding.pe" in sd and "transformer.decoder.layers.1.norm3.bias" in sd
+
+
+def test_sklearn_gridsearch_drives_the_estimator():
+    from sklearn.model_selection import GridSearchCV
+    from slnlp.data import synthetic_dataset
+    from slnlp.net import ScoringWrapper
+    ds = synthetic_dataset(90, seq_len=10, src_vocab=50, n_labels=3, seed=9, min_len=3)
+    net = make_net(ds, max_epochs=2)
+    gs = GridSearchCV(net, {"lr": [0.1, 0.01], "module__num_layers": [1, 2]}, cv=3, refit=True,
+                      scoring=ScoringWrapper("neg_log_loss", ds.labels()), error_score="raise")
+    gs.fit(ds, ds.y)
+    assert len(gs.cv_results_["params"]) == 4 and np.isfinite(gs.best_score_)
+    assert gs.best_estimator_.predict(ds).shape == (90,)
