@@ -51,7 +51,9 @@ int slnlp_abi_version(void);
  *   wgrad     dW = dy^T x    : A=dy  NOT kmajor, B=x NOT kmajor (k = token)
  * precision: 1 = single bf16 pass (~5e-3 rel); 3 = split-bf16 hi/lo, three MFMA
  * passes (~2e-5 rel, the parity-grade default).
- * Epilogue order: +bias[n] -> relu -> *gate -> dropout -> +resid.
+ * Epilogue order: +bias[n] -> activation (relu: 1 = ReLU, 2 = tanh) -> *gate -> dropout -> +resid.
+ * gate_mode 0: C *= (gate > 0 ? gate_scale : 0)   (ReLU + inverted-dropout backward, gate = saved output)
+ * gate_mode 1: C *= (1 - gate^2)                   (tanh backward, gate = saved tanh output)
  */
 typedef struct slnlp_gemm_args {
     const float* A; int64_t lda; int32_t a_kmajor;
@@ -65,6 +67,7 @@ typedef struct slnlp_gemm_args {
     const float* resid; int64_t ldr; /* added last; may alias C */
     float* rowsum_a;              /* [M] or NULL: sum_k A(m,k) (bias grad fused into wgrad) */
     int32_t precision;            /* 1 or 3 */
+    int32_t gate_mode;            /* see above */
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
@@ -74,7 +77,8 @@ int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
  * model/transformer.py:106-109 forward_embedding; positional_encoding.py:48-49.
  * ids is batch-first int64 [B,S] with row stride ld_ids (for y: S=1). */
 int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V,
-                    const float* table, const float* pe, float* out,
+                    const float* table, const float* pe /* NULL: no positional term */, float* out,
+                    float scale /* sqrt(E) for the Transformer, 1 for the RNN models (bkp.py:49) */,
                     float drop_p, int drop_site, const unsigned long long* rng,
                     int64_t nan_idx /* id whose rows become NaN (decoder <pad> target), or -1 */, void* stream);
 /* dtable[v,:] = sqrt(E) * sum_{tokens with id v} dropout_bwd(dx[token,:]);
@@ -82,7 +86,8 @@ int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int
  * float atomics).  scratch: slnlp_embed_bwd_scratch_bytes(B,S,E) bytes. */
 int64_t slnlp_embed_bwd_scratch_bytes(int B, int S, int E);
 int slnlp_embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V,
-                    const float* dx, float* dtable,
+                    const float* dx, float* dtable, float scale,
+                    int64_t zero_row /* nn.Embedding(padding_idx): this row gets no gradient; -1 = none */,
                     float drop_p, int drop_site, const unsigned long long* rng,
                     void* scratch, void* stream);
 
@@ -162,6 +167,55 @@ int slnlp_clip_sgd_step(float* params, const float* grads, float* momentum_buf, 
 int slnlp_dropout_mask(float* out, int R, int C, float p, int site,
                        const unsigned long long* rng, void* stream);
 
+/* ---------------------------------------------------------- LSTM / GRU cell --
+ * Point-wise cell of torch.nn.LSTM (gates i,f,g,o) / torch.nn.GRU (r,z,n) as the
+ * reference instantiates them (bkp.py:95-100,186-190), one timestep of up to two
+ * directions per launch.  xproj = x W_ih^T + b_ih and hproj = h_{t-1} W_hh^T + b_hh
+ * come from slnlp_gemm.  Sequence b advances only while t < lengths[b]
+ * (pack_padded_sequence, bkp.py:110-114); otherwise the state is carried and the
+ * layer output is `fill` (pad_packed_sequence(padding_value=pad_idx), :120-123).
+ * lengths == NULL: every row is valid (decoder step). */
+typedef struct slnlp_rnn_cell_dir {
+    const float* xproj;      /* [B, G*Hd] of this timestep */
+    const float* hproj;      /* [B, G*Hd] */
+    float* h;                /* [B, Hd] running state, updated in place */
+    float* c;                /* LSTM: [B, Hd] running cell state */
+    float* hprev_save;       /* [B, Hd] h before the update (kept for backward) */
+    float* cprev_save;       /* LSTM */
+    float* acts;             /* [B, G*Hd] gate activations (kept for backward) */
+    float* hn_save;          /* GRU: [B, Hd] hidden part of the n gate */
+    float* out;              /* layer output rows of this timestep (row stride ld_out), or NULL */
+    int32_t t, out_row0, out_col0; /* timestep; (row, col) origin of `out` inside its dropout site */
+} slnlp_rnn_cell_dir;
+int slnlp_rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int Hd,
+                       const int64_t* lengths, float fill, int64_t ld_out,
+                       float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+/* Backward of one timestep: consumes the running d(state) and d(out), emits the gate
+ * gradients dgx (w.r.t. xproj) / dgh (w.r.t. hproj; LSTM: same buffer as dgx) and
+ * `carry`, the part of dh that bypasses the recurrent matmul; the caller forms
+ * dh_state(t-1) = dgh W_hh + carry with slnlp_gemm. */
+typedef struct slnlp_rnn_cell_bwd_dir {
+    float* dh_state; float* dc_state;
+    const float* dout;       /* d(layer output) rows of this timestep (row stride ld_dout), or NULL */
+    const float* acts; const float* cprev_save; const float* hprev_save; const float* hn_save;
+    float* dgx; float* dgh; float* carry;
+    int32_t t, out_row0, out_col0;
+} slnlp_rnn_cell_bwd_dir;
+int slnlp_rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, int Hd,
+                       const int64_t* lengths, int64_t ld_dout,
+                       float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+
+/* Bahdanau (MLP) attention, one query per sequence (bkp.py:304-327 with max_len 1):
+ * scores[s] = w_e . tanh(q[b] + proj_key[s,b]); masked where ids[b,s] == pad; softmax;
+ * ctx = alphas . value.  proj_key [S*B,Hd] / value [S*B,2Hd] rows are time-major. */
+int slnlp_bahdanau_fwd(const float* q, const float* proj_key, const float* value, const float* w_energy,
+                       const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int B, int S, int Hd,
+                       float* alphas, float* ctx, void* stream);
+int slnlp_bahdanau_bwd(const float* q, const float* proj_key, const float* value, const float* w_energy,
+                       const float* alphas, const float* dctx, int B, int S, int Hd,
+                       float* dq, float* dproj_key, float* dvalue, float* dwe_partial /* [B,Hd] scratch */,
+                       float* dw_energy, void* stream);
+
 /* ------------------------------------------------------ Transformer plan --
  * Whole-model drop-in for model.Transformer (model/transformer.py:10-109):
  * the library owns the parameter-arena LAYOUT (names follow the reference
@@ -221,6 +275,42 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* plan, int B, void* stream);
 /* test helper: copy a named activation tap ("enc0", "memory", "dec1", "logits", ...) */
 int slnlp_tf_tap(slnlp_tf_plan* plan, const char* name, float* out, int64_t max_floats,
                  int64_t* n_out, void* stream);
+
+
+/* ------------------------------------------------- enc-dec RNN (+attn) plan --
+ * Whole-model drop-in for model.EncoderDecoder{LSTM,GRU}Attn
+ * (model/base/encoder_decoder_attn_bkp.py:330-413): packed bidirectional encoder
+ * (:102-132), bridge (:268-280), ONE Bahdanau-attention decoder step fed <bos>
+ * (:202-266 with MAX_OUTPUT_LEN = 1, :332), generator on the decoder state (:40-46,69-76).
+ * Same conventions as the Transformer plan; buffers are a slnlp_tf_buffers (pe unused). */
+typedef struct slnlp_rnn_config {
+    int32_t lstm;                /* 1 = LSTM, 0 = GRU */
+    int32_t E, Hd, N;            /* embedding_size, hidden_size, num_layers */
+    int32_t Vs, Vt, B, S;
+    int32_t pad_src, pad_tgt, bos_idx;   /* bos_idx = tgt_vocab.stoi['<bos>'] (0 on a torchtext-0.6 vocab) */
+    float dropout;
+    int32_t precision;
+} slnlp_rnn_config;
+int slnlp_rnn_num_params(const slnlp_rnn_config* cfg);
+int slnlp_rnn_param_info(const slnlp_rnn_config* cfg, int i, char* name, int64_t shape[2], int* ndim, int64_t* offset);
+int64_t slnlp_rnn_arena_floats(const slnlp_rnn_config* cfg);
+int64_t slnlp_rnn_workspace_bytes(const slnlp_rnn_config* cfg);
+typedef struct slnlp_rnn_plan slnlp_rnn_plan;
+int slnlp_rnn_create(const slnlp_rnn_config* cfg, const slnlp_tf_buffers* buf, slnlp_rnn_plan** out);
+void slnlp_rnn_destroy(slnlp_rnn_plan* plan);
+/* X int64 [B,S], y int64 [B] (only the criterion reads it: the decoder consumes <bos>), lengths int64 [B] */
+int slnlp_rnn_forward(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, const int64_t* lengths, int B,
+                      int train, float* logp, void* stream);
+int slnlp_rnn_seed_dlogp(slnlp_rnn_plan* plan, const float* dlogp, void* stream);
+int slnlp_rnn_backward(slnlp_rnn_plan* plan, void* stream);
+int slnlp_rnn_optim(slnlp_rnn_plan* plan, float momentum, float max_norm, void* stream);
+int slnlp_rnn_train_step(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, const int64_t* lengths, int B,
+                         float momentum, float max_norm, float* logp, void* stream);
+int slnlp_rnn_graph_capture_train(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, const int64_t* lengths,
+                                  int B, float momentum, float max_norm, float* logp, void* stream);
+int slnlp_rnn_graph_launch(slnlp_rnn_plan* plan, int B, void* stream);
+/* taps: "enc_out" [S*B,2Hd] (time-major), "enc_final" [N*B,2Hd], "alphas" [B,S], "context" [B,2Hd], "dec_out" [B,Hd], "logits" */
+int slnlp_rnn_tap(slnlp_rnn_plan* plan, const char* name, float* out, int64_t max_floats, int64_t* n_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -106,9 +106,11 @@ __device__ __forceinline__ float wave_max(float v) {
 namespace slnlp {
 int gemm(const slnlp_gemm_args& a, hipStream_t s);
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
-              float* out, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx, hipStream_t st);
+              float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
+              hipStream_t st);
 int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
-              float drop_p, int drop_site, const unsigned long long* rng, void* scratch, hipStream_t st);
+              float scale, int64_t zero_row, float drop_p, int drop_site, const unsigned long long* rng, void* scratch,
+              hipStream_t st);
 size_t embed_bwd_scratch_bytes(int B, int S, int E);
 int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
@@ -133,6 +135,17 @@ int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hi
 int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
             float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st);
 int lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits, hipStream_t st);
+int rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, float fill,
+                 int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
+                 int64_t ld_dout, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int bahdanau_fwd(const float* q, const float* pk, const float* val, const float* we, const int64_t* ids,
+                 int64_t ld_ids, int64_t pad, int B, int S, int Hd, float* alphas, float* ctx, hipStream_t st);
+int bahdanau_bwd(const float* q, const float* pk, const float* val, const float* we, const float* alphas,
+                 const float* dctx, int B, int S, int Hd, float* dq, float* dpk, float* dval, float* dwe_part,
+                 float* dwe, hipStream_t st);
+int add_rows(const float* in, int64_t ld_in, float* out, int64_t ld_out, int R, int C, int accumulate, hipStream_t st);
+int tanh_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t st);
 int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                   float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
                   hipStream_t st);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
         const long id = ids[(long)b * ld_ids + s];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (id >= 0 && id < V) v = *reinterpret_cast<const float4*>(table + id * E + c);
-        const float4 p = *reinterpret_cast<const float4*>(pe + (long)s * E + c);
+        const float4 p = pe ? *reinterpret_cast<const float4*>(pe + (long)s * E + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = v.x * scale + p.x; v.y = v.y * scale + p.y; v.z = v.z * scale + p.z; v.w = v.w * scale + p.w;
         if (drop_p > 0.f) {
             v.x = dropout_keep(rng, drop_site, m, c + 0, drop_thr) ? v.x * ik : 0.f;
@@ -153,15 +153,16 @@ __global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __res
 }
 
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
-              float* out, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx, hipStream_t st) {
-    SLNLP_CHECK_ARG(ids && table && pe && out, "embed_fwd: null pointer");
+              float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
+              hipStream_t st) {
+    SLNLP_CHECK_ARG(ids && table && out, "embed_fwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_fwd: bad shape B=%d S=%d E=%d V=%d", B, S, E, V);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_fwd: bad dropout args");
     const long total = (long)B * S * (E / 4);
     int grid = ceil_div(total, 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V,
-                       table, pe, out, sqrtf((float)E), drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx);
+                       table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx);
     SLNLP_CHECK_LAUNCH("embed_fwd");
     return 0;
 }
@@ -171,7 +172,8 @@ size_t embed_bwd_scratch_bytes(int B, int S, int E) {
 }
 
 int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
-              float drop_p, int drop_site, const unsigned long long* rng, void* scratch, hipStream_t st) {
+              float scale, int64_t zero_row, float drop_p, int drop_site, const unsigned long long* rng, void* scratch,
+              hipStream_t st) {
     SLNLP_CHECK_ARG(ids && dx && dtable && scratch, "embed_bwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_bwd: bad shape");
     SLNLP_CHECK_ARG((long)B * S <= 65536, "embed_bwd: more than 65536 tokens per batch");
@@ -186,9 +188,13 @@ int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3(ceil_div(M, EMB_CHUNK)), dim3(256), 0, st, (const long*)ids,
                        (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng);
     SLNLP_CHECK_LAUNCH("embed_bwd_chunk");
-    hipLaunchKernelGGL(embed_bwd_combine_kernel, dim3(M), dim3(256), 0, st, pid, M, E, partial, dtable,
-                       sqrtf((float)E));
+    hipLaunchKernelGGL(embed_bwd_combine_kernel, dim3(M), dim3(256), 0, st, pid, M, E, partial, dtable, scale);
     SLNLP_CHECK_LAUNCH("embed_bwd_combine");
+    if (zero_row >= 0 && zero_row < V &&
+        hipMemsetAsync(dtable + zero_row * E, 0, (size_t)E * sizeof(float), st) != hipSuccess) {
+        set_error("embed_bwd: memset of the padding_idx row failed");
+        return SLNLP_ERR_LAUNCH;
+    }
     return 0;
 }
 
@@ -536,14 +542,17 @@ __global__ void dropout_mask_kernel(float* out, int R, int C, unsigned thr, int 
 
 extern "C" {
 int slnlp_embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table,
-                    const float* pe, float* out, float drop_p, int drop_site, const unsigned long long* rng,
-                    int64_t nan_idx, void* stream) {
-    return slnlp::embed_fwd(ids, ld_ids, B, S, E, V, table, pe, out, drop_p, drop_site, rng, nan_idx, (hipStream_t)stream);
+                    const float* pe, float* out, float scale, float drop_p, int drop_site,
+                    const unsigned long long* rng, int64_t nan_idx, void* stream) {
+    return slnlp::embed_fwd(ids, ld_ids, B, S, E, V, table, pe, out, scale, drop_p, drop_site, rng, nan_idx,
+                            (hipStream_t)stream);
 }
 int64_t slnlp_embed_bwd_scratch_bytes(int B, int S, int E) { return (int64_t)slnlp::embed_bwd_scratch_bytes(B, S, E); }
 int slnlp_embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
-                    float drop_p, int drop_site, const unsigned long long* rng, void* scratch, void* stream) {
-    return slnlp::embed_bwd(ids, ld_ids, B, S, E, V, dx, dtable, drop_p, drop_site, rng, scratch, (hipStream_t)stream);
+                    float scale, int64_t zero_row, float drop_p, int drop_site, const unsigned long long* rng,
+                    void* scratch, void* stream) {
+    return slnlp::embed_bwd(ids, ld_ids, B, S, E, V, dx, dtable, scale, zero_row, drop_p, drop_site, rng, scratch,
+                            (hipStream_t)stream);
 }
 int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                         float* stats, void* stream) {

@@ -280,8 +280,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                 const int gm = gm0 + r;
                 if (gm >= M) break;
                 float v = acc[i][j][r] + bias;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.gate) v = (g.gate[(long)gm * g.ldg + gn] > 0.f) ? v * g.gate_scale : 0.f;
+                if (g.relu == 1) v = fmaxf(v, 0.f);
+                else if (g.relu == 2) v = tanhf(v);
+                if (g.gate) {
+                    const float gt = g.gate[(long)gm * g.ldg + gn];
+                    v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
+                }
                 if (g.drop_p > 0.f) v = (pick_word(bits, r) >= p.drop_thr) ? v * p.drop_scale : 0.f;
                 if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
                 g.C[(long)gm * g.ldc + gn] = v;

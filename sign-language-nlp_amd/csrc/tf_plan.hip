@@ -466,8 +466,8 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     const unsigned long long* rng = pl->buf.rng;
     pl->last_B = B; pl->last_p = p; pl->last_X = X; pl->last_y = y;
 
-    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, p, SITE_SRC_EMB, rng, -1, st));
-    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, p, SITE_TGT_EMB, rng, c.pad_tgt, st));
+    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st));
+    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st));
 
     const float* x = w.x0;
     for (int l = 0; l < c.N; ++l) {
@@ -623,7 +623,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         dt = a.gt0;
     }
     SLNLP_TRY(pl->fork(st, 2));
-    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s2));
+    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s2));
 
     // encoder: needs the complete d memory
     SLNLP_TRY(pl->join(st, 0));
@@ -655,7 +655,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         SLNLP_TRY(pl->dgrad(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1, st));
         dx = a.gx0;
     }
-    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), p, SITE_SRC_EMB, rng, w.emb_scratch_src, st));
+    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st));
     SLNLP_TRY(pl->join_all(st));
     SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
     return 0;

@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
                 ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("drop_site", i32), ("rng", vp),
                 ("resid", vp), ("ldr", i64),
-                ("rowsum_a", vp), ("precision", i32)]
+                ("rowsum_a", vp), ("precision", i32), ("gate_mode", i32)]
 
 
 class TfConfig(C.Structure):
@@ -36,6 +36,22 @@ class TfBuffers(C.Structure):
                 ("rng", vp), ("lr", vp), ("scalars", vp)]
 
 
+class RnnConfig(C.Structure):
+    _fields_ = [("lstm", i32), ("E", i32), ("Hd", i32), ("N", i32), ("Vs", i32), ("Vt", i32), ("B", i32), ("S", i32),
+                ("pad_src", i32), ("pad_tgt", i32), ("bos_idx", i32), ("dropout", f32), ("precision", i32)]
+
+
+class RnnCellDir(C.Structure):
+    _fields_ = [("xproj", vp), ("hproj", vp), ("h", vp), ("c", vp), ("hprev_save", vp), ("cprev_save", vp),
+                ("acts", vp), ("hn_save", vp), ("out", vp), ("t", i32), ("out_row0", i32), ("out_col0", i32)]
+
+
+class RnnCellBwdDir(C.Structure):
+    _fields_ = [("dh_state", vp), ("dc_state", vp), ("dout", vp), ("acts", vp), ("cprev_save", vp),
+                ("hprev_save", vp), ("hn_save", vp), ("dgx", vp), ("dgh", vp), ("carry", vp),
+                ("t", i32), ("out_row0", i32), ("out_col0", i32)]
+
+
 class LnReduceEntry(C.Structure):
     _fields_ = [("partial", vp), ("dgamma", vp), ("dbeta", vp), ("nblk", i32), ("E", i32)]
 
@@ -46,9 +62,9 @@ SIGNATURES = {
     "slnlp_last_error": (C.c_char_p, []),
     "slnlp_abi_version": (i32, []),
     "slnlp_gemm": (i32, [C.POINTER(GemmArgs), vp]),
-    "slnlp_embed_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp, i64, vp]),
+    "slnlp_embed_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "slnlp_embed_bwd_scratch_bytes": (i64, [i32, i32, i32]),
-    "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp]),
+    "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i64, f32, i32, vp, vp, vp]),
     "slnlp_attn_self_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     "slnlp_attn_self_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, f32, i32, vp, vp]),
     "slnlp_attn_cross_fwd": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
@@ -60,6 +76,25 @@ SIGNATURES = {
     "slnlp_lsm_bwd": (i32, [vp, vp, i32, i32, vp, i64, vp]),
     "slnlp_clip_sgd_step": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp]),
     "slnlp_dropout_mask": (i32, [vp, i32, i32, f32, i32, vp, vp]),
+    "slnlp_rnn_cell_fwd": (i32, [i32, C.POINTER(RnnCellDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, vp]),
+    "slnlp_rnn_cell_bwd": (i32, [i32, C.POINTER(RnnCellBwdDir), i32, i32, i32, vp, i64, f32, i32, vp, vp]),
+    "slnlp_bahdanau_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]),
+    "slnlp_bahdanau_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "slnlp_rnn_num_params": (i32, [C.POINTER(RnnConfig)]),
+    "slnlp_rnn_param_info": (i32, [C.POINTER(RnnConfig), i32, C.c_char_p, C.POINTER(i64 * 2), C.POINTER(i32),
+                                   C.POINTER(i64)]),
+    "slnlp_rnn_arena_floats": (i64, [C.POINTER(RnnConfig)]),
+    "slnlp_rnn_workspace_bytes": (i64, [C.POINTER(RnnConfig)]),
+    "slnlp_rnn_create": (i32, [C.POINTER(RnnConfig), C.POINTER(TfBuffers), C.POINTER(vp)]),
+    "slnlp_rnn_destroy": (None, [vp]),
+    "slnlp_rnn_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
+    "slnlp_rnn_seed_dlogp": (i32, [vp, vp, vp]),
+    "slnlp_rnn_backward": (i32, [vp, vp]),
+    "slnlp_rnn_optim": (i32, [vp, f32, f32, vp]),
+    "slnlp_rnn_train_step": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
+    "slnlp_rnn_graph_capture_train": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
+    "slnlp_rnn_graph_launch": (i32, [vp, i32, vp]),
+    "slnlp_rnn_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
     "slnlp_tf_num_params": (i32, [C.POINTER(TfConfig)]),
     "slnlp_tf_param_info": (i32, [C.POINTER(TfConfig), i32, C.c_char_p, C.POINTER(i64 * 2), C.POINTER(i32),
                                   C.POINTER(i64)]),

@@ -15,7 +15,7 @@ def make_rng(seed=0, step=0, device="cuda"):
 
 
 def gemm(A, B, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=None, out=None, ldc=None,
-         bias=None, relu=False, gate=None, gate_scale=1.0, drop_p=0.0, drop_site=0, rng=None,
+         bias=None, relu=False, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0, drop_site=0, rng=None,
          resid=None, rowsum_a=None, precision=3):
     _lib.require_gpu()
     lda = lda if lda is not None else (K if a_kmajor else M)
@@ -31,27 +31,29 @@ def gemm(A, B, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=None, out
     a.gate, a.ldg, a.gate_scale = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale
     a.drop_p, a.drop_site, a.rng = drop_p, drop_site, ptr(rng)
     a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
-    a.rowsum_a, a.precision = ptr(rowsum_a), precision
+    a.rowsum_a, a.precision, a.gate_mode = ptr(rowsum_a), precision, gate_mode
     check(load().slnlp_gemm(C.byref(a), stream_ptr()), "gemm")
     return out
 
 
-def embed_fwd(ids, table, pe, *, B, S, drop_p=0.0, drop_site=0, rng=None, nan_idx=-1):
+def embed_fwd(ids, table, pe, *, B, S, scale=None, drop_p=0.0, drop_site=0, rng=None, nan_idx=-1):
     _lib.require_gpu()
     V, E = table.shape
     out = torch.empty(S * B, E, dtype=torch.float32, device=table.device)
     check(load().slnlp_embed_fwd(ptr(ids), ids.stride(0) if ids.ndim == 2 else 1, B, S, E, V, ptr(table), ptr(pe),
-                                 ptr(out), drop_p, drop_site, ptr(rng), nan_idx, stream_ptr()), "embed_fwd")
+                                 ptr(out), float(E ** 0.5 if scale is None else scale), drop_p, drop_site, ptr(rng),
+                                 nan_idx, stream_ptr()), "embed_fwd")
     return out
 
 
-def embed_bwd(ids, dx, *, B, S, V, drop_p=0.0, drop_site=0, rng=None):
+def embed_bwd(ids, dx, *, B, S, V, scale=None, zero_row=-1, drop_p=0.0, drop_site=0, rng=None):
     _lib.require_gpu()
     E = dx.shape[1]
     dt = torch.empty(V, E, dtype=torch.float32, device=dx.device)
     scratch = torch.empty(int(load().slnlp_embed_bwd_scratch_bytes(B, S, E)), dtype=torch.uint8, device=dx.device)
     check(load().slnlp_embed_bwd(ptr(ids), ids.stride(0) if ids.ndim == 2 else 1, B, S, E, V, ptr(dx), ptr(dt),
-                                 drop_p, drop_site, ptr(rng), ptr(scratch), stream_ptr()), "embed_bwd")
+                                 float(E ** 0.5 if scale is None else scale), zero_row, drop_p, drop_site, ptr(rng),
+                                 ptr(scratch), stream_ptr()), "embed_bwd")
     return dt
 
 

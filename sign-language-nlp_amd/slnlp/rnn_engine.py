@@ -1,0 +1,140 @@
+"""Host-side owner of one EncoderDecoder{LSTM,GRU}Attn plan (libslnlp ``slnlp_rnn_*``).
+Mirrors ``tf_engine.TransformerEngine``: torch allocates arenas / workspace and provides the
+stream; layout, launch sequence and arithmetic live in the HIP library."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import RnnConfig, TfBuffers, check, load, ptr, stream_ptr
+
+
+def make_config(rnn_type, E, Hd, N, Vs, Vt, B, S, pad_src=1, pad_tgt=1, bos_idx=0, dropout=0.0, precision=3):
+    assert rnn_type in ("lstm", "gru"), "Invalid `rnn_type`."       # bkp.py:347
+    return RnnConfig(int(rnn_type == "lstm"), E, Hd, N, Vs, Vt, B, S, pad_src, pad_tgt, bos_idx, float(dropout), precision)
+
+
+def layout(cfg):
+    """[(name, shape, offset)] in reference state_dict order + arena size; host-only query."""
+    lib = load()
+    n = lib.slnlp_rnn_num_params(C.byref(cfg))
+    if n < 0:
+        check(1, "rnn_num_params")
+    out = []
+    for i in range(n):
+        name = C.create_string_buffer(128)
+        shape = (C.c_int64 * 2)()
+        ndim, off = C.c_int32(0), C.c_int64(0)
+        check(lib.slnlp_rnn_param_info(C.byref(cfg), i, name, C.byref(shape), C.byref(ndim), C.byref(off)), "rnn_param_info")
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value)), int(off.value)))
+    return out, int(lib.slnlp_rnn_arena_floats(C.byref(cfg)))
+
+
+class RnnEngine:
+    def __init__(self, cfg, device="cuda", seed=0, params=None, grads=None, momentum=None):
+        _lib.require_gpu()
+        self.cfg, self.device = cfg, torch.device(device)
+        self.entries, self.arena_floats = layout(cfg)
+        dev = self.device
+        mk = lambda t: torch.zeros(self.arena_floats, dtype=torch.float32, device=dev) if t is None else t
+        self.params, self.grads, self.momentum = mk(params), mk(grads), mk(momentum)
+        for t in (self.params, self.grads, self.momentum):
+            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.arena_floats and t.is_contiguous()
+        self.workspace = torch.empty(int(load().slnlp_rnn_workspace_bytes(C.byref(cfg))), dtype=torch.uint8, device=dev)
+        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+        self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.logp = torch.empty(cfg.B, cfg.Vt, dtype=torch.float32, device=dev)
+        bufs = TfBuffers(ptr(self.params), ptr(self.grads), ptr(self.momentum), None, ptr(self.workspace),
+                         ptr(self.rng), ptr(self.lr), ptr(self.scalars))
+        handle = C.c_void_p()
+        check(load().slnlp_rnn_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "rnn_create")
+        self.handle = handle
+        self._graph_keys = {}
+        self._xbuf = self._ybuf = self._lbuf = None
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                load().slnlp_rnn_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    def views(self, arena=None):
+        arena = self.params if arena is None else arena
+        out = {}
+        for name, shape, off in self.entries:
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = arena[off:off + n].view(*shape)
+        return out
+
+    def load_state(self, sd):
+        for k, t in self.views().items():
+            t.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32))
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def forward(self, X, y, lengths, train=False):
+        B = X.shape[0]
+        self._keep = (X.contiguous(), y.contiguous(), lengths.contiguous())
+        X, y, L = self._keep
+        check(load().slnlp_rnn_forward(self.handle, ptr(X), ptr(y), ptr(L), B, int(train), ptr(self.logp), stream_ptr()),
+              "rnn_forward")
+        return self.logp[:B]
+
+    def seed_dlogp(self, dlogp):
+        check(load().slnlp_rnn_seed_dlogp(self.handle, ptr(dlogp.contiguous()), stream_ptr()), "rnn_seed_dlogp")
+
+    def backward(self):
+        check(load().slnlp_rnn_backward(self.handle, stream_ptr()), "rnn_backward")
+
+    def optim(self, momentum=0.9, max_norm=0.5):
+        check(load().slnlp_rnn_optim(self.handle, momentum, max_norm, stream_ptr()), "rnn_optim")
+
+    def train_step(self, X, y, lengths, momentum=0.9, max_norm=0.5):
+        B = X.shape[0]
+        self._keep = (X.contiguous(), y.contiguous(), lengths.contiguous())
+        X, y, L = self._keep
+        check(load().slnlp_rnn_train_step(self.handle, ptr(X), ptr(y), ptr(L), B, momentum, max_norm, ptr(self.logp),
+                                          stream_ptr()), "rnn_train_step")
+        return self.logp[:B]
+
+    def train_step_graph(self, X, y, lengths, momentum=0.9, max_norm=0.5):
+        B = X.shape[0]
+        key = (B, float(momentum), float(max_norm))
+        if self._xbuf is None:
+            dev = self.device
+            self._xbuf = torch.empty(self.cfg.B, self.cfg.S, dtype=torch.int64, device=dev)
+            self._ybuf = torch.empty(self.cfg.B, dtype=torch.int64, device=dev)
+            self._lbuf = torch.empty(self.cfg.B, dtype=torch.int64, device=dev)
+        xb, yb, lb = self._xbuf[:B], self._ybuf[:B], self._lbuf[:B]
+        xb.copy_(X); yb.copy_(y); lb.copy_(lengths)
+        st = stream_ptr()
+        if st == 0:
+            raise RuntimeError("train_step_graph needs a non-default stream (use torch.cuda.stream(...))")
+        if self._graph_keys.get(B) != key:
+            check(load().slnlp_rnn_graph_capture_train(self.handle, ptr(xb), ptr(yb), ptr(lb), B, momentum, max_norm,
+                                                       ptr(self.logp), st), "rnn_graph_capture_train")
+            self._graph_keys[B] = key
+        check(load().slnlp_rnn_graph_launch(self.handle, B, st), "rnn_graph_launch")
+        return self.logp[:B]
+
+    def tap(self, name, rows, cols):
+        out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
+        n = C.c_int64(0)
+        check(load().slnlp_rnn_tap(self.handle, name.encode(), ptr(out), out.numel(), C.byref(n), stream_ptr()), "rnn_tap")
+        assert n.value == rows * cols, (name, n.value, rows, cols)
+        return out
+
+    @property
+    def loss(self):
+        return float(self.scalars[0])
+
+    @property
+    def grad_norm(self):
+        return float(self.scalars[1])

@@ -1,0 +1,139 @@
+"""GPU parity of the EncoderDecoder{LSTM,GRU}Attn path (libslnlp slnlp_rnn_* through
+slnlp.rnn_engine) against the golden vectors captured from the reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import gold
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+TOL_GRAD = 2e-2
+
+
+def make_engine(c, sd, dropout=0.0, precision=3, seed=0):
+    from slnlp import rnn_engine as re_
+    cfg = re_.make_config(c["rnn_type"], c["E"], c["Hd"], c["N"], c["Vs"], c["Vt"], c["B"], c["S"], 1, 1, 0, dropout, precision)
+    eng = re_.RnnEngine(cfg, seed=seed)
+    eng.load_state(sd)
+    return eng
+
+
+CASES = [("lstm", "tiny"), ("lstm", "mid"), ("lstm", "cfg3"), ("gru", "tiny"), ("gru", "mid")]
+
+
+def test_layout_is_reference_state_dict():
+    from oracle import rnn_ref as rr
+    from slnlp import rnn_engine as re_
+    for rt in ("lstm", "gru"):
+        cfg = re_.make_config(rt, 128, 256, 2, 3000, 202, 50, 48)
+        ents, total = re_.layout(cfg)
+        assert [(n, s) for n, s, _ in ents] == [(n, tuple(s)) for n, s in rr.param_shapes(rt, 128, 256, 2, 3000, 202)]
+    n = sum(int(np.prod(s)) for _, s, _ in re_.layout(re_.make_config("lstm", 128, 256, 2, 3000, 200, 50, 48))[0])
+    assert n == 4831744
+
+
+@pytest.mark.parametrize("rnn_type,name", CASES)
+def test_forward_vs_golden(rnn_type, name):
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, name)
+    eng = make_engine(c, sd)
+    logp = eng.forward(X.cuda(), y.cuda(), L.cuda()).cpu()
+    err = gold.rel_err(logp.numpy(), g["logp"])
+    print(f"[{rnn_type} {name}] logp rel err {err:.2e}")
+    assert err < TOL
+    assert np.array_equal(logp.argmax(-1).numpy(), g["argmax"])
+    B, S, Hd, N = c["B"], c["S"], c["Hd"], c["N"]
+    al = eng.tap("alphas", B, S).cpu().numpy()
+    assert gold.rel_err(al.reshape(g["tap_alphas"].shape), g["tap_alphas"]) < TOL
+    fin = eng.tap("enc_final", N * B, 2 * Hd).cpu().view(N, B, 2 * Hd)
+    if name == "tiny":
+        assert gold.rel_err(fin.numpy(), g["tap_enc_final"]) < 2e-4
+        eo = eng.tap("enc_out", S * B, 2 * Hd).cpu().view(S, B, 2 * Hd).transpose(0, 1)      # -> [B,S,2Hd]
+        assert gold.rel_err(eo.numpy(), g["tap_enc_out"]) < 2e-4
+        assert torch.all(eo[torch.arange(S)[None, :] >= L[:, None]] == 1.0)                   # pad rows = float(pad_idx)
+        ctx = eng.tap("context", B, 2 * Hd).cpu().numpy()
+        assert gold.rel_err(ctx.reshape(g["tap_context"].shape), g["tap_context"]) < 2e-4
+        y2 = (y - 2 + 3) % (c["Vt"] - 2) + 2
+        out2 = eng.forward(X.cuda(), y2.cuda(), L.cuda()).cpu()
+        assert torch.equal(out2, logp)                                                        # output independent of y
+    else:
+        assert gold.rel_err(fin[:, :8].numpy(), g["tap_enc_final"]) < TOL
+
+
+@pytest.mark.parametrize("rnn_type,name", [c for c in CASES if c[1] != "cfg3"])
+def test_train_steps_vs_golden(rnn_type, name):
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, name)
+    eng = make_engine(c, sd)
+    eng.set_lr(0.01)
+    Xc, yc, Lc = X.cuda(), y.cuda(), L.cuda()
+    eng.forward(Xc, yc, Lc, train=True)
+    eng.backward()
+    gv = {k: v.cpu() for k, v in eng.views(eng.grads).items()}
+    gold.check_summary(g, "grad0", gv, TOL_GRAD)
+    assert float(gv["model.decoder.pre_output_layer.weight"].abs().max()) == 0.0      # dead weight
+    assert float(gv["model.src_embed.weight"][1].abs().max()) == 0.0                  # padding_idx row
+    assert float(gv["model.trg_embed.weight"][1:].abs().max()) == 0.0                 # only <bos> (=0) sees grad
+    for s in range(len(g["losses"])):
+        eng.train_step(Xc, yc, Lc, momentum=0.9, max_norm=0.5)
+        torch.cuda.synchronize()
+        print(f"[{rnn_type} {name}] step {s}: loss {eng.loss:.6f} (ref {g['losses'][s]:.6f}) norm {eng.grad_norm:.5f} (ref {g['grad_norms'][s]:.5f})")
+        assert abs(eng.loss - g["losses"][s]) < TOL * g["losses"][s]
+        assert abs(eng.grad_norm - g["grad_norms"][s]) < 2e-3 * g["grad_norms"][s]
+    gold.check_summary(g, "wfinal", {k: v.cpu() for k, v in eng.views().items()}, TOL)
+
+
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_gradients_vs_oracle_and_graph(rnn_type):
+    from oracle import rnn_ref, train_ref
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, "tiny")
+    fwd = lambda p, X, y, L: rnn_ref.forward(p, X, y, L, rnn_type=rnn_type, num_layers=c["N"])
+    loss_o, _, grads_o = train_ref.Trainer(sd, fwd, frozen=("model.decoder.pre_output_layer.weight",)).loss_and_grads(X, y, L)
+    eng = make_engine(c, sd)
+    eng.forward(X.cuda(), y.cuda(), L.cuda(), train=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(eng.loss - float(loss_o)) < TOL * float(loss_o)
+    gv = {k: v.cpu() for k, v in eng.views(eng.grads).items()}
+    for k, go in grads_o.items():
+        if go is None:
+            continue
+        scale = float(go.abs().max())
+        e = float((gv[k] - go).abs().max()) / max(scale, 1e-12) if scale > 0 else float(gv[k].abs().max())
+        assert e < 2e-3, f"{k}: grad err {e:.2e}"
+    # graph replay == eager, bitwise
+    e1, e2 = make_engine(c, sd), make_engine(c, sd)
+    e1.set_lr(0.01); e2.set_lr(0.01)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for _ in range(3):
+            e1.train_step(X.cuda(), y.cuda(), L.cuda())
+            e2.train_step_graph(X.cuda(), y.cuda(), L.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(e1.params, e2.params)
+
+
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_dropout_path_vs_oracle_with_same_masks(rnn_type):
+    from oracle import rnn_ref, train_ref
+    from slnlp import ops
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, "tiny")
+    p, B, S, Hd, N = 0.3, c["B"], c["S"], c["Hd"], c["N"]
+    eng = make_engine(c, sd, dropout=p, seed=5)
+    masks = {}
+    for l in range(N - 1):
+        m = ops.dropout_mask(S * B, 2 * Hd, p, 32 + l, eng.rng).cpu().view(S, B, 2 * Hd).transpose(0, 1)
+        masks[f"model.encoder.rnn.dropout{l}"] = m
+        masks[f"model.decoder.rnn.dropout{l}"] = ops.dropout_mask(B, Hd, p, 64 + l, eng.rng).cpu()
+    logp = eng.forward(X.cuda(), y.cuda(), L.cuda(), train=True).cpu().clone()
+    eng.backward()
+    torch.cuda.synchronize()
+    fwd = lambda pr, X, y, L: rnn_ref.forward(pr, X, y, L, rnn_type=rnn_type, num_layers=N, p_drop=p, masks=masks)
+    loss_o, logp_o, grads_o = train_ref.Trainer(sd, fwd, frozen=("model.decoder.pre_output_layer.weight",)).loss_and_grads(X, y, L)
+    assert gold.rel_err(logp.numpy(), logp_o.numpy()) < TOL
+    gv = {k: v.cpu() for k, v in eng.views(eng.grads).items()}
+    for k, go in grads_o.items():
+        if go is None:
+            continue
+        scale = float(go.abs().max())
+        e = float((gv[k] - go).abs().max()) / max(scale, 1e-12) if scale > 0 else float(gv[k].abs().max())
+        assert e < 2e-3, f"{k}: grad err {e:.2e}"
