@@ -34,6 +34,9 @@ WORKLOADS = {
     # configs[0] -- the reference's own CPU-runnable debug case (.vscode/launch.json:26)
     "cfg1": dict(E=128, H=4, N=2, F=256, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
     "e1024": dict(E=1024, H=8, N=6, F=512, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
+    # configs[2] -- EncoderDecoderLSTMAttn hidden=512, 4 layers, batch=50
+    "cfg3": dict(rnn="lstm", E=512, Hd=512, N=4, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
+    "cfg3gru": dict(rnn="gru", E=512, Hd=512, N=4, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
 }
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 MOMENTUM, MAX_NORM, LR = 0.9, 0.5, 0.01
@@ -41,6 +44,11 @@ MOMENTUM, MAX_NORM, LR = 0.9, 0.5, 0.01
 
 def fwd_flops_per_seq(c):
     """SURVEY.md section 8d contract: 2mnk per GEMM, attention dense, T=1."""
+    if "rnn" in c:   # enc-dec RNN: x/h projections of the bi-encoder, key layer, one decoder step, generator
+        E, Hd, N, S, V, G = c["E"], c["Hd"], c["N"], c["S"], c["Vt"], 4 if c["rnn"] == "lstm" else 3
+        enc = sum(2 * S * 2 * G * Hd * ((E if l == 0 else 2 * Hd) + Hd) for l in range(N))
+        dec = sum(2 * G * Hd * ((E + 2 * Hd if l == 0 else Hd) + Hd) for l in range(N))
+        return enc + dec + 2 * S * 2 * Hd * Hd + 2 * N * 2 * Hd * Hd + 2 * Hd * Hd + 4 * S * Hd + 4 * S * Hd + 2 * Hd * V
     E, F, N, S, V = c["E"], c["F"], c["N"], c["S"], c["Vt"]
     enc = N * S * (8 * E * E + 4 * S * E + 4 * E * F)
     dec = N * (12 * E * E + 4 * E + 4 * S * E * E + 4 * S * E + 4 * E * F)
@@ -49,6 +57,13 @@ def fwd_flops_per_seq(c):
 
 def build_sd(c, seed):
     from slnlp import synth, tf_engine as te
+    if "rnn" in c:
+        from slnlp import rnn_engine as re_
+        cfg = re_.make_config(c["rnn"], c["E"], c["Hd"], c["N"], c["Vs"], c["Vt"], c["B"], c["S"], 1, 1, 0, c["dropout"],
+                              c.get("precision", 3))
+        ents, _ = re_.layout(cfg)
+        w = synth.make_weights([(n, s) for n, s, _ in ents], seed=seed)
+        return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
     cfg = te.make_config(c["E"], c["H"], c["N"], c["F"], c["Vs"], c["Vt"], c["B"], c["S"], 1, 1, c["dropout"],
                          c.get("precision", 3))
     ents, _ = te.layout(cfg)
@@ -56,21 +71,26 @@ def build_sd(c, seed):
     return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
 
 
-def cpu_baseline(c, sd, X, y, budget_s=20.0):
+def cpu_baseline(c, sd, X, y, Ln, budget_s=20.0):
     """The oracle (CPU port of the reference step) timed on this host's cores on a bounded sample."""
-    from oracle import train_ref, transformer_ref as tr
+    from oracle import rnn_ref, train_ref, transformer_ref as tr
     # the GPU box gives this process a CPU share (16 cores per GPU), not the whole host
     cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     masks = None  # dropout-free arithmetic: the reference's bernoulli cost is not charged to the CPU side
-    fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=c["H"], num_layers=c["N"], p_drop=0.0, masks=masks)
-    trn = train_ref.Trainer(sd, fwd, pad_tgt=1, lr=LR, momentum=MOMENTUM, max_norm=MAX_NORM)
+    if "rnn" in c:
+        fwd = lambda p, X, y, L: rnn_ref.forward(p, X, y, L, rnn_type=c["rnn"], num_layers=c["N"])
+        frozen = ("model.decoder.pre_output_layer.weight",)
+    else:
+        fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=c["H"], num_layers=c["N"], p_drop=0.0, masks=masks)
+        frozen = ()
+    trn = train_ref.Trainer(sd, fwd, pad_tgt=1, lr=LR, momentum=MOMENTUM, max_norm=MAX_NORM, frozen=frozen)
     B = c["B"]
-    trn.step(X[:B], y[:B], None)  # warm-up
+    trn.step(X[:B], y[:B], Ln[:B])  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
         i = (n % (X.shape[0] // B)) * B
-        trn.step(X[i:i + B], y[i:i + B], None)
+        trn.step(X[i:i + B], y[i:i + B], Ln[i:i + B])
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 50:
@@ -106,21 +126,24 @@ def main():
     c = dict(WORKLOADS[args.workload], precision=args.precision)
     B, S = c["B"], c["S"]
     cfg, sd = build_sd(c, seed=1 + rank)
-    eng = te.TransformerEngine(cfg, device=dev, seed=1 + rank)
+    if "rnn" in c:
+        from slnlp import rnn_engine as re_
+        eng = re_.RnnEngine(cfg, device=dev, seed=1 + rank)
+    else:
+        eng = te.TransformerEngine(cfg, device=dev, seed=1 + rank)
     eng.load_state(sd)
     eng.set_lr(LR)
     # synthetic dataset, resident in HBM before the timed region (SURVEY.md section 8d recipe)
     n_batches = 200
     Xn, Ln, yn = synth.make_batch(n_batches * B, S, c["Vs"], c["Vt"], seed=1 + rank)
-    Xd, yd = torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev)
+    Xd, yd, Ld = torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev), torch.from_numpy(Ln).to(dev)
 
     stream = torch.cuda.Stream(device=dev)
-    step_fn = eng.train_step if args.eager else eng.train_step_graph
 
     def run(k0, k):
         for i in range(k0, k0 + k):
             j = (i % n_batches) * B
-            step_fn(Xd[j:j + B], yd[j:j + B], MOMENTUM, MAX_NORM)
+            eng.step(Xd[j:j + B], yd[j:j + B], Ld[j:j + B], MOMENTUM, MAX_NORM, graph=not args.eager)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -152,13 +175,19 @@ def main():
         ms_event = ev_ms / args.steps           # HIP events on the launch stream, rank 0
         achieved = step_flops / (ms_event * 1e-3) / 1e12
         # parity on a held-out batch (eval mode) against the CPU oracle
-        from oracle import transformer_ref as tr
+        from oracle import rnn_ref, transformer_ref as tr
         cfg0, sd0 = build_sd(c, seed=1)
-        e2 = te.TransformerEngine(cfg0, device=dev)
-        e2.load_state(sd0)
-        Xe, ye = torch.from_numpy(Xn[:B]), torch.from_numpy(yn[:B])
-        lp = e2.forward(Xe.to(dev), ye.to(dev)).cpu()
-        lo = tr.forward(sd0, Xe, ye, num_heads=c["H"], num_layers=c["N"])
+        Xe, ye, Le = torch.from_numpy(Xn[:B]), torch.from_numpy(yn[:B]), torch.from_numpy(Ln[:B])
+        if "rnn" in c:
+            e2 = re_.RnnEngine(cfg0, device=dev)
+            e2.load_state(sd0)
+            lp = e2.forward(Xe.to(dev), ye.to(dev), Le.to(dev)).cpu()
+            lo = rnn_ref.forward(sd0, Xe, ye, Le, rnn_type=c["rnn"], num_layers=c["N"])
+        else:
+            e2 = te.TransformerEngine(cfg0, device=dev)
+            e2.load_state(sd0)
+            lp = e2.forward(Xe.to(dev), ye.to(dev)).cpu()
+            lo = tr.forward(sd0, Xe, ye, num_heads=c["H"], num_layers=c["N"])
         parity = {"argmax_agree": float((lp.argmax(-1) == lo.argmax(-1)).float().mean()),
                   "logp_rel_err": float((lp - lo).abs().max() / lo.abs().max())}
         out = {
@@ -167,7 +196,9 @@ def main():
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
             "data": "synthetic (numpy seed recipe: ids, lengths, labels; seed-recipe weights)",
-            "config": {"workload": f"{args.workload}: Transformer train step E{c['E']} H{c['H']} N{c['N']} F{c['F']} "
+            "config": {"workload": (f"{args.workload}: EncoderDecoder{c['rnn'].upper()}Attn train step E{c['E']} Hd{c['Hd']} N{c['N']} "
+                                    if "rnn" in c else
+                                    f"{args.workload}: Transformer train step E{c['E']} H{c['H']} N{c['N']} F{c['F']} ") +
                                    f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
                        "launch": "eager" if args.eager else "hipGraph replay", "per_gpu": "independent fit (grid shard)"},
@@ -178,7 +209,7 @@ def main():
             "parity": parity, "final_loss": round(loss_end, 5),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn))
+            out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))
             out["gpu_over_cpu"] = round(out["value"] / world / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:

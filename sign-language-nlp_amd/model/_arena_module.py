@@ -1,0 +1,135 @@
+"""Shared machinery of the HIP-backed drop-in modules: every nn.Parameter is a view of ONE flat
+fp32 arena whose layout the HIP library defines, and the forward is a ``torch.autograd.Function``
+whose backward launches the HIP backward and hands each parameter its gradient."""
+import torch
+import torch.nn as nn
+
+
+class _Holder(nn.Module):
+    """Name-space node so parameters get the reference's dotted key names."""
+
+
+def _register(root, dotted, tensor, is_param=True):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if not hasattr(node, p):
+            node.add_module(p, _Holder())
+        node = getattr(node, p)
+    if is_param:
+        node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=True))
+    else:
+        node.register_buffer(parts[-1], tensor)
+
+
+class _HipFn(torch.autograd.Function):
+    """log-probs = HIP forward; backward = HIP backward into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, module, inputs, *params):
+        eng = module._engine_for(inputs[0].shape[0], inputs[0].shape[1])
+        logp = eng.forward(*inputs, train=True).clone()
+        ctx.module, ctx.eng = module, eng
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        eng = ctx.eng
+        eng.seed_dlogp(dlogp)
+        eng.backward()
+        gv = eng.views(eng.grads)
+        dead = ctx.module._dead_params
+        grads = tuple(None if name in dead else gv[name].clone() for name in ctx.module._param_names)
+        return (None, None) + grads
+
+
+class ArenaModule(nn.Module):
+    """Subclasses set ``_entries`` [(name, shape, offset)], ``_arena_floats`` and implement
+    ``_state_order(views)`` (registration order incl. buffers) and ``_make_engine(B, S, old)``."""
+
+    _dead_params = frozenset()
+
+    def _setup_arena(self, entries, total, init_values):
+        self._entries = entries
+        self._param_names = [n for n, _, _ in entries]
+        self._engines = {}
+        self._build(torch.zeros(total, dtype=torch.float32), init_values)
+
+    def _state_order(self, views):
+        raise NotImplementedError
+
+    def _make_engine(self, B, S, old):
+        raise NotImplementedError
+
+    def _build(self, arena, values=None):
+        for name in list(self._modules):
+            del self._modules[name]
+        self._arena = arena
+        views = {}
+        for name, shape, off in self._entries:
+            n = 1
+            for s in shape:
+                n *= s
+            views[name] = arena[off:off + n].view(*shape)
+            if values is not None:
+                with torch.no_grad():
+                    views[name].copy_(values[name])
+        for name, tensor, is_param in self._state_order(views):
+            _register(self, name, tensor, is_param)
+
+    def to(self, device):
+        """Reference contract (transformer.py:50-58, bkp.py:383-386): move, remember the device, return self."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self._arena.device:
+            grads = {n: p.grad for n, p in self.named_parameters() if p.grad is not None}
+            self._move_buffers(device)
+            self._build(self._arena.detach().to(device))
+            for n, p in self.named_parameters():
+                if n in grads:
+                    p.grad = grads[n].to(device)
+            self._engines = {}
+        self.device = device
+        return self
+
+    def _move_buffers(self, device):
+        pass
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def _engine_for(self, B, S):
+        """One HIP plan per sequence length, grown when a larger batch arrives; all share the arenas."""
+        if not self._arena.is_cuda:
+            raise RuntimeError("%s: the module is on %s -- the HIP path is the only compute path "
+                               "(no CPU fallback); call .to('cuda') first" % (type(self).__name__, self._arena.device))
+        eng = self._engines.get(S)
+        if eng is None or eng.cfg.B < B:
+            old = eng
+            eng = self._make_engine(max(B, old.cfg.B if old is not None else 0), S, old)
+            if old is not None:
+                eng.rng.copy_(old.rng)
+                eng.lr.copy_(old.lr)
+            self._engines[S] = eng
+        return eng
+
+    def engine(self, B, S):
+        """Public handle for the fused-step estimator (slnlp.net)."""
+        return self._engine_for(B, S)
+
+    def _run(self, inputs):
+        if self.training and torch.is_grad_enabled():
+            named = dict(self.named_parameters())
+            return _HipFn.apply(self, inputs, *[named[n] for n in self._param_names])
+        eng = self._engine_for(inputs[0].shape[0], inputs[0].shape[1])
+        return eng.forward(*inputs, train=self.training).clone()
+
+    # engines hold ctypes handles: rebuild lazily after copy / pickle (sklearn.clone, checkpoints)
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_engines"] = {}
+        return d

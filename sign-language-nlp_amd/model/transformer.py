@@ -11,32 +11,14 @@ defines; forward / backward run through ``libslnlp.so`` (``slnlp.tf_engine``).
 There is no CPU compute path: calling ``forward`` on a CPU-resident module
 raises.  Autograd integration: in training mode ``forward`` is a
 ``torch.autograd.Function`` whose backward launches the HIP backward and hands
-each parameter its gradient view, so stock ``torch.optim`` / skorch loops work;
+each parameter its gradient, so stock ``torch.optim`` / skorch loops work;
 ``slnlp.net.NeuralNetClassifier`` uses the fused clip+SGD step instead.
 """
-import math
-
 import torch
 import torch.nn as nn
 
 from . import util
-
-
-class _Holder(nn.Module):
-    """Name-space node so parameters get the reference's dotted key names."""
-
-
-def _register(root, dotted, tensor, is_param=True):
-    parts = dotted.split(".")
-    node = root
-    for p in parts[:-1]:
-        if not hasattr(node, p):
-            node.add_module(p, _Holder())
-        node = getattr(node, p)
-    if is_param:
-        node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=True))
-    else:
-        node.register_buffer(parts[-1], tensor)
+from ._arena_module import ArenaModule
 
 
 def _reference_init(E, H, N, F, dropout, Vs, Vt):
@@ -57,27 +39,7 @@ def _reference_init(E, H, N, F, dropout, Vs, Vt):
     return {k: v.detach() for k, v in sd.items()}
 
 
-class _TransformerFn(torch.autograd.Function):
-    """log-probs = HIP forward; backward = HIP backward into the gradient arena."""
-
-    @staticmethod
-    def forward(ctx, module, X, y, *params):
-        eng = module._engine_for(X.shape[0], X.shape[1])
-        logp = eng.forward(X, y, train=True).clone()
-        ctx.module, ctx.eng = module, eng
-        return logp
-
-    @staticmethod
-    def backward(ctx, dlogp):
-        eng = ctx.eng
-        eng.seed_dlogp(dlogp)
-        eng.backward()
-        gv = eng.views(eng.grads)
-        grads = tuple(gv[name].clone() for name in ctx.module._param_names)
-        return (None, None, None) + grads
-
-
-class Transformer(nn.Module):
+class Transformer(ArenaModule):
     def __init__(self,
                  embedding_size,
                  num_heads,
@@ -108,91 +70,32 @@ class Transformer(nn.Module):
                               Vs=len(src_vocab), Vt=len(tgt_vocab),
                               pad_src=util.get_pad_idx(src_vocab), pad_tgt=util.get_pad_idx(tgt_vocab),
                               dropout=self.dropout_p, precision=self.precision)
-        cfg = te.make_config(B=1, S=1, **self._cfg_args)
-        entries, total = te.layout(cfg)          # host query of the library's arena layout
-        self._entries = entries
-        self._param_names = [n for n, _, _ in entries]
-        arena = torch.zeros(total, dtype=torch.float32)
+        entries, total = te.layout(te.make_config(B=1, S=1, **self._cfg_args))   # host query of the arena layout
+        self._pe = te.positional_table(5000, embedding_size).unsqueeze(1)        # [5000, 1, E] like the reference buffer
         init = _reference_init(embedding_size, num_heads, num_layers, hidden_size, self.dropout_p,
                                len(src_vocab), len(tgt_vocab))
-        pe = te.positional_table(5000, embedding_size).unsqueeze(1)   # [5000, 1, E] like the reference buffer
-        self._build(arena, pe, init)
-        self._engines = {}
+        self._setup_arena(entries, total, init)
 
-    # ------------------------------------------------------------------ state
-    def _build(self, arena, pe, values=None):
-        """(Re)create every nn.Parameter as a view of ``arena``; buffers follow
-        the reference's registration order so ``state_dict()`` keys line up."""
-        for name in list(self._modules):
-            del self._modules[name]
-        self._arena = arena
-        views = {}
-        for name, shape, off in self._entries:
-            n = 1
-            for s in shape:
-                n *= s
-            views[name] = arena[off:off + n].view(*shape)
-            if values is not None:
-                with torch.no_grad():
-                    views[name].copy_(values[name])
-        order = ["src_embedding.weight", ("src_pos_encoding.pe", pe), "tgt_embedding.weight",
-                 ("tgt_pos_encoding.pe", pe)]
-        order += [n for n in self._param_names if n not in ("src_embedding.weight", "tgt_embedding.weight")]
-        for item in order:
-            if isinstance(item, tuple):
-                _register(self, item[0], item[1], is_param=False)
-            else:
-                _register(self, item, views[item])
-        self._pe = pe
+    # registration order = the reference's state_dict order (pe buffers sit after each embedding)
+    def _state_order(self, views):
+        order = [("src_embedding.weight", views["src_embedding.weight"], True),
+                 ("src_pos_encoding.pe", self._pe, False),
+                 ("tgt_embedding.weight", views["tgt_embedding.weight"], True),
+                 ("tgt_pos_encoding.pe", self._pe, False)]
+        order += [(n, views[n], True) for n in self._param_names
+                  if n not in ("src_embedding.weight", "tgt_embedding.weight")]
+        return order
 
-    def to(self, device):
-        """transformer.py:50-58: move, remember the device, return self."""
-        device = torch.device(device)
-        if device.type == "cuda" and device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        if device != self._arena.device:
-            grads = {n: p.grad for n, p in self.named_parameters() if p.grad is not None}
-            self._build(self._arena.detach().to(device), self._pe.to(device))
-            for n, p in self.named_parameters():
-                if n in grads:
-                    p.grad = grads[n].to(device)
-            self._engines = {}
-        self.device = device
-        return self
+    def _move_buffers(self, device):
+        self._pe = self._pe.to(device)
 
-    def cuda(self, device=None):
-        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
-
-    def cpu(self):
-        return self.to("cpu")
-
-    # ----------------------------------------------------------------- engine
-    def _engine_for(self, B, S):
-        """One HIP plan per (max batch, seq_len); all plans share the arenas."""
-        if not self._arena.is_cuda:
-            raise RuntimeError("model.Transformer: the module is on %s -- the HIP path is the only compute "
-                               "path (no CPU fallback); call .to('cuda') first" % self._arena.device)
+    def _make_engine(self, B, S, old):
         from slnlp import tf_engine as te
-        key = S
-        eng = self._engines.get(key)
-        if eng is None or eng.cfg.B < B:
-            cap = max(B, eng.cfg.B if eng is not None else 0)
-            cfg = te.make_config(B=cap, S=S, **self._cfg_args)
-            old = eng
-            eng = te.TransformerEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
-                                       grads=old.grads if old else None, momentum=old.momentum if old else None,
-                                       pe=self._pe.view(-1, self.embedding_size))
-            if old is not None:
-                eng.rng.copy_(old.rng)
-                eng.lr.copy_(old.lr)
-            self._engines[key] = eng
-        return eng
+        cfg = te.make_config(B=B, S=S, **self._cfg_args)
+        return te.TransformerEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
+                                    grads=old.grads if old else None, momentum=old.momentum if old else None,
+                                    pe=self._pe.view(-1, self.embedding_size))
 
-    def engine(self, B, S):
-        """Public handle for the fused-step estimator (slnlp.net)."""
-        return self._engine_for(B, S)
-
-    # ---------------------------------------------------------------- forward
     def forward(self, X, y, lengths=None, **kwargs):
         assert (X is not None), "`X` is a required paramenter"
         assert (y is not None), "`y` is a required paramenter"
@@ -204,11 +107,7 @@ class Transformer(nn.Module):
             X = X.transpose(0, 1)
         X = X.to(self._arena.device, torch.int64).contiguous()
         y = y.to(self._arena.device, torch.int64).reshape(-1).contiguous()
-        if self.training and torch.is_grad_enabled():
-            params = [p for _, p in self.named_parameters()]
-            return _TransformerFn.apply(self, X, y, *params)
-        eng = self._engine_for(X.shape[0], X.shape[1])
-        return eng.forward(X, y, train=self.training).clone()
+        return self._run((X, y))
 
     # kept for API parity with the reference class
     def adjust_batch_in(self, data):
@@ -226,9 +125,3 @@ class Transformer(nn.Module):
     def extra_repr(self):
         return (f"embedding_size={self.embedding_size}, num_heads={self.num_heads}, num_layers={self.num_layers}, "
                 f"hidden_size={self.hidden_size}, dropout={self.dropout_p}, precision={self.precision}")
-
-    # engines hold ctypes handles: rebuild lazily after copy / pickle (sklearn.clone, checkpoints)
-    def __getstate__(self):
-        d = self.__dict__.copy()
-        d["_engines"] = {}
-        return d

@@ -250,8 +250,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             if train and self._fused:
                 eng = self.module_.engine(xb.shape[0], xb.shape[1])
                 eng.set_lr(self.lr_)
-                step = eng.train_step_graph if self.use_graph else eng.train_step
-                logp = step(xb, yb, momentum, max_norm)
+                logp = eng.step(xb, yb, lb, momentum, max_norm, graph=bool(self.use_graph))
                 losses.append(eng.scalars[0].clone())
             elif train:
                 self.optimizer_.zero_grad()

@@ -138,3 +138,7 @@ class RnnEngine:
     @property
     def grad_norm(self):
         return float(self.scalars[1])
+
+    def step(self, X, y, lengths, momentum=0.9, max_norm=0.5, graph=True):
+        """Uniform fused-step entry (estimator)."""
+        return (self.train_step_graph if graph else self.train_step)(X, y, lengths, momentum, max_norm)

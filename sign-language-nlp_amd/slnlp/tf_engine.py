@@ -174,3 +174,7 @@ class TransformerEngine:
     @property
     def grad_norm(self):
         return float(self.scalars[1])
+
+    def step(self, X, y, lengths=None, momentum=0.9, max_norm=0.5, graph=True):
+        """Uniform fused-step entry (estimator): the Transformer ignores ``lengths`` (transformer.py:60)."""
+        return (self.train_step_graph if graph else self.train_step)(X, y, momentum, max_norm)

@@ -99,3 +99,59 @@ def test_seq_first_input_and_growing_batch():
     b = m(X=X.T.cuda(), y=y.cuda())                       # then a larger one (plan is rebuilt)
     assert gold.rel_err(b.cpu().numpy(), g["logp"]) < 1e-3
     assert gold.rel_err(a.cpu().numpy(), g["logp"][:10]) < 1e-3
+
+
+# ----------------------------------------------------------------------------- RNN drop-ins
+def make_rnn(rnn_type, c, dropout=0.0):
+    import model
+    cls = model.EncoderDecoderLSTMAttn if rnn_type == "lstm" else model.EncoderDecoderGRUAttn
+    return cls(src_vocab=model.util.Vocab(c["Vs"]), tgt_vocab=model.util.Vocab(c["Vt"]), batch_first=True,
+               embedding_size=c["E"], hidden_size=c["Hd"], num_layers=c["N"], dropout=dropout)
+
+
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_rnn_state_dict_and_init_parity(rnn_type):
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, "tiny")
+    torch.manual_seed(5)
+    m = make_rnn(rnn_type, c, dropout=0.2)
+    assert list(m.state_dict().keys()) == list(g["param_order"])
+    torch.manual_seed(5)
+    cls = torch.nn.LSTM if rnn_type == "lstm" else torch.nn.GRU
+    enc = cls(input_size=c["E"], hidden_size=c["Hd"], num_layers=c["N"], batch_first=True, bidirectional=True, dropout=0.2)
+    key = torch.nn.Linear(2 * c["Hd"], c["Hd"], bias=False)
+    msd = m.state_dict()
+    for k, v in enc.state_dict().items():
+        assert torch.equal(msd["model.encoder.rnn." + k], v), k
+    assert torch.equal(msd["model.decoder.attention.key_layer.weight"], key.weight)
+    assert float(msd["model.src_embed.weight"][1].abs().max()) == 0.0       # nn.Embedding(padding_idx) zeroes the pad row
+    import model
+    with pytest.raises(AssertionError, match="rnn_type"):
+        model.encoder_decoder_attn.EncoderDecoderAttnBase(src_vocab=model.util.Vocab(8), tgt_vocab=model.util.Vocab(8),
+                                                          batch_first=True, rnn_type="rnn")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rnn_type", ["lstm", "gru"])
+def test_rnn_autograd_training_matches_golden(rnn_type):
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, "tiny")
+    m = make_rnn(rnn_type, c).to(torch.device("cuda"))
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        logp = m(X=X.cuda(), y=y.cuda(), lengths=L.cuda())
+    assert gold.rel_err(logp.cpu().numpy(), g["logp"]) < 1e-3
+    assert np.array_equal(logp.argmax(-1).cpu().numpy(), g["argmax"])
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=1)
+    for s in range(len(g["losses"])):
+        opt.zero_grad()
+        loss = crit(m(X=X.cuda(), y=y.cuda(), lengths=L.cuda()), y.cuda())
+        loss.backward()
+        params = [p for p in m.parameters() if p.grad is not None]
+        norm = torch.nn.utils.clip_grad_norm_(params, 0.5)
+        opt.step()
+        assert abs(float(loss) - g["losses"][s]) < 1e-3 * g["losses"][s], s
+        assert abs(float(norm) - g["grad_norms"][s]) < 2e-3 * g["grad_norms"][s], s
+    assert dict(m.named_parameters())["model.decoder.pre_output_layer.weight"].grad is None   # dead weight, as in the reference
+    gold.check_summary(g, "wfinal", {k: v.detach().cpu() for k, v in m.named_parameters()}, 1e-3)

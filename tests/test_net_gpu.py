@@ -97,3 +97,21 @@ def test_sklearn_gridsearch_drives_the_estimator():
     gs.fit(ds, ds.y)
     assert len(gs.cv_results_["params"]) == 4 and np.isfinite(gs.best_score_)
     assert gs.best_estimator_.predict(ds).shape == (90,)
+
+
+@pytest.mark.parametrize("module", ["model.EncoderDecoderLSTMAttn", "model.EncoderDecoderGRUAttn"])
+def test_rnn_modules_through_the_estimator(module):
+    """config-enc-dec-{lstm,gru}-attn.yaml style fit: same estimator, RNN module, fused step."""
+    from slnlp.data import synthetic_dataset
+    from slnlp.net import NeuralNetClassifier
+    ds = synthetic_dataset(120, seq_len=12, src_vocab=64, n_labels=6, seed=5, min_len=3)
+    torch.manual_seed(3)
+    net = NeuralNetClassifier(module=module, module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y,
+                              module__batch_first=True, module__embedding_size=24, module__hidden_size=32,
+                              module__num_layers=2, module__dropout=0.1, criterion__ignore_index=1,
+                              optimizer__momentum=0.9, lr=0.5, max_epochs=12, batch_size=20,
+                              gradient_clipping={"gradient_clip_value": 0.5}, scoring=["accuracy"])
+    net.fit(ds)
+    h = net.history
+    assert net._fused and h[-1]["train_loss"] < h[0]["train_loss"] - 0.05
+    assert np.allclose(net.predict_proba(ds).sum(1), 1.0, atol=1e-5)
