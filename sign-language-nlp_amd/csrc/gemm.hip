@@ -24,6 +24,8 @@
 // projections / nn.LSTM / nn.GRU that the reference reaches at
 // /root/reference/model/transformer.py:40-48 and
 // /root/reference/model/base/encoder_decoder_attn_bkp.py:95-100,186-200.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace slnlp {
@@ -34,7 +36,12 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int BM = 64, BKT = 64;
-constexpr int KLD = BKT + 8;  // [row][k] image: 72 bf16 = 144 B rows (16-B aligned fragments)
+constexpr int KLD = BKT;      // [row][k] image: 64 bf16 = 128-B rows, 16-B slots XOR-swizzled by (row & 7)
+
+// element offset of (row, k) in the k-major image.  The mixed-row lane groups of ds_read_b128
+// ({0-3,12-15,20-27}, ...) hit 16 distinct 16-B slots of the 256-B bank row with this swizzle;
+// a padded stride cannot do that (the g=1 slots are the g=0 slots shifted by one).
+__device__ __forceinline__ int kmaj_off(int row, int k) { return row * KLD + ((((k >> 3) ^ (row & 7)) << 3) | (k & 7)); }
 
 struct GemmParams {
     slnlp_gemm_args a;
@@ -54,7 +61,7 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // !KMAJOR: element (row,k) at P + k*ld + row; float4 runs along row; ROWS/4 float4 per k.
 template <bool KMAJOR, int ROWS>
 struct TileIO {
-    static constexpr int NV = ROWS * BKT / 4 / 256;       // 4 (ROWS=64) or 1 (ROWS=16)
+    static constexpr int NV = ROWS * BKT / 4 / 256;       // 4 (ROWS=64), 2 (ROWS=32) or 1 (ROWS=16)
     static constexpr int MLD = ROWS + 8;                  // [k][row] image row stride (bf16)
     static constexpr int PLANE = KMAJOR ? ROWS * KLD : BKT * MLD;
 
@@ -92,31 +99,50 @@ struct TileIO {
         }
     }
 
-    template <int NSPLIT>
+    // fp32 -> bf16 hi (+ lo) and store into the LDS image.  hi is the TRUNCATED upper half of the
+    // fp32 word (1 VALU op instead of a round-to-nearest convert); x - hi is exact in fp32 and
+    // lo = rne_bf16(x - hi) absorbs the truncation, so hi + lo still represents x to ~2^-16.
+    // EDGE = false: interior tile, no bounds masks at all.
+    template <int NSPLIT, bool EDGE>
     __device__ static __forceinline__ void stash(unsigned short* __restrict__ T, int tid, const float4 (&r)[NV],
                                                  int row0, int nrows, int k0, int K) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             int row, k;
             coords(tid + 256 * u, row, k);
             float x[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
-            unsigned short hi[4], lo[4];
+            if (EDGE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = row0 + (KMAJOR ? row : row + e), kk = k0 + (KMAJOR ? k + e : k);
-                if (!(rr < nrows && kk < K)) x[e] = 0.f;      // edge / K-tail zero fill (v_cndmask)
-                hi[e] = f2bf(x[e]);
-                if (NSPLIT == 3) lo[e] = f2bf(x[e] - bf2f(hi[e]));
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = row0 + (KMAJOR ? row : row + e), kk = k0 + (KMAJOR ? k + e : k);
+                    if (!(rr < nrows && kk < K)) x[e] = 0.f;      // edge / K-tail zero fill (v_cndmask)
+                }
             }
-            const int off = KMAJOR ? row * KLD + k : k * MLD + row;   // both 8-B aligned
+            const int off = KMAJOR ? kmaj_off(row, k) : k * MLD + row;   // both 8-B aligned
+            unsigned ub[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ub[e] = __float_as_uint(x[e]);
             uint2 w;
-            w.x = hi[0] | ((unsigned)hi[1] << 16);
-            w.y = hi[2] | ((unsigned)hi[3] << 16);
-            *reinterpret_cast<uint2*>(T + off) = w;
             if (NSPLIT == 3) {
-                w.x = lo[0] | ((unsigned)lo[1] << 16);
-                w.y = lo[2] | ((unsigned)lo[3] << 16);
+                w.x = (ub[0] >> 16) | (ub[1] & 0xFFFF0000u);
+                w.y = (ub[2] >> 16) | (ub[3] & 0xFFFF0000u);
+                *reinterpret_cast<uint2*>(T + off) = w;
+                float lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = x[e] - __uint_as_float(ub[e] & 0xFFFF0000u);
+                const bf16x2 l01 = __builtin_convertvector(f32x2{lo[0], lo[1]}, bf16x2);
+                const bf16x2 l23 = __builtin_convertvector(f32x2{lo[2], lo[3]}, bf16x2);
+                w.x = __builtin_bit_cast(unsigned, l01);
+                w.y = __builtin_bit_cast(unsigned, l23);
                 *reinterpret_cast<uint2*>(T + PLANE + off) = w;
+            } else {   // single pass: round to nearest
+                const bf16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, bf16x2);
+                const bf16x2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, bf16x2);
+                w.x = __builtin_bit_cast(unsigned, h01);
+                w.y = __builtin_bit_cast(unsigned, h23);
+                *reinterpret_cast<uint2*>(T + off) = w;
             }
         }
     }
@@ -125,7 +151,7 @@ struct TileIO {
     // lane l holds (row r0 + (l&15), k = kk*32 + 8*(l>>4) + j), j = 0..7.
     __device__ static __forceinline__ bf16x8 frag(const unsigned short* __restrict__ T, int r0, int kk, int lane) {
         if (KMAJOR) {
-            return *reinterpret_cast<const bf16x8*>(T + (r0 + (lane & 15)) * KLD + kk * 32 + ((lane >> 4) << 3));
+            return *reinterpret_cast<const bf16x8*>(T + kmaj_off(r0 + (lane & 15), kk * 32 + ((lane >> 4) << 3)));
         } else {
             // transposing read: lane (i = l&15; q = i>>2, p = i&3) addresses k-row q, columns 4p..4p+3 of a
             // 4(k) x 16(row) block and receives the 4 k-values of column i.
@@ -142,7 +168,7 @@ struct TileIO {
     // bf16(hi)+bf16(lo) value of tile element (row, k) -- for the fused bias-gradient row sums
     template <int NSPLIT>
     __device__ static __forceinline__ float value(const unsigned short* __restrict__ T, int row, int k) {
-        const int off = KMAJOR ? row * KLD + k : k * MLD + row;
+        const int off = KMAJOR ? kmaj_off(row, k) : k * MLD + row;
         float v = bf2f(T[off]);
         if (NSPLIT == 3) v += bf2f(T[PLANE + off]);
         return v;
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     using TA = TileIO<AK, BM>;
     using TB = TileIO<BK, BNT>;
     constexpr int NP = (NSPLIT == 3) ? 2 : 1;
-    constexpr int MT = (BNT == 64) ? 2 : 1;  // 16x16 tiles per wave along M
+    constexpr int MT = (BNT == 16) ? 1 : 2;  // 16x16 tiles per wave along M
     constexpr int NT = (BNT == 64) ? 2 : 1;  // ... along N
     __shared__ __attribute__((aligned(16))) unsigned short As[NP * TA::PLANE];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[NP * TB::PLANE];
@@ -170,9 +196,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
     const slnlp_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // BNT=64: waves 2x2, each 32x32.  BNT=16: waves 4x1, each 16x16.
-    const int wm0 = (BNT == 64) ? (wave >> 1) * 32 : wave * 16;
-    const int wn0 = (BNT == 64) ? (wave & 1) * 32 : 0;
+    // BNT=64: waves 2x2, each 32x32.  BNT=32: waves 2x2, each 32x16.  BNT=16: waves 4x1, each 16x16.
+    const int wm0 = (BNT == 16) ? wave * 16 : (wave >> 1) * 32;
+    const int wn0 = (BNT == 64) ? (wave & 1) * 32 : (BNT == 32) ? (wave & 1) * 16 : 0;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each);
     // remap so each XCD owns a contiguous run of tiles (all column blocks of a few row blocks): its
     // L2 then holds the whole B operand plus a few A panels instead of every panel of both.
@@ -240,23 +266,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     };
 
     // two K-steps per trip so the prefetch registers keep compile-time names
-    for (int kt = 0; kt < ktiles; kt += 2) {
-        lds_barrier();
-        TA::template stash<NSPLIT>(As, tid, ra0, bm0, M, kt * BKT, K);
-        TB::template stash<NSPLIT>(Bs, tid, rb0, bn0, N, kt * BKT, K);
-        lds_barrier();
-        TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 2) * BKT, K, tid, ra0);
-        TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 2) * BKT, K, tid, rb0);
-        consume();
-        if (kt + 1 >= ktiles) break;
-        lds_barrier();
-        TA::template stash<NSPLIT>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
-        TB::template stash<NSPLIT>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
-        lds_barrier();
-        TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 3) * BKT, K, tid, ra1);
-        TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 3) * BKT, K, tid, rb1);
-        consume();
-    }
+    auto mainloop = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            lds_barrier();
+            TA::template stash<NSPLIT, EDGE>(As, tid, ra0, bm0, M, kt * BKT, K);
+            TB::template stash<NSPLIT, EDGE>(Bs, tid, rb0, bn0, N, kt * BKT, K);
+            lds_barrier();
+            TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 2) * BKT, K, tid, ra0);
+            TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 2) * BKT, K, tid, rb0);
+            consume();
+            if (kt + 1 >= ktiles) break;
+            lds_barrier();
+            TA::template stash<NSPLIT, EDGE>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
+            TB::template stash<NSPLIT, EDGE>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
+            lds_barrier();
+            TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 3) * BKT, K, tid, ra1);
+            TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 3) * BKT, K, tid, rb1);
+            consume();
+        }
+    };
+    // interior tile (block-uniform): no bounds masks in the conversion
+    if (bm0 + BM <= M && bn0 + BNT <= N && (K % BKT) == 0) mainloop(std::false_type{});
+    else mainloop(std::true_type{});
     if (do_rowsum) {
         rsum[tid >> 6][tid & 63] = rowsum;
         __syncthreads();
@@ -301,7 +333,7 @@ static void launch2(const GemmParams& p, hipStream_t s) {
     if (narrow) {
         dim3 grid(ceil_div(p.a.N, 16), ceil_div(p.a.M, BM));
         hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 16, VEC>), grid, dim3(256), 0, s, p);
-    } else {
+    } else {   // (64x32 tiles for ~1-block-per-CU grids were measured: no gain, 17.6 vs 16.0 us)
         dim3 grid(ceil_div(p.a.N, 64), ceil_div(p.a.M, BM));
         hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 64, VEC>), grid, dim3(256), 0, s, p);
     }
