@@ -68,9 +68,19 @@ typedef struct slnlp_gemm_args {
     float* rowsum_a;              /* [M] or NULL: sum_k A(m,k) (bias grad fused into wgrad) */
     int32_t precision;            /* 1 or 3 */
     int32_t gate_mode;            /* see above */
+    /* Optional PRE-SPLIT operands (bf16 hi / lo planes, row-major, rows and columns zero-padded to
+     * multiples of 64, row stride ld*_p elements).  When A_hi and B_hi are set the GEMM stages them by
+     * LDS-DMA and does no conversion (A, B, lda, ldb are then ignored; *_lo required for precision 3).
+     * C_hi / C_lo (optional): also emit the result as planes for the next GEMM. C may then be NULL. */
+    const uint16_t* A_hi; const uint16_t* A_lo; int64_t lda_p;
+    const uint16_t* B_hi; const uint16_t* B_lo; int64_t ldb_p;
+    uint16_t* C_hi; uint16_t* C_lo; int64_t ldc_p;
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
+/* fp32 [R,C] (row stride ld) -> bf16 hi/lo planes with row stride ldp (lo may be NULL); writes the valid
+ * region only -- the planes' zero padding comes from their allocation. */
+int slnlp_split_planes(const float* x, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream);
 
 /* ------------------------------------------------------------- embedding --
  * x[s*B+b, :] = table[ids[b,s], :] * sqrt(E) + pe[s, :], then dropout.

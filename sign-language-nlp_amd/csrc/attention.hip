@@ -82,7 +82,7 @@ __device__ __forceinline__ void cols_times_tile(const float* __restrict__ W, con
 __global__ __launch_bounds__(256) void attn_self_fwd_kernel(
     const float* __restrict__ qkv, const long* __restrict__ ids, long ld_ids, long pad_idx, int causal, int B,
     int S, int H, int dh, float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr,
-    int drop_site, const unsigned long long* __restrict__ rng) {
+    int drop_site, const unsigned long long* __restrict__ rng, PlaneOut po) {
     __shared__ __attribute__((aligned(16))) float Qs[SMAX * TLD];
     __shared__ __attribute__((aligned(16))) float Ks[SMAX * TLD];
     __shared__ __attribute__((aligned(16))) float Ps[SMAX * TLD];
@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256) void attn_self_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ti + 16 * r;
-                if (i < S) *reinterpret_cast<float4*>(ctx + ((long)i * B + b) * E + h * dh + d0 + td * 4) = o[r];
+                if (i < S) {
+                    const long at = ((long)i * B + b) * E + h * dh + d0 + td * 4;
+                    *reinterpret_cast<float4*>(ctx + at) = o[r];
+                    store_planes4(po, at, o[r]);
+                }
             }
         }
     }
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_self_fwd_kernel(
 __global__ __launch_bounds__(256) void attn_self_bwd_kernel(
     const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dctx, int B, int S,
     int H, int dh, float* __restrict__ dqkv, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng) {
+    const unsigned long long* __restrict__ rng, PlaneOut po) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ta = smem;                 // dO chunk / Q chunk
     float* Tb = Ta + SMAX * TLD;      // V chunk / K chunk
@@ -226,6 +230,10 @@ __global__ __launch_bounds__(256) void attn_self_bwd_kernel(
                     *reinterpret_cast<float4*>(dst) = dq[r];
                     *reinterpret_cast<float4*>(dst + E) = dk[r];
                     *reinterpret_cast<float4*>(dst + 2 * E) = dv[r];
+                    const long at = dst - dqkv;
+                    store_planes4(po, at, dq[r]);
+                    store_planes4(po, at + E, dk[r]);
+                    store_planes4(po, at + 2 * E, dv[r]);
                 }
             }
         }
@@ -281,7 +289,8 @@ __global__ __launch_bounds__(256) void attn_cross_fwd_kernel(
 __global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ kv, long ld_kv, const float* __restrict__ probs,
     const float* __restrict__ dctx, int B, int S, int H, int dh, float* __restrict__ dq, float* __restrict__ dkv,
-    long ld_dkv, float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* __restrict__ rng) {
+    long ld_dkv, float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* __restrict__ rng,
+    PlaneOut po) {
     __shared__ __attribute__((aligned(16))) float gs[4][XDH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.x * 4 + wave;
@@ -322,6 +331,8 @@ __global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
                 a += dsj * kv[row * ld_kv + h * dh + d];
                 dkv[row * ld_dkv + h * dh + d] = dsj * qd;
                 dkv[row * ld_dkv + E + h * dh + d] = pdj * gd;
+                store_planes1(po, row * ld_dkv + h * dh + d, dsj * qd);
+                store_planes1(po, row * ld_dkv + E + h * dh + d, pdj * gd);
             }
         }
         if (act) dq[(long)b * E + h * dh + d] = a;
@@ -378,26 +389,26 @@ static int check_attn(const char* who, int B, int S, int H, int dh) {
 
 int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
-                  const unsigned long long* rng, hipStream_t st) {
+                  const unsigned long long* rng, hipStream_t st, PlaneOut po) {
     SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
     hipLaunchKernelGGL(attn_self_fwd_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
                        (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site,
-                       rng);
+                       rng, po);
     SLNLP_CHECK_LAUNCH("attn_self_fwd");
     return 0;
 }
 
 int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
-                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st) {
+                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po) {
     SLNLP_TRY(check_attn("attn_self_bwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && probs && dctx && dqkv, "attn_self_bwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
     const size_t lds = ATTN_BWD_LDS;
     SLNLP_TRY(attn_init());
     hipLaunchKernelGGL(attn_self_bwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, probs, dctx, B, S, H, dh, dqkv,
-                       drop_p, dropout_threshold(drop_p), drop_site, rng);
+                       drop_p, dropout_threshold(drop_p), drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_self_bwd");
     return 0;
 }
@@ -416,13 +427,13 @@ int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S,
 
 int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
                    int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
-                   const unsigned long long* rng, hipStream_t st) {
+                   const unsigned long long* rng, hipStream_t st, PlaneOut po) {
     SLNLP_TRY(check_attn("attn_cross_bwd", B, S, H, dh));
     SLNLP_CHECK_ARG(q && kv && probs && dctx && dq && dkv, "attn_cross_bwd: null pointer");
     SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh && ld_dkv >= 2L * H * dh, "attn_cross_bwd: bad ld");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_bwd: bad dropout args");
     hipLaunchKernelGGL(attn_cross_bwd_kernel, dim3(ceil_div(B * H, 4)), dim3(256), 0, st, q, kv, (long)ld_kv, probs,
-                       dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng);
+                       dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_cross_bwd");
     return 0;
 }
@@ -434,7 +445,7 @@ int slnlp_attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, in
                         int S, int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
                         const unsigned long long* rng, void* stream) {
     return slnlp::attn_self_fwd(qkv, ids, ld_ids, pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, drop_site, rng,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, slnlp::PlaneOut{});
 }
 int slnlp_attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh,
                         float* dqkv, float drop_p, int drop_site, const unsigned long long* rng, void* stream) {

@@ -88,6 +88,38 @@ __device__ __forceinline__ bool dropout_keep(const unsigned long long* rng, int 
     return pick_word(b, r & 3) >= thr;
 }
 
+// ------------------------------------------------------- bf16 plane sinks ----
+// Producers of GEMM operands also emit the value as bf16 hi / lo planes (same row stride as the fp32
+// tensor) so the consuming GEMM can stage them by LDS-DMA with no conversion (gemm_planes.hip).
+// hi = truncated upper half of the fp32 word, lo = rne_bf16(x - hi): hi + lo == x to ~2^-16.
+struct PlaneOut {
+    unsigned short* hi = nullptr;
+    unsigned short* lo = nullptr;
+};
+__device__ __forceinline__ void split_bf16(float x, unsigned short& h, unsigned short& l) {
+    const unsigned u = __float_as_uint(x);
+    h = (unsigned short)(u >> 16);
+    __bf16 b = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
+    l = __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ void store_planes1(const PlaneOut& po, long idx, float v) {
+    if (!po.hi) return;
+    unsigned short h, l;
+    split_bf16(v, h, l);
+    po.hi[idx] = h;
+    po.lo[idx] = l;
+}
+__device__ __forceinline__ void store_planes4(const PlaneOut& po, long idx, float4 v) {   // idx % 4 == 0
+    if (!po.hi) return;
+    unsigned short h[4], l[4];
+    split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]); split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+    uint2 w;
+    w.x = h[0] | ((unsigned)h[1] << 16); w.y = h[2] | ((unsigned)h[3] << 16);
+    *reinterpret_cast<uint2*>(po.hi + idx) = w;
+    w.x = l[0] | ((unsigned)l[1] << 16); w.y = l[2] | ((unsigned)l[3] << 16);
+    *reinterpret_cast<uint2*>(po.lo + idx) = w;
+}
+
 // ------------------------------------------------------------- wave ops -----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -105,31 +137,35 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------- internal kernel launchers
 namespace slnlp {
 int gemm(const slnlp_gemm_args& a, hipStream_t s);
+int gemm_planes(const slnlp_gemm_args& a, hipStream_t s);
+int gemm_planes_init();
+int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, unsigned short* lo, int64_t ldp, hipStream_t st);
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
-              hipStream_t st);
+              hipStream_t st, PlaneOut po = {});
 int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
               float scale, int64_t zero_row, float drop_p, int drop_site, const unsigned long long* rng, void* scratch,
               hipStream_t st);
 size_t embed_bwd_scratch_bytes(int B, int S, int E);
 int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
-                  const unsigned long long* rng, hipStream_t st);
+                  const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
 int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
-                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
 int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
                    float* probs, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
 int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
                    int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
-                   const unsigned long long* rng, hipStream_t st);
+                   const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
 int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site, const unsigned long long* rng,
                  hipStream_t st);
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
-                  float* stats, hipStream_t st);
+                  float* stats, hipStream_t st, PlaneOut po = {});
 int ln_bwd_blocks(int rows);
 int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
                   const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
-                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st);
+                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st,
+                  PlaneOut po_dx = {}, PlaneOut po_drop = {});
 int attn_init();
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st);
 int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,

@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
                                                         int E, int V, const float* __restrict__ table,
                                                         const float* __restrict__ pe, float* __restrict__ out,
                                                         float scale, float drop_p, unsigned drop_thr, int drop_site,
-                                                        const unsigned long long* __restrict__ rng, long nan_idx) {
+                                                        const unsigned long long* __restrict__ rng, long nan_idx,
+                                                        PlaneOut po) {
     const int e4 = E >> 2;
     const long total = (long)B * S * e4;
     const float ik = 1.f / (1.f - drop_p);
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
         // (transformer.py:72-73) -> softmax over an empty set -> NaN row in torch.
         if (id == nan_idx) v = make_float4(NAN, NAN, NAN, NAN);
         *reinterpret_cast<float4*>(out + (long)m * E + c) = v;
+        store_planes4(po, (long)m * E + c, v);
     }
 }
 
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __res
 
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
-              hipStream_t st) {
+              hipStream_t st, PlaneOut po) {
     SLNLP_CHECK_ARG(ids && table && out, "embed_fwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_fwd: bad shape B=%d S=%d E=%d V=%d", B, S, E, V);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_fwd: bad dropout args");
@@ -162,7 +164,7 @@ int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     int grid = ceil_div(total, 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V,
-                       table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx);
+                       table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx, po);
     SLNLP_CHECK_LAUNCH("embed_fwd");
     return 0;
 }
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int rows, int E,
                                                             float eps, float* __restrict__ y,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, PlaneOut po) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         o.x = (v.x - mean) * rstd * g.x + b.x; o.y = (v.y - mean) * rstd * g.y + b.y;
         o.z = (v.z - mean) * rstd * g.z + b.z; o.w = (v.w - mean) * rstd * g.w + b.w;
         *reinterpret_cast<float4*>(y + (long)row * E + c) = o;
+        store_planes4(po, (long)row * E + c, o);
     }
     if (lane == 0 && stats) {
         stats[2 * row] = mean;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
     float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng, float* __restrict__ partial) {
+    const unsigned long long* __restrict__ rng, float* __restrict__ partial, PlaneOut po_dx, PlaneOut po_drop) {
     __shared__ float red[4][2][LN_MAXU * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 dg[LN_MAXU], db[LN_MAXU];
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                 }
                 *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
+                store_planes4(po_dx, (long)row * E + c, o);
                 if (dx_drop) {
                     if (drop_p > 0.f) {
                         o.x = dropout_keep(rng, drop_site, row, c + 0, drop_thr) ? o.x * ik : 0.f;
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                         o.w = dropout_keep(rng, drop_site, row, c + 3, drop_thr) ? o.w * ik : 0.f;
                     }
                     *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
+                    store_planes4(po_drop, (long)row * E + c, o);
                 }
             }
         }
@@ -331,11 +336,11 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_red
 }
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
-                  float* stats, hipStream_t st) {
+                  float* stats, hipStream_t st, PlaneOut po) {
     SLNLP_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
     SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0, "layernorm_fwd: bad shape rows=%d E=%d", rows, E);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, gamma, beta, rows, E, eps, y,
-                       stats);
+                       stats, po);
     SLNLP_CHECK_LAUNCH("layernorm_fwd");
     return 0;
 }
@@ -347,7 +352,8 @@ int ln_bwd_blocks(int rows) {
 
 int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
                   const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
-                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st) {
+                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st,
+                  PlaneOut po_dx, PlaneOut po_drop) {
     SLNLP_CHECK_ARG(dy && x && gamma && stats && dx && partial, "layernorm_bwd: null pointer");
     SLNLP_CHECK_ARG(nblk_force >= 0 && nblk_force <= SLNLP_LN_MAX_PARTIALS, "layernorm_bwd: nblk_force %d", nblk_force);
     SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "layernorm_bwd: need E %% 4 == 0 and E <= %d, got %d", LN_MAXU * 256, E);
@@ -357,7 +363,7 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
     const int nblk = nblk_force ? nblk_force : ln_bwd_blocks(rows);
     if (nblk_out) *nblk_out = nblk;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, x, gamma, stats, rows, E, add_to_dx, dx,
-                       dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial);
+                       dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop);
     SLNLP_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }

@@ -352,6 +352,7 @@ static bool vec_ok(const float* ptr, long ld) {
 }
 
 int gemm(const slnlp_gemm_args& a, hipStream_t s) {
+    if (a.A_hi || a.B_hi) return gemm_planes(a, s);   // pre-split operands: LDS-DMA kernel (gemm_planes.hip)
     SLNLP_CHECK_ARG(a.A && a.B && a.C, "gemm: null operand");
     SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SLNLP_CHECK_ARG(a.precision == 1 || a.precision == 3, "gemm: precision must be 1 or 3, got %d", a.precision);

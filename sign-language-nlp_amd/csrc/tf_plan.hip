@@ -141,13 +141,21 @@ struct Bump {
 // forward activations kept for backward + this layer's gradient buffers.  Every gradient buffer is
 // written exactly once per step, so work forked to a side stream (wgrads) can keep reading it while
 // the main stream moves on -- there is nothing to overwrite until the next step.
+// bf16 hi/lo planes of a GEMM operand (same logical shape / row stride as its fp32 twin, rows
+// zero-padded to a multiple of 64): written once by the producer, read by gemm_planes.hip
+struct PP {
+    unsigned short *hi = nullptr, *lo = nullptr;
+    PlaneOut out() const { PlaneOut o; o.hi = hi; o.lo = lo; return o; }
+};
 struct EncA {
     float *qkv, *probs, *ctx, *y1, *st1, *x1, *h, *y2, *st2, *x2, *lnp1, *lnp2;
     float *gA2, *gB2, *gh, *gx1, *gA1, *gB1, *gctx, *gqkv, *gx0;
+    PP ctxp, x1p, hp, x2p, d2p, ghp, d1p, gqkvp;
 };
 struct DecA {
     float *v, *y1, *st1, *t1, *q, *kv, *xprobs, *xctx, *y2, *st2, *t2, *h, *y3, *st3, *t3, *lnp1, *lnp2, *lnp3;
     float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gkv, *gt1, *gA1, *gB1, *gv, *gt0;
+    PP gkvp;
 };
 struct Ws {
     float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp, *row_nll;
@@ -155,6 +163,8 @@ struct Ws {
     std::vector<DecA> dec;
     float *gfin, *gtl, *gmem, *gxl;     // d tfin, d t_last, d memory, d x_last
     void *emb_scratch_src, *emb_scratch_tgt;
+    PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
+    char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
     float* opt_partials;
     slnlp_ln_reduce_entry* ln_table;
     size_t bytes;
@@ -246,6 +256,24 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
     w.opt_partials = b.take<float>(1024);
     w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
+    // ---- bf16 operand planes (only used when E and F are multiples of 64)
+    const size_t Mp = (M + 63) / 64 * 64;
+    auto pp = [&](size_t cols) { PP q; q.hi = b.take<unsigned short>(Mp * cols); q.lo = b.take<unsigned short>(Mp * cols); return q; };
+    const size_t wtot = (size_t)build_layout(c).total + 64 * 3 * (E > F ? E : F);   // tail pad: tiles may over-read rows
+    w.wp.hi = b.take<unsigned short>(wtot);
+    w.wp.lo = b.take<unsigned short>(wtot);
+    b.cur = (b.cur + 255) & ~(size_t)255;
+    w.planes_begin = b.base + b.cur;
+    w.x0p = pp(E);
+    w.memp = pp(E);
+    for (int i = 0; i < c.N; ++i) {
+        EncA& a = w.enc[i];
+        a.ctxp = pp(E); a.x1p = pp(E); a.hp = pp(F); a.x2p = pp(E);
+        a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
+        w.dec[i].gkvp = pp(2 * E);
+    }
+    b.cur = (b.cur + 255) & ~(size_t)255;
+    w.planes_end = b.base + b.cur;
     w.bytes = (b.cur + 255) & ~(size_t)255;
     return w;
 }
@@ -278,6 +306,8 @@ struct slnlp_tf_plan {
     hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_kv;
     bool side_dirty[NSIDE] = {false, false, false};
+    bool use_planes = false;   // E, F multiples of 64: M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
+    int planes_B = -1;         // batch size the activation planes' zero padding is valid for
 
     float* P(long off) const { return buf.params + off; }
     float* G(long off) const { return buf.grads + off; }
@@ -347,6 +377,54 @@ struct slnlp_tf_plan {
         a.precision = cfg.precision;
         return gemm(a, st);
     }
+    // ---- the same three GEMM roles over pre-split planes; weights: planes of the arena at offset woff
+    int linear_p(const PP& x, int M, int K, long woff, int N, const float* bias, float* y, long ldy, int relu, float p,
+                 int site, const float* resid, const PP* outp, hipStream_t st) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
+        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; a.b_kmajor = 1;
+        a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+        a.bias = bias; a.relu = relu;
+        a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
+        a.resid = resid; a.ldr = ldy;
+        if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
+        a.precision = cfg.precision;
+        return gemm(a, st);
+    }
+    int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
+                float gate_scale, const float* resid, const PP* outp, hipStream_t st) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = ldy; a.a_kmajor = 1;
+        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = Kin; a.b_kmajor = 0;
+        a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
+        a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
+        a.resid = resid; a.ldr = Kin;
+        if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = Kin; }
+        a.precision = cfg.precision;
+        return gemm(a, st);
+    }
+    int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = ldy; a.a_kmajor = 0;
+        a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
+        a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
+        a.rowsum_a = db;
+        a.precision = cfg.precision;
+        return gemm(a, st);
+    }
+    // zero padding of the activation planes is per batch size: re-zero when it changes (outside any capture)
+    int prepare_planes(int B, hipStream_t st) {
+        if (!use_planes || B == planes_B) return 0;
+        if (hipMemsetAsync(w.planes_begin, 0, (size_t)(w.planes_end - w.planes_begin), st) != hipSuccess) {
+            set_error("tf: zeroing operand planes failed");
+            return SLNLP_ERR_LAUNCH;
+        }
+        planes_B = B;
+        return 0;
+    }
     int forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
                      bool defer_join);
 };
@@ -413,7 +491,8 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     p->buf = *buf;
     p->L = build_layout(*cfg);
     p->w = carve(*cfg, buf->workspace);
-    bool ok = attn_init() == 0;
+    bool ok = attn_init() == 0 && gemm_planes_init() == 0;
+    p->use_planes = (cfg->E % 64 == 0) && (cfg->F % 64 == 0);
     for (int k = 0; ok && k < NSIDE; ++k)
         ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
@@ -466,31 +545,53 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     const unsigned long long* rng = pl->buf.rng;
     pl->last_B = B; pl->last_p = p; pl->last_X = X; pl->last_y = y;
 
-    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st));
+    const bool up = use_planes;
+    if (up) {   // weights as bf16 planes, once per forward (they changed in the optimizer step / load_state_dict)
+        SLNLP_TRY(prepare_planes(B, st));
+        SLNLP_TRY(split_planes(pl->buf.params, L.total, 1, (int)L.total, w.wp.hi, w.wp.lo, L.total, st));
+    }
+    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st,
+                        up ? w.x0p.out() : PlaneOut{}));
     SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st));
 
     const float* x = w.x0;
+    const PP* xp = &w.x0p;
     for (int l = 0; l < c.N; ++l) {
         const EncP& q = L.enc[l];
         const EncA& a = w.enc[l];
-        SLNLP_TRY(pl->linear(x, M, E, pl->P(q.in_w), 3 * E, pl->P(q.in_b), a.qkv, 3 * E, 0, 0.f, 0, nullptr, st));
-        SLNLP_TRY(attn_self_fwd(a.qkv, X, S, c.pad_src, 1, B, S, H, dh, a.ctx, a.probs, p, pl->enc_site(l, 0), rng, st));
-        SLNLP_TRY(pl->linear(a.ctx, M, E, pl->P(q.out_w), E, pl->P(q.out_b), a.y1, E, 0, p, pl->enc_site(l, 1), x, st));
-        SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), M, E, 1e-5f, a.x1, a.st1, st));
-        SLNLP_TRY(pl->linear(a.x1, M, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->enc_site(l, 2), nullptr, st));
-        SLNLP_TRY(pl->linear(a.h, M, F, pl->P(q.l2_w), E, pl->P(q.l2_b), a.y2, E, 0, p, pl->enc_site(l, 3), a.x1, st));
-        SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), M, E, 1e-5f, a.x2, a.st2, st));
+        if (up) {
+            SLNLP_TRY(pl->linear_p(*xp, M, E, q.in_w, 3 * E, pl->P(q.in_b), a.qkv, 3 * E, 0, 0.f, 0, nullptr, nullptr, st));
+            SLNLP_TRY(attn_self_fwd(a.qkv, X, S, c.pad_src, 1, B, S, H, dh, a.ctx, a.probs, p, pl->enc_site(l, 0), rng, st, a.ctxp.out()));
+            SLNLP_TRY(pl->linear_p(a.ctxp, M, E, q.out_w, E, pl->P(q.out_b), a.y1, E, 0, p, pl->enc_site(l, 1), x, nullptr, st));
+            SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), M, E, 1e-5f, a.x1, a.st1, st, a.x1p.out()));
+            SLNLP_TRY(pl->linear_p(a.x1p, M, E, q.l1_w, F, pl->P(q.l1_b), a.h, F, 1, p, pl->enc_site(l, 2), nullptr, &a.hp, st));
+            SLNLP_TRY(pl->linear_p(a.hp, M, F, q.l2_w, E, pl->P(q.l2_b), a.y2, E, 0, p, pl->enc_site(l, 3), a.x1, nullptr, st));
+            SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), M, E, 1e-5f, a.x2, a.st2, st, a.x2p.out()));
+        } else {
+            SLNLP_TRY(pl->linear(x, M, E, pl->P(q.in_w), 3 * E, pl->P(q.in_b), a.qkv, 3 * E, 0, 0.f, 0, nullptr, st));
+            SLNLP_TRY(attn_self_fwd(a.qkv, X, S, c.pad_src, 1, B, S, H, dh, a.ctx, a.probs, p, pl->enc_site(l, 0), rng, st));
+            SLNLP_TRY(pl->linear(a.ctx, M, E, pl->P(q.out_w), E, pl->P(q.out_b), a.y1, E, 0, p, pl->enc_site(l, 1), x, st));
+            SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), M, E, 1e-5f, a.x1, a.st1, st));
+            SLNLP_TRY(pl->linear(a.x1, M, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->enc_site(l, 2), nullptr, st));
+            SLNLP_TRY(pl->linear(a.h, M, F, pl->P(q.l2_w), E, pl->P(q.l2_b), a.y2, E, 0, p, pl->enc_site(l, 3), a.x1, st));
+            SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), M, E, 1e-5f, a.x2, a.st2, st));
+        }
         x = a.x2;
+        xp = &a.x2p;
     }
-    SLNLP_TRY(layernorm_fwd(x, pl->P(L.encn_w), pl->P(L.encn_b), M, E, 1e-5f, w.mem, w.st_mem, st));
+    SLNLP_TRY(layernorm_fwd(x, pl->P(L.encn_w), pl->P(L.encn_b), M, E, 1e-5f, w.mem, w.st_mem, st, up ? w.memp.out() : PlaneOut{}));
 
     // memory K|V projections of ALL decoder layers depend only on `mem`: run them on side[0]
     // while the main stream walks the decoder's chain of small (B-row) kernels.
     SLNLP_TRY(fork(st, 0));
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
-        SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0,
-                             0.f, 0, nullptr, side[0]));
+        if (up)
+            SLNLP_TRY(pl->linear_p(w.memp, M, E, q.cin_w + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0, 0.f, 0,
+                                   nullptr, nullptr, side[0]));
+        else
+            SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0,
+                                 0.f, 0, nullptr, side[0]));
         if (hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
             set_error("tf_forward: event record failed");
             return SLNLP_ERR_LAUNCH;
@@ -561,6 +662,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     const float p = pl->last_p, ik = 1.f / (1.f - p);
     const unsigned long long* rng = pl->buf.rng;
     const int64_t *X = pl->last_X, *y = pl->last_y;
+    const bool up = pl->use_planes;
     int nb;
     // Main stream = the dependent chain (LN backward, dgrads, attention backward).
     // side[1]/side[2] = weight gradients (they only feed the optimizer); side[0] = d memory accumulation.
@@ -593,14 +695,21 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         SLNLP_TRY(pl->fork(st, 1));
         SLNLP_TRY(pl->wgrad(d2, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b), s1));
         SLNLP_TRY(pl->dgrad(d2, E, B, E, pl->P(q.cout_w), E, a.gxctx, nullptr, 0.f, nullptr, st));
-        SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, a.gxctx, B, S, H, dh, a.gq, a.gkv, 2 * E, p, pl->dec_site(l, 2), rng, st));
+        SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, a.gxctx, B, S, H, dh, a.gq, a.gkv, 2 * E, p, pl->dec_site(l, 2), rng, st,
+                                 up ? a.gkvp.out() : PlaneOut{}));
         SLNLP_TRY(pl->fork(st, 0));
         SLNLP_TRY(pl->fork(st, 1));
         SLNLP_TRY(pl->fork(st, 2));
         // d memory accumulates over decoder layers in a fixed order on side[0]
-        SLNLP_TRY(pl->dgrad(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
-                            l == c.N - 1 ? nullptr : w.gmem, s0));
-        SLNLP_TRY(pl->wgrad(a.gkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, s1));
+        if (up) {
+            SLNLP_TRY(pl->dgrad_p(a.gkvp, 2 * E, M, 2 * E, q.cin_w + (long)E * E, E, w.gmem, nullptr, 0.f,
+                                  l == c.N - 1 ? nullptr : w.gmem, nullptr, s0));
+            SLNLP_TRY(pl->wgrad_p(a.gkvp, 2 * E, M, 2 * E, w.memp, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, s1));
+        } else {
+            SLNLP_TRY(pl->dgrad(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
+                                l == c.N - 1 ? nullptr : w.gmem, s0));
+            SLNLP_TRY(pl->wgrad(a.gkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, s1));
+        }
         SLNLP_TRY(pl->wgrad(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b), s2));
         SLNLP_TRY(pl->dgrad(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2, st));
         // norm1 / self-attention (single key)
@@ -634,25 +743,48 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         const EncP& q = L.enc[l];
         const EncA& a = w.enc[l];
         const float* x_in = l > 0 ? w.enc[l - 1].x2 : w.x0;
+        const PP& xp_in = l > 0 ? w.enc[l - 1].x2p : w.x0p;
+        const PlaneOut none{};
+        // LayerNorm backward also emits the bf16 planes of the gradient that feeds the sub-layer's GEMMs
+        // (the dropout-masked copy when dropout is on, else dx itself)
         SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
-                                pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st));
+                                pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st, (up && p == 0.f) ? a.d2p.out() : none,
+                                (up && p > 0.f) ? a.d2p.out() : none));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
         SLNLP_TRY(pl->fork(st, 1));
-        SLNLP_TRY(pl->wgrad(d2, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
-        SLNLP_TRY(pl->dgrad(d2, E, M, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
-        SLNLP_TRY(pl->fork(st, 2));
-        SLNLP_TRY(pl->wgrad(a.gh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
-        SLNLP_TRY(pl->dgrad(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2, st));
+        if (up) {
+            SLNLP_TRY(pl->wgrad_p(a.d2p, E, M, E, a.hp, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
+            SLNLP_TRY(pl->dgrad_p(a.d2p, E, M, E, q.l2_w, F, a.gh, a.h, ik, nullptr, &a.ghp, st));
+            SLNLP_TRY(pl->fork(st, 2));
+            SLNLP_TRY(pl->wgrad_p(a.ghp, F, M, F, a.x1p, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
+            SLNLP_TRY(pl->dgrad_p(a.ghp, F, M, F, q.l1_w, E, a.gx1, nullptr, 0.f, a.gA2, nullptr, st));
+        } else {
+            SLNLP_TRY(pl->wgrad(d2, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
+            SLNLP_TRY(pl->dgrad(d2, E, M, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
+            SLNLP_TRY(pl->fork(st, 2));
+            SLNLP_TRY(pl->wgrad(a.gh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
+            SLNLP_TRY(pl->dgrad(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2, st));
+        }
         SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
-                                pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st));
+                                pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st, (up && p == 0.f) ? a.d1p.out() : none,
+                                (up && p > 0.f) ? a.d1p.out() : none));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
         SLNLP_TRY(pl->fork(st, 0));
-        SLNLP_TRY(pl->wgrad(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), s0));
-        SLNLP_TRY(pl->dgrad(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr, st));
-        SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st));
-        SLNLP_TRY(pl->fork(st, 1));
-        SLNLP_TRY(pl->wgrad(a.gqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b), s1));
-        SLNLP_TRY(pl->dgrad(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1, st));
+        if (up) {
+            SLNLP_TRY(pl->wgrad_p(a.d1p, E, M, E, a.ctxp, E, pl->G(q.out_w), pl->G(q.out_b), s0));
+            SLNLP_TRY(pl->dgrad_p(a.d1p, E, M, E, q.out_w, E, a.gctx, nullptr, 0.f, nullptr, nullptr, st));
+            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st, a.gqkvp.out()));
+            SLNLP_TRY(pl->fork(st, 1));
+            SLNLP_TRY(pl->wgrad_p(a.gqkvp, 3 * E, M, 3 * E, xp_in, E, pl->G(q.in_w), pl->G(q.in_b), s1));
+            SLNLP_TRY(pl->dgrad_p(a.gqkvp, 3 * E, M, 3 * E, q.in_w, E, a.gx0, nullptr, 0.f, a.gA1, nullptr, st));
+        } else {
+            SLNLP_TRY(pl->wgrad(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), s0));
+            SLNLP_TRY(pl->dgrad(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr, st));
+            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st));
+            SLNLP_TRY(pl->fork(st, 1));
+            SLNLP_TRY(pl->wgrad(a.gqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b), s1));
+            SLNLP_TRY(pl->dgrad(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1, st));
+        }
         dx = a.gx0;
     }
     SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st));
@@ -682,6 +814,7 @@ int slnlp_tf_graph_capture_train(slnlp_tf_plan* pl, const int64_t* X, const int6
                                  float max_norm, float* logp, void* stream) {
     SLNLP_CHECK_ARG(pl && stream, "tf_graph_capture_train: needs a plan and a non-default stream");
     hipStream_t st = (hipStream_t)stream;
+    SLNLP_TRY(pl->prepare_planes(B, st));   // must not be captured: it runs once per batch-size change
     auto old = pl->graphs.find(B);
     if (old != pl->graphs.end()) {          // re-capture for this batch size: the old exec may still be running
         (void)hipStreamSynchronize(st);
@@ -718,6 +851,7 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* pl, int B, void* stream) {
     SLNLP_CHECK_ARG(pl, "tf_graph_launch: null plan");
     auto it = pl->graphs.find(B);
     SLNLP_CHECK_ARG(it != pl->graphs.end(), "tf_graph_launch: no captured graph for batch %d", B);
+    SLNLP_TRY(pl->prepare_planes(B, (hipStream_t)stream));
     if (hipGraphLaunch(it->second, (hipStream_t)stream) != hipSuccess) {
         set_error("tf_graph_launch: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;

@@ -22,7 +22,9 @@ class GemmArgs(C.Structure):
                 ("gate", vp), ("ldg", i64), ("gate_scale", f32),
                 ("drop_p", f32), ("drop_site", i32), ("rng", vp),
                 ("resid", vp), ("ldr", i64),
-                ("rowsum_a", vp), ("precision", i32), ("gate_mode", i32)]
+                ("rowsum_a", vp), ("precision", i32), ("gate_mode", i32),
+                ("A_hi", vp), ("A_lo", vp), ("lda_p", i64), ("B_hi", vp), ("B_lo", vp), ("ldb_p", i64),
+                ("C_hi", vp), ("C_lo", vp), ("ldc_p", i64)]
 
 
 class TfConfig(C.Structure):
@@ -62,6 +64,7 @@ SIGNATURES = {
     "slnlp_last_error": (C.c_char_p, []),
     "slnlp_abi_version": (i32, []),
     "slnlp_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "slnlp_split_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp]),
     "slnlp_embed_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "slnlp_embed_bwd_scratch_bytes": (i64, [i32, i32, i32]),
     "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i64, f32, i32, vp, vp, vp]),

@@ -36,6 +36,42 @@ def gemm(A, B, *, M, N, K, a_kmajor=True, b_kmajor=True, lda=None, ldb=None, out
     return out
 
 
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def split_planes(x, want_lo=True):
+    """fp32 [R,C] -> (hi, lo) bf16 planes (int16 storage) zero-padded to multiples of 64."""
+    _lib.require_gpu()
+    R, Cc = x.shape
+    hi = torch.zeros(pad64(R), pad64(Cc), dtype=torch.int16, device=x.device)
+    lo = torch.zeros_like(hi) if want_lo else None
+    check(load().slnlp_split_planes(ptr(x), x.stride(0), R, Cc, ptr(hi), ptr(lo), hi.stride(0), stream_ptr()), "split_planes")
+    return hi, lo
+
+
+def gemm_planes(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, precision=3, rowsum_a=None, bias=None,
+                relu=False, resid=None, want_planes=False):
+    """C = A B^T over pre-split operands Ap = (hi, lo), Bp = (hi, lo) (see split_planes)."""
+    _lib.require_gpu()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=Ap[0].device)
+    a = GemmArgs()
+    a.C, a.ldc, a.M, a.N, a.K = ptr(out), out.stride(0), M, N, K
+    a.a_kmajor, a.b_kmajor, a.precision = int(a_kmajor), int(b_kmajor), precision
+    a.A_hi, a.A_lo, a.lda_p = ptr(Ap[0]), ptr(Ap[1]), Ap[0].stride(0)
+    a.B_hi, a.B_lo, a.ldb_p = ptr(Bp[0]), ptr(Bp[1]), Bp[0].stride(0)
+    a.bias, a.relu, a.rowsum_a = ptr(bias), int(relu), ptr(rowsum_a)
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    cp = None
+    if want_planes:
+        cp = (torch.zeros(pad64(M), pad64(N), dtype=torch.int16, device=out.device),
+              torch.zeros(pad64(M), pad64(N), dtype=torch.int16, device=out.device))
+        a.C_hi, a.C_lo, a.ldc_p = ptr(cp[0]), ptr(cp[1]), cp[0].stride(0)
+    check(load().slnlp_gemm(C.byref(a), stream_ptr()), "gemm_planes")
+    return (out, cp) if want_planes else out
+
+
 def embed_fwd(ids, table, pe, *, B, S, scale=None, drop_p=0.0, drop_site=0, rng=None, nan_idx=-1):
     _lib.require_gpu()
     V, E = table.shape

@@ -261,3 +261,42 @@ def test_clip_sgd(ops):
         assert abs(float(norm) - float(total)) < 1e-5 * float(total)
         assert rel(P, params["w"]) < 1e-6 and rel(Bf, bufs["w"]) < 1e-6
         assert int(rng[1]) == 42                            # dropout step counter advanced
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+@pytest.mark.parametrize("M,N,K", [(2400, 512, 512), (50, 202, 512), (50, 512, 202), (64, 64, 64), (130, 70, 100),
+                                   (512, 512, 2400), (202, 512, 50)])
+def test_gemm_planes_layouts(ops, layout, M, N, K, prec):
+    """LDS-DMA GEMM over pre-split, zero-padded bf16 planes (gemm_planes.hip) vs fp64."""
+    Al, Bl = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = Al.double() @ Bl.double().T
+    a_k = layout in ("fwd", "dgrad")
+    b_k = layout == "fwd"
+    Ap = ops.split_planes((Al if a_k else Al.T.contiguous()).cuda() if (K % 4 == 0 or not a_k) and (M % 4 == 0 or a_k) else None) \
+        if False else None
+    # split_planes needs column counts that are multiples of 4: pad the fp32 source like a producer would
+    def planes(x):
+        R, Cc = x.shape
+        xp = torch.zeros(R, (Cc + 3) // 4 * 4)
+        xp[:, :Cc] = x
+        return ops.split_planes(xp.cuda())
+    Ap = planes(Al if a_k else Al.T.contiguous())
+    Bp = planes(Bl if b_k else Bl.T.contiguous())
+    rs = torch.empty(M, device="cuda") if layout == "wgrad" else None
+    out = ops.gemm_planes(Ap, Bp, M=M, N=N, K=K, a_kmajor=a_k, b_kmajor=b_k, precision=prec, rowsum_a=rs)
+    assert rel(out, ref) < TOL[prec] * max(1.0, math.sqrt(K / 64))
+    if rs is not None:
+        assert rel(rs, Al.double().sum(1)) < (1e-4 if prec == 3 else 2e-2)
+
+
+def test_gemm_planes_epilogue_and_output_planes(ops):
+    M, N, K = 300, 200, 128
+    A, B, bias, R = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = torch.relu(A.double() @ B.double().T + bias.double()) + R.double()
+    out, (hi, lo) = ops.gemm_planes(ops.split_planes(A.cuda()), ops.split_planes(B.cuda()), M=M, N=N, K=K,
+                                    bias=bias.cuda(), relu=True, resid=R.cuda(), want_planes=True)
+    assert rel(out, ref) < 1e-4
+    back = (hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float())[:M, :N]
+    assert rel(back, ref) < 1e-4                                          # emitted planes reconstruct the result
+    assert float(hi[M:].abs().max()) == 0 and float(hi[:, N:].abs().max()) == 0   # padding untouched

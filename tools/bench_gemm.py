@@ -16,13 +16,18 @@ SHAPES = [  # (label, layout, M, N, K)
 
 def main():
     prec = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    planes = len(sys.argv) > 2 and sys.argv[2] == "planes"
     for label, layout, M, N, K in SHAPES:
         a_k = layout in ("fwd", "dgrad"); b_k = layout == "fwd"
         A = torch.randn((M, K) if a_k else (K, M), device="cuda")
         B = torch.randn((N, K) if b_k else (K, N), device="cuda")
         out = torch.empty(M, N, device="cuda")
         rs = torch.empty(M, device="cuda") if layout == "wgrad" else None
-        f = lambda: ops.gemm(A, B, M=M, N=N, K=K, a_kmajor=a_k, b_kmajor=b_k, out=out, rowsum_a=rs, precision=prec)
+        if planes:
+            Ap, Bp = ops.split_planes(A), ops.split_planes(B)
+            f = lambda: ops.gemm_planes(Ap, Bp, M=M, N=N, K=K, a_kmajor=a_k, b_kmajor=b_k, out=out, rowsum_a=rs, precision=prec)
+        else:
+            f = lambda: ops.gemm(A, B, M=M, N=N, K=K, a_kmajor=a_k, b_kmajor=b_k, out=out, rowsum_a=rs, precision=prec)
         for _ in range(10): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
