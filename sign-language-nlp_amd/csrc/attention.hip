@@ -240,6 +240,330 @@ __global__ __launch_bounds__(256) void attn_self_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------- MFMA self-attention ---
+// head_dim <= 64 (every Transformer config of the reference grid except E512/H4 and E1024): the four
+// 64x64x64 contractions of one (batch, head) run on v_mfma_f32_16x16x32_bf16 in split-bf16 (hi/lo, 3 passes,
+// same arithmetic as the GEMMs).  All operand tiles live in LDS as bf16 [row][col] images with a 72-element row
+// stride; an operand whose contraction index runs along the rows is read with ds_read_b64_tr_b16, so one image
+// serves both orientations and nothing is transposed in HBM.  Softmax / softmax-backward / dropout happen in
+// the MFMA accumulator layout (lane -> 4 consecutive rows x 1 column; a row's 64 columns sit in 16 lanes).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int ALD = 72;            // bf16 row stride: 144 B -> the 16 rows of a b128 fragment read hit 16 distinct 16-B slots
+constexpr int ATILE = SMAX * ALD;  // one plane of one tile
+constexpr int MFMA_DH = 64;        // largest head dim of the MFMA path
+
+// issue the loads of a [S x dh] slice (token-major rows m = s*B + b); no use of the values here (see gemm.hip)
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ src, long ld, int B, int b, int S, int col0,
+                                           int dc, int tid, float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u, s = idx >> 4, c = (idx & 15) << 2;
+        const bool ok = s < S && c < dc;
+        r[u] = *reinterpret_cast<const float4*>(src + ((long)(ok ? s : 0) * B + b) * ld + col0 + (ok ? c : 0));
+    }
+}
+// fp32 -> bf16 hi / lo planes (T, T + ATILE); rows >= S and cols >= dc are zero
+__device__ __forceinline__ void stash_tile(unsigned short* __restrict__ T, int S, int dc, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u, s = idx >> 4, c = (idx & 15) << 2;
+        const bool ok = s < S && c < dc;
+        const float x[4] = {ok ? r[u].x : 0.f, ok ? r[u].y : 0.f, ok ? r[u].z : 0.f, ok ? r[u].w : 0.f};
+        unsigned short hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_bf16(x[e], hh[e], ll[e]);
+        uint2 w;
+        w.x = hh[0] | ((unsigned)hh[1] << 16); w.y = hh[2] | ((unsigned)hh[3] << 16);
+        *reinterpret_cast<uint2*>(T + s * ALD + c) = w;
+        w.x = ll[0] | ((unsigned)ll[1] << 16); w.y = ll[2] | ((unsigned)ll[3] << 16);
+        *reinterpret_cast<uint2*>(T + ATILE + s * ALD + c) = w;
+    }
+}
+// fragment whose contraction index k runs along the image columns: lane l <- (row r0 + (l&15), k = 32kk + 8(l>>4) + j)
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned short* __restrict__ T, int r0, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8*>(T + (r0 + (lane & 15)) * ALD + kk * 32 + ((lane >> 4) << 3));
+}
+// fragment whose contraction index runs along the image rows: lane l <- (k = 32kk + 8(l>>4) + j, col c0 + (l&15))
+__device__ __forceinline__ bf16x8 frag_cols(const unsigned short* __restrict__ T, int c0, int kk, int lane) {
+    const int i = lane & 15, kb = kk * 32 + ((lane >> 4) << 3) + (i >> 2);
+    const unsigned short* p0 = T + kb * ALD + c0 + ((i & 3) << 2);
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + 4 * ALD));
+    const s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+// reductions over the 16 lanes that hold one accumulator row
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// keep flags of rows row0..row0+3 at column col of a dropout site (one Philox call when row0 % 4 == 0)
+__device__ __forceinline__ unsigned keep_mask4(const unsigned long long* rng, int site, unsigned row0, unsigned col,
+                                               unsigned thr) {
+    unsigned m = 0;
+    if ((row0 & 3u) == 0u) {
+        const uint4 bits = dropout_bits4(rng, site, row0 >> 2, col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m |= (pick_word(bits, r) >= thr ? 1u : 0u) << r;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m |= (dropout_keep(rng, site, row0 + r, col, thr) ? 1u : 0u) << r;
+    }
+    return m;
+}
+__device__ __forceinline__ void put_planes(unsigned short* __restrict__ T, int off, float v) {
+    unsigned short h, l;
+    split_bf16(v, h, l);
+    T[off] = h;
+    T[ATILE + off] = l;
+}
+
+__global__ __launch_bounds__(256) void attn_self_fwd_mfma_kernel(
+    const float* __restrict__ qkv, const long* __restrict__ ids, long ld_ids, long pad_idx, int causal, int B,
+    int S, int H, int dh, float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr,
+    int drop_site, const unsigned long long* __restrict__ rng, PlaneOut po) {
+    __shared__ __attribute__((aligned(16))) unsigned short sm[6 * ATILE];   // Q (then P) | K | V, hi+lo each: 55 296 B
+    unsigned short* TQ = sm;
+    unsigned short* TK = sm + 2 * ATILE;
+    unsigned short* TV = sm + 4 * ATILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * dh;
+    const long ld = 3L * E;
+    const int jc = lane & 15, i0 = wave * 16 + ((lane >> 4) << 2);
+
+    long idv[4] = {0, 0, 0, 0};
+    if (ids) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { const int j = 16 * n + jc; idv[n] = ids[(long)b * ld_ids + (j < S ? j : 0)]; }
+    }
+    float4 rq[4], rk[4], rv[4];
+    fetch_tile(qkv, ld, B, b, S, h * dh, dh, tid, rq);
+    fetch_tile(qkv, ld, B, b, S, E + h * dh, dh, tid, rk);
+    fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh, dh, tid, rv);
+    stash_tile(TQ, S, dh, tid, rq);
+    stash_tile(TK, S, dh, tid, rk);
+    stash_tile(TV, S, dh, tid, rv);
+    __syncthreads();
+
+    // scores: rows 16w..16w+15 of Q K^T
+    f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (dh + 31) >> 5;
+    for (int kk = 0; kk < nk; ++kk) {
+        const bf16x8 ah = frag_rows(TQ, wave * 16, kk, lane), al = frag_rows(TQ + ATILE, wave * 16, kk, lane);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            acc[n] = mfma3(ah, al, frag_rows(TK, 16 * n, kk, lane), frag_rows(TK + ATILE, 16 * n, kk, lane), acc[n]);
+    }
+    // softmax + dropout in the accumulator layout; P (dropped) replaces this wave's own Q rows
+    const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
+    const long prow0 = ((long)b * H + h) * S + i0;
+    unsigned keep[4] = {15u, 15u, 15u, 15u};
+    bool kblock[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int j = 16 * n + jc;
+        kblock[n] = j >= S || (ids && idv[n] == pad_idx);
+        if (drop_p > 0.f && j < S && i0 < S) keep[n] = keep_mask4(rng, drop_site, (unsigned)prow0, (unsigned)j, drop_thr);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + r;
+        float v[4], m = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const bool blocked = kblock[n] || (causal && 16 * n + jc > i);
+            v[n] = blocked ? -INFINITY : acc[n][r] * scale;
+            m = fmaxf(m, v[n]);
+        }
+        m = row16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { v[n] = expf(v[n] - m); sum += v[n]; }   // all-masked row: NaN, as torch
+        sum = row16_sum(sum);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int j = 16 * n + jc;
+            float p = v[n] / sum;
+            if (i < S && j < S) probs[(prow0 + r) * S + j] = p;
+            else p = 0.f;
+            if (drop_p > 0.f) p = ((keep[n] >> r) & 1u) ? p * inv_keep : 0.f;
+            put_planes(TQ, i * ALD + j, p);
+        }
+    }
+    __syncthreads();
+    // ctx = P V
+    const int nd = (dh + 15) >> 4, nkk = (S + 31) >> 5;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < nkk; ++kk) {
+        const bf16x8 ah = frag_rows(TQ, wave * 16, kk, lane), al = frag_rows(TQ + ATILE, wave * 16, kk, lane);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TV, 16 * n, kk, lane), frag_cols(TV + ATILE, 16 * n, kk, lane), acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int d = 16 * n + jc;
+        if (d >= dh) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r;
+            if (i >= S) continue;
+            const long at = ((long)i * B + b) * E + h * dh + d;
+            ctx[at] = acc[n][r];
+            store_planes1(po, at, acc[n][r]);
+        }
+    }
+}
+
+// Backward.  Tiles: TQ | TK | TO (dO, later dS) | TV (V, later dropped P), hi+lo each = 73 728 B dynamic LDS.
+__global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dctx, int B, int S,
+    int H, int dh, float* __restrict__ dqkv, float drop_p, unsigned drop_thr, int drop_site,
+    const unsigned long long* __restrict__ rng, PlaneOut po) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* TQ = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* TK = TQ + 2 * ATILE;
+    unsigned short* TO = TQ + 4 * ATILE;
+    unsigned short* TV = TQ + 6 * ATILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * dh;
+    const long ld = 3L * E;
+    const int jc = lane & 15, i0 = wave * 16 + ((lane >> 4) << 2);
+    const long prow0 = ((long)b * H + h) * S + i0;
+
+    float4 ro[4], rv[4], rq[4], rk[4];
+    fetch_tile(dctx, E, B, b, S, h * dh, dh, tid, ro);
+    fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh, dh, tid, rv);
+    fetch_tile(qkv, ld, B, b, S, h * dh, dh, tid, rq);
+    fetch_tile(qkv, ld, B, b, S, E + h * dh, dh, tid, rk);
+    float pr[4][4];   // [n][r]: probs of (row i0 + r, key 16n + jc); clamped address, masked after the loads
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * n + jc;
+            const bool ok = (i0 + r) < S && j < S;
+            pr[n][r] = probs[ok ? (prow0 + r) * S + j : 0];
+        }
+    stash_tile(TO, S, dh, tid, ro);
+    stash_tile(TV, S, dh, tid, rv);
+    __syncthreads();
+    // dP = dO V^T  (rows 16w..)
+    f32x4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (dh + 31) >> 5;
+    for (int kk = 0; kk < nk; ++kk) {
+        const bf16x8 ah = frag_rows(TO, wave * 16, kk, lane), al = frag_rows(TO + ATILE, wave * 16, kk, lane);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            acc[n] = mfma3(ah, al, frag_rows(TV, 16 * n, kk, lane), frag_rows(TV + ATILE, 16 * n, kk, lane), acc[n]);
+    }
+    stash_tile(TQ, S, dh, tid, rq);
+    stash_tile(TK, S, dh, tid, rk);
+    // softmax backward in registers: ds = p (dp - sum_j dp p) scale;  pd = dropped p
+    const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
+    float ds[4][4], pd[4][4];
+    {
+        unsigned keep[4] = {15u, 15u, 15u, 15u};
+        if (drop_p > 0.f) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (16 * n + jc < S && i0 < S) keep[n] = keep_mask4(rng, drop_site, (unsigned)prow0, (unsigned)(16 * n + jc), drop_thr);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float dp[4], s = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const bool ok = (i0 + r) < S && (16 * n + jc) < S;
+                const float p = ok ? pr[n][r] : 0.f;
+                const bool k = (keep[n] >> r) & 1u;
+                pr[n][r] = p;
+                dp[n] = drop_p > 0.f ? (k ? acc[n][r] * inv_keep : 0.f) : acc[n][r];
+                pd[n][r] = drop_p > 0.f ? (k ? p * inv_keep : 0.f) : p;
+                s += dp[n] * p;
+            }
+            s = row16_sum(s);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) ds[n][r] = pr[n][r] * (dp[n] - s) * scale;
+        }
+    }
+    __syncthreads();   // every wave is done with V; Q / K tiles are complete
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put_planes(TV, (i0 + r) * ALD + 16 * n + jc, pd[n][r]);
+    __syncthreads();
+    const int nd = (dh + 15) >> 4, nkk = (S + 31) >> 5;
+    auto store = [&](const f32x4 (&o)[4], int part) {   // rows 16w.. of dQ (0) / dK (1) / dV (2)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int d = 16 * n + jc;
+            if (d >= dh) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r;
+                if (i >= S) continue;
+                const long at = ((long)i * B + b) * ld + (long)part * E + h * dh + d;
+                dqkv[at] = o[n][r];
+                store_planes1(po, at, o[n][r]);
+            }
+        }
+    };
+    // dV = Pd^T dO   (rows = keys 16w..; contraction over s)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < nkk; ++kk) {
+        const bf16x8 ah = frag_cols(TV, wave * 16, kk, lane), al = frag_cols(TV + ATILE, wave * 16, kk, lane);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TO, 16 * n, kk, lane), frag_cols(TO + ATILE, 16 * n, kk, lane), acc[n]);
+    }
+    store(acc, 2);
+    __syncthreads();   // every wave is done with dO
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put_planes(TO, (i0 + r) * ALD + 16 * n + jc, ds[n][r]);
+    __syncthreads();
+    // dQ = dS K  (rows 16w.., contraction over keys);  dK = dS^T Q  (rows = keys 16w.., contraction over s)
+    f32x4 acq[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acq[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int kk = 0; kk < nkk; ++kk) {
+        const bf16x8 qh = frag_rows(TO, wave * 16, kk, lane), ql = frag_rows(TO + ATILE, wave * 16, kk, lane);
+        const bf16x8 kh = frag_cols(TO, wave * 16, kk, lane), kl = frag_cols(TO + ATILE, wave * 16, kk, lane);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < nd) {
+                acq[n] = mfma3(qh, ql, frag_cols(TK, 16 * n, kk, lane), frag_cols(TK + ATILE, 16 * n, kk, lane), acq[n]);
+                acc[n] = mfma3(kh, kl, frag_cols(TQ, 16 * n, kk, lane), frag_cols(TQ + ATILE, 16 * n, kk, lane), acc[n]);
+            }
+    }
+    store(acq, 0);
+    store(acc, 1);
+}
+
 // ------------------------------------------------------------------ cross ---
 constexpr int XDH = 256;  // max head dim
 
@@ -364,6 +688,7 @@ int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site,
 }
 
 constexpr size_t ATTN_BWD_LDS = 5 * SMAX * TLD * sizeof(float);  // 87 040 B of dynamic LDS (> 64 KiB default cap)
+constexpr size_t ATTN_BWD_MFMA_LDS = 8 * ATILE * sizeof(unsigned short);  // 73 728 B
 
 // one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
 int attn_init() {
@@ -371,6 +696,11 @@ int attn_init() {
     if (state == 1) return 0;
     if (hipFuncSetAttribute((const void*)attn_self_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)ATTN_BWD_LDS) != hipSuccess) {
+        set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    if (hipFuncSetAttribute((const void*)attn_self_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ATTN_BWD_MFMA_LDS) != hipSuccess) {
         set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
@@ -393,9 +723,14 @@ int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t 
     SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
-    hipLaunchKernelGGL(attn_self_fwd_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
-                       (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site,
-                       rng, po);
+    if (dh <= MFMA_DH)
+        hipLaunchKernelGGL(attn_self_fwd_mfma_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids,
+                           (long)ld_ids, (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p,
+                           dropout_threshold(drop_p), drop_site, rng, po);
+    else
+        hipLaunchKernelGGL(attn_self_fwd_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
+                           (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p),
+                           drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_self_fwd");
     return 0;
 }
@@ -407,8 +742,12 @@ int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
     const size_t lds = ATTN_BWD_LDS;
     SLNLP_TRY(attn_init());
-    hipLaunchKernelGGL(attn_self_bwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, probs, dctx, B, S, H, dh, dqkv,
-                       drop_p, dropout_threshold(drop_p), drop_site, rng, po);
+    if (dh <= MFMA_DH)
+        hipLaunchKernelGGL(attn_self_bwd_mfma_kernel, dim3(B * H), dim3(256), ATTN_BWD_MFMA_LDS, st, qkv, probs, dctx,
+                           B, S, H, dh, dqkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
+    else
+        hipLaunchKernelGGL(attn_self_bwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, probs, dctx, B, S, H, dh, dqkv,
+                           drop_p, dropout_threshold(drop_p), drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_self_bwd");
     return 0;
 }
