@@ -78,6 +78,16 @@ typedef struct slnlp_gemm_args {
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
+/* Grouped launch: up to 4 independent pre-split (plane) GEMMs in ONE kernel launch -- e.g. the data gradient
+ * and the weight gradient of one dY, which replace autograd's separate mm calls for nn.Linear
+ * (transformer.py:40-48 -> torch).  split_k[i] > 1 (or NULL = all 1) divides job i's K loop over that many
+ * workgroups per output tile; the partial tiles meet in `scratch` and are added in split order by the last
+ * workgroup to arrive, so the result is deterministic (no float atomics).  scratch: at least
+ * slnlp_gemm_group_scratch_bytes(...) bytes, 16-byte aligned, its first 16 KiB zero before the first use (the
+ * library leaves them zero); one scratch buffer must not serve two launches that may run concurrently. */
+int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs);
+int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
+                     int64_t scratch_bytes, void* stream);
 /* fp32 [R,C] (row stride ld) -> bf16 hi/lo planes with row stride ldp (lo may be NULL); writes the valid
  * region only -- the planes' zero padding comes from their allocation. */
 int slnlp_split_planes(const float* x, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream);

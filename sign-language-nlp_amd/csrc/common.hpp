@@ -139,6 +139,10 @@ namespace slnlp {
 int gemm(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_planes(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_planes_init();
+// up to 4 independent plane GEMMs in ONE launch, optional deterministic split-K per job (gemm_planes.hip)
+int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs, void* scratch, size_t scratch_bytes,
+                      hipStream_t s);
+size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs);
 int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, unsigned short* lo, int64_t ldp, hipStream_t st);
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,

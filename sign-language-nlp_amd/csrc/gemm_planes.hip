@@ -31,10 +31,24 @@ constexpr int IMG = PT * PT;           // bf16 elements per plane image (8 KiB)
 constexpr int PTHREADS = 512;
 constexpr int NSTAGE = 2;              // LDS ring depth (NSTAGE-1 tiles in flight)
 
-struct PlaneGemmParams {
+// One GEMM of a grouped launch.  A launch runs up to MAX_JOBS independent GEMMs (e.g. the data-gradient and
+// the weight-gradient of one dY): blocks [block_begin, block_begin + tiles_x * tiles_y * nks) belong to the job.
+// nks > 1 splits the K loop over nks blocks per output tile; partial tiles go to scratch in the accumulator
+// layout and the LAST block to arrive (per-tile counter) adds them in split order -- deterministic, no float atomics.
+struct PlaneJob {
     slnlp_gemm_args a;
     unsigned drop_thr;
     float drop_scale;
+    int variant;        // 0: A,B k-major   1: A k-major, B m-major   2: A,B m-major
+    int tiles_x, tiles_y, nks, block_begin;
+    float* part;        // [tile][nks][PTHREADS * 8]
+    float* part_rs;     // [tile_y][nks][PT]     (row sums of A)
+    int* counters;      // [tiles], zero outside a launch
+};
+constexpr int MAX_JOBS = 4;
+struct PlaneGroupParams {
+    PlaneJob job[MAX_JOBS];
+    int njobs;
 };
 
 __device__ __forceinline__ int mswz(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
@@ -74,28 +88,42 @@ __device__ __forceinline__ bf16x8 pfrag(const unsigned short* __restrict__ img, 
 
 __device__ __forceinline__ float pbf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// 8-byte agent-scope (sc1) store / load: write-through to / fetched from the memory side, never a stale XCD-L2 line
+__device__ __forceinline__ void st_agent2(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_agent2(const float* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
+// One block's work: output tile (bx, by) of the job, K-tiles [kt0, kt1).
 template <int NSPLIT, bool AK, bool BK>
-__global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGemmParams p) {
+__device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
     constexpr int NP = NSPLIT == 3 ? 2 : 1;
     constexpr int STAGE = 2 * NP * IMG;     // A planes then B planes
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // NSTAGE stages (+ row-sum scratch after the loop)
-    const slnlp_gemm_args& g = p.a;
+    const slnlp_gemm_args& g = job.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * 16, wn0 = (wave & 1) * 32;
-    int bx, by;
-    {   // XCD-aware tile order (see gemm.hip)
-        const int nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
-        const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        by = t / gridDim.x;
-        bx = t - by * gridDim.x;
+    const int nks = job.nks;
+    int bx, by, ks, tile;
+    {   // XCD-aware order (see gemm.hip): each XCD owns a contiguous run of (tile, split) units
+        const int nwg = job.tiles_x * job.tiles_y * nks;
+        const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+        tile = t / nks;
+        ks = t - tile * nks;
+        by = tile / job.tiles_x;
+        bx = tile - by * job.tiles_x;
     }
     const int bm0 = by * PT, bn0 = bx * PT;
     const int M = g.M, N = g.N, K = g.K;
     const int ktiles = (K + PT - 1) / PT;
+    const int kt0 = (int)((long)ktiles * ks / nks), kt1 = (int)((long)ktiles * (ks + 1) / nks);
 
     auto issue = [&](int kt, int stage) {
-        const int k0 = (kt < ktiles ? kt : 0) * PT;       // past-the-end prefetch re-reads tile 0 (never consumed)
+        const int k0 = (kt < kt1 ? kt : kt0) * PT;        // past-the-end prefetch re-reads a valid tile (never consumed)
         unsigned short* s = smem + stage * STAGE;
         dma_plane<AK>(g.A_hi, g.lda_p, bm0, k0, s, wave, lane);
         if (NSPLIT == 3) dma_plane<AK>(g.A_lo, g.lda_p, bm0, k0, s + IMG, wave, lane);
@@ -110,14 +138,15 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGemmPa
     // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-1 are in flight while tile kt is consumed (a K-step's
     // MFMA work is ~0.2 us, one DMA round trip ~1 us).  ONE barrier per step: the stage refilled at step kt
     // was consumed at step kt-1, which every wave has finished once it passes this step's barrier.
-    for (int t = 0; t < NSTAGE - 1; ++t) issue(t, t);
-    for (int kt = 0; kt < ktiles; ++kt) {
+    for (int t = 0; t < NSTAGE - 1; ++t) issue(kt0 + t, t);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int it = kt - kt0;
         // this wave's DMA of tile kt has landed once only the (NSTAGE-2) newer tiles' pieces are outstanding
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NSTAGE - 2) * 2 * NP) : "memory");
         __builtin_amdgcn_s_barrier();                      // ... and so has every other wave's part
         asm volatile("" ::: "memory");
-        issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
-        const unsigned short* s = smem + (kt % NSTAGE) * STAGE;
+        issue(kt + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
+        const unsigned short* s = smem + (it % NSTAGE) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 ah, al, bh[2], bl[2];
@@ -151,17 +180,49 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGemmPa
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the dummy prefetches before LDS is reused / freed
     __builtin_amdgcn_s_barrier();
+    float* rs = reinterpret_cast<float*>(smem);
+    int* flag = reinterpret_cast<int*>(smem) + PTHREADS;
+    float rs_row = 0.f;                                      // tid < PT: this block's row sum of A row bm0 + tid
     if (do_rowsum) {
-        float* rs = reinterpret_cast<float*>(smem);
         rs[(tid >> 6) * PT + (tid & 63)] = rowsum;
         __syncthreads();
-        if (tid < PT && bm0 + tid < M) {
-            float t = 0.f;
+        if (tid < PT) {
 #pragma unroll
-            for (int w = 0; w < PTHREADS / 64; ++w) t += rs[w * PT + tid];
-            g.rowsum_a[bm0 + tid] = t;
+            for (int w = 0; w < PTHREADS / 64; ++w) rs_row += rs[w * PT + tid];
         }
     }
+    if (nks > 1) {
+        // Split-K meeting point.  The L2s of the 8 XCDs are not coherent with each other and an agent-scope fence
+        // costs a whole-L2 write-back per wave (measured: 8x slower kernel), so the partial tiles never live in
+        // L2: they are written and read with agent-scope (sc1, write-through / bypass) accesses, and the only
+        // ordering needed is "my stores have completed (vmcnt 0, block barrier) before my arrival is counted".
+        float* mine = job.part + ((long)tile * nks + ks) * (PTHREADS * 8) + tid * 8;
+        st_agent2(mine, acc[0][0], acc[0][1]);
+        st_agent2(mine + 2, acc[0][2], acc[0][3]);
+        st_agent2(mine + 4, acc[1][0], acc[1][1]);
+        st_agent2(mine + 6, acc[1][2], acc[1][3]);
+        if (do_rowsum && tid < PT)
+            __hip_atomic_store(job.part_rs + ((long)by * nks + ks) * PT + tid, rs_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            *flag = __hip_atomic_fetch_add(job.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nks - 1;
+        __syncthreads();
+        if (!*flag) return;
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rs_row = 0.f;
+        for (int s = 0; s < nks; ++s) {                      // fixed order: the result does not depend on arrival order
+            const float* q = job.part + ((long)tile * nks + s) * (PTHREADS * 8) + tid * 8;
+            const float2 p0 = ld_agent2(q), p1 = ld_agent2(q + 2), p2 = ld_agent2(q + 4), p3 = ld_agent2(q + 6);
+            acc[0] += f32x4{p0.x, p0.y, p1.x, p1.y};
+            acc[1] += f32x4{p2.x, p2.y, p3.x, p3.y};
+            if (do_rowsum && tid < PT)
+                rs_row += __hip_atomic_load(job.part_rs + ((long)by * nks + s) * PT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(job.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    if (do_rowsum && tid < PT && bm0 + tid < M) g.rowsum_a[bm0 + tid] = rs_row;
 
     // ---- epilogue: +bias -> activation -> gate -> dropout -> +resid ; fp32 store (+ optional bf16 planes)
     const int crow = (lane >> 4) << 2, ccol = lane & 15;
@@ -184,7 +245,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGemmPa
                 const float gt = g.gate[(long)gm * g.ldg + gn];
                 v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
             }
-            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= p.drop_thr) ? v * p.drop_scale : 0.f;
+            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
             if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
             if (g.C) g.C[(long)gm * g.ldc + gn] = v;
             if (g.C_hi) {
@@ -199,42 +260,38 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGemmPa
     }
 }
 
-constexpr size_t PLANE_LDS = (size_t)NSTAGE * 2 * 2 * IMG * sizeof(unsigned short);   // NSTAGE x (A,B) x (hi,lo) x 8 KiB = 128 KiB
-
-template <int NSPLIT, bool AK, bool BK>
-static int launch_planes(const PlaneGemmParams& p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm_planes_kernel<NSPLIT, AK, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)PLANE_LDS) != hipSuccess) {
-            set_error("gemm_planes: cannot raise dynamic LDS limit");
-            return SLNLP_ERR_LAUNCH;
-        }
-        attr = true;
-    }
-    dim3 grid(ceil_div(p.a.N, PT), ceil_div(p.a.M, PT));
-    hipLaunchKernelGGL((gemm_planes_kernel<NSPLIT, AK, BK>), grid, dim3(PTHREADS), PLANE_LDS, s, p);
-    return 0;
+template <int NSPLIT>
+__global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // NSTAGE stages (+ scratch after the loop)
+    int j = 0;
+    for (int t = 1; t < P.njobs; ++t)
+        if ((int)blockIdx.x >= P.job[t].block_begin) j = t;                 // block-uniform
+    const PlaneJob& job = P.job[j];
+    const int lid = blockIdx.x - job.block_begin;
+    if (job.variant == 0) plane_tile<NSPLIT, true, true>(job, lid, smem);
+    else if (job.variant == 1) plane_tile<NSPLIT, true, false>(job, lid, smem);
+    else plane_tile<NSPLIT, false, false>(job, lid, smem);
 }
 
-template <int NSPLIT, bool AK, bool BK>
-static bool set_lds_attr() {
-    return hipFuncSetAttribute((const void*)gemm_planes_kernel<NSPLIT, AK, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)PLANE_LDS) == hipSuccess;
-}
+constexpr size_t PLANE_LDS = (size_t)NSTAGE * 2 * 2 * IMG * sizeof(unsigned short);   // NSTAGE x (A,B) x (hi,lo) x 8 KiB = 64 KiB
+constexpr int GROUP_COUNTERS = 4096;                       // ints at the head of the scratch buffer
 
-// set every instantiation's LDS attribute up front (plan creation) so none lands inside a graph capture
+// set the kernels' LDS attribute up front (plan creation) so it never lands inside a graph capture
 int gemm_planes_init() {
-    const bool ok = set_lds_attr<3, true, true>() && set_lds_attr<3, true, false>() && set_lds_attr<3, false, false>() &&
-                    set_lds_attr<1, true, true>() && set_lds_attr<1, true, false>() && set_lds_attr<1, false, false>();
+    static bool done = false;
+    if (done) return 0;
+    const bool ok =
+        hipFuncSetAttribute((const void*)gemm_planes_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLANE_LDS) == hipSuccess &&
+        hipFuncSetAttribute((const void*)gemm_planes_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLANE_LDS) == hipSuccess;
     if (!ok) {
         set_error("gemm_planes_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
+    done = true;
     return 0;
 }
 
-int gemm_planes(const slnlp_gemm_args& a, hipStream_t s) {
+static int check_plane_job(const slnlp_gemm_args& a) {
     SLNLP_CHECK_ARG(a.A_hi && a.B_hi, "gemm_planes: operand planes required");
     SLNLP_CHECK_ARG(a.C || a.C_hi, "gemm_planes: no output");
     SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_planes: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -246,18 +303,69 @@ int gemm_planes(const slnlp_gemm_args& a, hipStream_t s) {
     SLNLP_CHECK_ARG(!a.C_hi || a.ldc_p >= a.N, "gemm_planes: ldc_p < N");
     SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "gemm_planes: bad dropout args");
     SLNLP_CHECK_ARG(!(a.a_kmajor == 0 && a.b_kmajor != 0), "gemm_planes: layout (A m-major, B k-major) not built");
-    PlaneGemmParams p;
-    p.a = a;
-    p.drop_thr = dropout_threshold(a.drop_p);
-    p.drop_scale = 1.f / (1.f - a.drop_p);
-    const bool ak = a.a_kmajor != 0, bk = a.b_kmajor != 0;
-    int rc;
-    if (a.precision == 3) rc = (ak && bk) ? launch_planes<3, true, true>(p, s) : ak ? launch_planes<3, true, false>(p, s) : launch_planes<3, false, false>(p, s);
-    else rc = (ak && bk) ? launch_planes<1, true, true>(p, s) : ak ? launch_planes<1, true, false>(p, s) : launch_planes<1, false, false>(p, s);
-    if (rc) return rc;
+    return 0;
+}
+
+size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
+    size_t floats = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const int nks = split_k ? split_k[i] : 1;
+        if (nks <= 1) continue;
+        const size_t tx = ceil_div(jobs[i].N, PT), ty = ceil_div(jobs[i].M, PT);
+        floats += tx * ty * nks * (size_t)(PTHREADS * 8) + ty * nks * (size_t)PT;
+    }
+    return GROUP_COUNTERS * sizeof(int) + floats * sizeof(float);
+}
+
+int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs, void* scratch, size_t scratch_bytes,
+                      hipStream_t s) {
+    SLNLP_CHECK_ARG(jobs && njobs >= 1 && njobs <= MAX_JOBS, "gemm_group: 1..%d jobs", MAX_JOBS);
+    PlaneGroupParams P;
+    P.njobs = njobs;
+    int blocks = 0, ctr = 0;
+    size_t off = GROUP_COUNTERS * sizeof(int);
+    for (int i = 0; i < njobs; ++i) {
+        const slnlp_gemm_args& a = jobs[i];
+        SLNLP_TRY(check_plane_job(a));
+        SLNLP_CHECK_ARG(a.precision == jobs[0].precision, "gemm_group: jobs of one launch share the precision");
+        PlaneJob& j = P.job[i];
+        j.a = a;
+        j.drop_thr = dropout_threshold(a.drop_p);
+        j.drop_scale = 1.f / (1.f - a.drop_p);
+        j.variant = (a.a_kmajor && a.b_kmajor) ? 0 : a.a_kmajor ? 1 : 2;
+        j.tiles_x = ceil_div(a.N, PT);
+        j.tiles_y = ceil_div(a.M, PT);
+        const int ktiles = ceil_div(a.K, PT);
+        int nks = split_k ? split_k[i] : 1;
+        if (nks < 1) nks = 1;
+        if (nks > ktiles) nks = ktiles;
+        j.nks = nks;
+        j.block_begin = blocks;
+        j.part = nullptr;
+        j.part_rs = nullptr;
+        j.counters = nullptr;
+        const int tiles = j.tiles_x * j.tiles_y;
+        if (nks > 1) {
+            SLNLP_CHECK_ARG(scratch && (((uintptr_t)scratch) & 15) == 0, "gemm_group: split-K needs a 16-byte aligned scratch buffer");
+            SLNLP_CHECK_ARG(ctr + tiles <= GROUP_COUNTERS, "gemm_group: more than %d split-K tiles in one launch", GROUP_COUNTERS);
+            j.counters = reinterpret_cast<int*>(scratch) + ctr;
+            ctr += tiles;
+            j.part = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + off);
+            off += (size_t)tiles * nks * PTHREADS * 8 * sizeof(float);
+            j.part_rs = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + off);
+            off += (size_t)j.tiles_y * nks * PT * sizeof(float);
+            SLNLP_CHECK_ARG(off <= scratch_bytes, "gemm_group: scratch too small (%zu > %zu bytes)", off, scratch_bytes);
+        }
+        blocks += tiles * nks;
+    }
+    SLNLP_TRY(gemm_planes_init());
+    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_planes_kernel<3>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P);
+    else hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P);
     SLNLP_CHECK_LAUNCH("gemm_planes");
     return 0;
 }
+
+int gemm_planes(const slnlp_gemm_args& a, hipStream_t s) { return gemm_planes_group(&a, nullptr, 1, nullptr, 0, s); }
 
 // fp32 [R, C] (row stride ld) -> bf16 hi / lo planes with row stride ldp (valid region only; the padding of the
 // planes stays zero from their one-time memset).  Used for the weights once per step and by tests.
@@ -297,6 +405,16 @@ int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, u
 }
 
 }  // namespace slnlp
+
+extern "C" int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs) {
+    if (!jobs || njobs < 1) return 0;
+    return (int64_t)slnlp::gemm_group_scratch_bytes(jobs, split_k, njobs);
+}
+extern "C" int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
+                                int64_t scratch_bytes, void* stream) {
+    return slnlp::gemm_planes_group(jobs, split_k, njobs, scratch, (size_t)(scratch_bytes < 0 ? 0 : scratch_bytes),
+                                    (hipStream_t)stream);
+}
 
 extern "C" int slnlp_split_planes(const float* x, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,
                                   void* stream) {

@@ -166,9 +166,18 @@ struct Ws {
     PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
     char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
     float* opt_partials;
+    char* gscr[2];          // split-K scratch of the grouped GEMM launches: [0] main stream, [1] side stream
+    size_t gscr_bytes;
     slnlp_ln_reduce_entry* ln_table;
     size_t bytes;
 };
+
+constexpr int MAX_SPLITK = 8;
+// weight-gradient GEMMs contract over the T tokens: aim at ~10 K-tiles (of 64) per workgroup
+static int splitk_for(int T) {
+    const int n = ((T + 63) / 64 + 5) / 10;
+    return n < 1 ? 1 : n > MAX_SPLITK ? MAX_SPLITK : n;
+}
 
 static Ws carve(const slnlp_tf_config& c, void* base) {
     Ws w;
@@ -271,6 +280,12 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.ctxp = pp(E); a.x1p = pp(E); a.hp = pp(F); a.x2p = pp(E);
         a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
         w.dec[i].gkvp = pp(2 * E);
+    }
+    {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
+        const size_t tx = ((E > F ? E : F) + 63) / 64, ty = ((3 * E > F ? 3 * E : F) + 63) / 64;
+        w.gscr_bytes = 16384 + tx * ty * MAX_SPLITK * (512 * 8 * sizeof(float)) + ty * MAX_SPLITK * 64 * sizeof(float);
+        w.gscr_bytes = (w.gscr_bytes + 255) & ~(size_t)255;
+        for (int i = 0; i < 2; ++i) w.gscr[i] = b.take<char>(w.gscr_bytes);
     }
     b.cur = (b.cur + 255) & ~(size_t)255;
     w.planes_end = b.base + b.cur;
@@ -392,8 +407,8 @@ struct slnlp_tf_plan {
         a.precision = cfg.precision;
         return gemm(a, st);
     }
-    int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
-                float gate_scale, const float* resid, const PP* outp, hipStream_t st) const {
+    slnlp_gemm_args dgrad_p_args(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
+                                 float gate_scale, const float* resid, const PP* outp) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = ldy; a.a_kmajor = 1;
@@ -403,9 +418,13 @@ struct slnlp_tf_plan {
         a.resid = resid; a.ldr = Kin;
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = Kin; }
         a.precision = cfg.precision;
-        return gemm(a, st);
+        return a;
     }
-    int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {
+    int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
+                float gate_scale, const float* resid, const PP* outp, hipStream_t st) const {
+        return gemm(dgrad_p_args(dy, ldy, M, Nout, woff, Kin, dx, gate, gate_scale, resid, outp), st);
+    }
+    slnlp_gemm_args wgrad_p_args(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = ldy; a.a_kmajor = 0;
@@ -413,7 +432,29 @@ struct slnlp_tf_plan {
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
         a.precision = cfg.precision;
-        return gemm(a, st);
+        return a;
+    }
+    int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {
+        return gemm(wgrad_p_args(dy, ldy, T, Nout, x, Kin, dW, db), st);
+    }
+    // weight gradient (split-K over the tokens) and data gradient of one dY in ONE launch: the wgrad's workgroups
+    // fill the CUs the dgrad leaves idle, and there is no cross-queue edge to pay for (measured 4-10 us each)
+    int wd_group(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, int which_scratch, hipStream_t st) const {
+        const slnlp_gemm_args jobs[2] = {wg, dg};
+        // Split factor of the weight gradient (K loop = tokens): the plane GEMM keeps 2 workgroups per CU resident
+        // (512 slots) and a K-step costs about the same in every workgroup, so estimate
+        //   time ~ rounds(total workgroups / 512) x longest K loop   (+1 step for the split-K meeting)
+        // and take the best split; more workgroups than slots only adds a second, mostly empty round.
+        auto cd = [](int a, int b) { return (a + b - 1) / b; };
+        const int tw = cd(wg.M, 64) * cd(wg.N, 64), td = cd(dg.M, 64) * cd(dg.N, 64), kw = cd(wg.K, 64), kd = cd(dg.K, 64);
+        int best = 1, best_cost = 1 << 30;
+        for (int n = 1; n <= MAX_SPLITK && n <= kw; ++n) {
+            const int len = cd(kw, n) + (n > 1 ? 1 : 0);
+            const int cost = cd(tw * n + td, 512) * (len > kd ? len : kd);
+            if (cost < best_cost) { best_cost = cost; best = n; }
+        }
+        const int split[2] = {best, 1};
+        return gemm_planes_group(jobs, split, 2, w.gscr[which_scratch], w.gscr_bytes, st);
     }
     // zero padding of the activation planes is per batch size: re-zero when it changes (outside any capture)
     int prepare_planes(int B, hipStream_t st) {
@@ -702,9 +743,9 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         SLNLP_TRY(pl->fork(st, 2));
         // d memory accumulates over decoder layers in a fixed order on side[0]
         if (up) {
-            SLNLP_TRY(pl->dgrad_p(a.gkvp, 2 * E, M, 2 * E, q.cin_w + (long)E * E, E, w.gmem, nullptr, 0.f,
-                                  l == c.N - 1 ? nullptr : w.gmem, nullptr, s0));
-            SLNLP_TRY(pl->wgrad_p(a.gkvp, 2 * E, M, 2 * E, w.memp, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, s1));
+            SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gkvp, 2 * E, M, 2 * E, w.memp, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E),
+                                   pl->dgrad_p_args(a.gkvp, 2 * E, M, 2 * E, q.cin_w + (long)E * E, E, w.gmem, nullptr, 0.f,
+                                                    l == c.N - 1 ? nullptr : w.gmem, nullptr), 1, s0));
         } else {
             SLNLP_TRY(pl->dgrad(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
                                 l == c.N - 1 ? nullptr : w.gmem, s0));
@@ -751,14 +792,13 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                 pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st, (up && p == 0.f) ? a.d2p.out() : none,
                                 (up && p > 0.f) ? a.d2p.out() : none));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
-        SLNLP_TRY(pl->fork(st, 1));
         if (up) {
-            SLNLP_TRY(pl->wgrad_p(a.d2p, E, M, E, a.hp, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
-            SLNLP_TRY(pl->dgrad_p(a.d2p, E, M, E, q.l2_w, F, a.gh, a.h, ik, nullptr, &a.ghp, st));
-            SLNLP_TRY(pl->fork(st, 2));
-            SLNLP_TRY(pl->wgrad_p(a.ghp, F, M, F, a.x1p, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
-            SLNLP_TRY(pl->dgrad_p(a.ghp, F, M, F, q.l1_w, E, a.gx1, nullptr, 0.f, a.gA2, nullptr, st));
+            SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.d2p, E, M, E, a.hp, F, pl->G(q.l2_w), pl->G(q.l2_b)),
+                                   pl->dgrad_p_args(a.d2p, E, M, E, q.l2_w, F, a.gh, a.h, ik, nullptr, &a.ghp), 0, st));
+            SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.ghp, F, M, F, a.x1p, E, pl->G(q.l1_w), pl->G(q.l1_b)),
+                                   pl->dgrad_p_args(a.ghp, F, M, F, q.l1_w, E, a.gx1, nullptr, 0.f, a.gA2, nullptr), 0, st));
         } else {
+            SLNLP_TRY(pl->fork(st, 1));
             SLNLP_TRY(pl->wgrad(d2, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
             SLNLP_TRY(pl->dgrad(d2, E, M, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
             SLNLP_TRY(pl->fork(st, 2));
@@ -769,15 +809,14 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                 pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st, (up && p == 0.f) ? a.d1p.out() : none,
                                 (up && p > 0.f) ? a.d1p.out() : none));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
-        SLNLP_TRY(pl->fork(st, 0));
         if (up) {
-            SLNLP_TRY(pl->wgrad_p(a.d1p, E, M, E, a.ctxp, E, pl->G(q.out_w), pl->G(q.out_b), s0));
-            SLNLP_TRY(pl->dgrad_p(a.d1p, E, M, E, q.out_w, E, a.gctx, nullptr, 0.f, nullptr, nullptr, st));
+            SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.d1p, E, M, E, a.ctxp, E, pl->G(q.out_w), pl->G(q.out_b)),
+                                   pl->dgrad_p_args(a.d1p, E, M, E, q.out_w, E, a.gctx, nullptr, 0.f, nullptr, nullptr), 0, st));
             SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st, a.gqkvp.out()));
-            SLNLP_TRY(pl->fork(st, 1));
-            SLNLP_TRY(pl->wgrad_p(a.gqkvp, 3 * E, M, 3 * E, xp_in, E, pl->G(q.in_w), pl->G(q.in_b), s1));
-            SLNLP_TRY(pl->dgrad_p(a.gqkvp, 3 * E, M, 3 * E, q.in_w, E, a.gx0, nullptr, 0.f, a.gA1, nullptr, st));
+            SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, xp_in, E, pl->G(q.in_w), pl->G(q.in_b)),
+                                   pl->dgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, q.in_w, E, a.gx0, nullptr, 0.f, a.gA1, nullptr), 0, st));
         } else {
+            SLNLP_TRY(pl->fork(st, 0));
             SLNLP_TRY(pl->wgrad(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), s0));
             SLNLP_TRY(pl->dgrad(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr, st));
             SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st));

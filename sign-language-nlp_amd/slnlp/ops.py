@@ -50,6 +50,34 @@ def split_planes(x, want_lo=True):
     return hi, lo
 
 
+def plane_job(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, precision=3, rowsum_a=None, bias=None,
+              relu=False, resid=None):
+    """GemmArgs of one pre-split GEMM (for gemm_group); returns (args, out)."""
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=Ap[0].device)
+    a = GemmArgs()
+    a.C, a.ldc, a.M, a.N, a.K = ptr(out), out.stride(0), M, N, K
+    a.a_kmajor, a.b_kmajor, a.precision = int(a_kmajor), int(b_kmajor), precision
+    a.A_hi, a.A_lo, a.lda_p = ptr(Ap[0]), ptr(Ap[1]), Ap[0].stride(0)
+    a.B_hi, a.B_lo, a.ldb_p = ptr(Bp[0]), ptr(Bp[1]), Bp[0].stride(0)
+    a.bias, a.relu, a.rowsum_a = ptr(bias), int(relu), ptr(rowsum_a)
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    return a, out
+
+
+def gemm_group(jobs, split_k=None, scratch=None):
+    """ONE launch for up to 4 plane GEMMs (list of GemmArgs); split_k[i] > 1 = deterministic split-K."""
+    _lib.require_gpu()
+    n = len(jobs)
+    arr = (GemmArgs * n)(*jobs)
+    sk = (C.c_int32 * n)(*(split_k or [1] * n))
+    if scratch is None:
+        nbytes = int(load().slnlp_gemm_group_scratch_bytes(arr, sk, n))
+        scratch = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    check(load().slnlp_gemm_group(arr, sk, n, ptr(scratch), scratch.numel(), stream_ptr()), "gemm_group")
+    return scratch
+
+
 def gemm_planes(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, precision=3, rowsum_a=None, bias=None,
                 relu=False, resid=None, want_planes=False):
     """C = A B^T over pre-split operands Ap = (hi, lo), Bp = (hi, lo) (see split_planes)."""

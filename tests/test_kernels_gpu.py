@@ -302,3 +302,34 @@ def test_gemm_planes_epilogue_and_output_planes(ops):
     back = (hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float())[:M, :N]
     assert rel(back, ref) < 1e-4                                          # emitted planes reconstruct the result
     assert float(hi[M:].abs().max()) == 0 and float(hi[:, N:].abs().max()) == 0   # padding untouched
+
+
+@pytest.mark.parametrize("split", [1, 4, 7])
+def test_gemm_group_dgrad_wgrad_one_launch(ops, split):
+    """Data- and weight-gradient of one dY in ONE launch (gemm_planes.hip group kernel); the weight gradient's long
+    K loop (= tokens) is split over `split` workgroups per tile and reduced in a fixed order -> bit-reproducible."""
+    Mtok, Nout, Kin = 2400, 192, 320
+    dY, X, W = rnd(Mtok, Nout, seed=1), rnd(Mtok, Kin, seed=2), rnd(Nout, Kin, seed=3)
+    dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
+    rs = torch.empty(Nout, device="cuda")
+    jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)   # dW = dY^T X, db = colsum dY
+    jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)                 # dX = dY W
+    scratch = ops.gemm_group([jw, jd], [split, 1])
+    assert rel(dW, dY.double().T @ X.double()) < 2e-4
+    assert rel(dX, dY.double() @ W.double()) < 1e-4
+    assert rel(rs, dY.double().sum(0)) < 1e-4
+    if split > 1:
+        assert int(scratch[:16384].view(torch.int32).abs().max()) == 0          # arrival counters back to zero
+        dW1, rs1 = dW.clone(), rs.clone()
+        dW.zero_(); rs.zero_()
+        ops.gemm_group([jw, jd], [split, 1], scratch)                           # same scratch, no re-zeroing
+        assert torch.equal(dW, dW1) and torch.equal(rs, rs1)                    # deterministic
+    # three jobs, ragged shapes, split larger than the number of K tiles (clamped)
+    A2, B2 = rnd(70, 130, seed=5), rnd(50, 130, seed=6)
+    def planes(x):
+        xp = torch.zeros(x.shape[0], (x.shape[1] + 3) // 4 * 4); xp[:, :x.shape[1]] = x
+        return ops.split_planes(xp.cuda())
+    A2p, B2p = planes(A2), planes(B2)                                           # jobs hold raw pointers: keep the planes alive
+    j3, o3 = ops.plane_job(A2p, B2p, M=70, N=50, K=130)
+    ops.gemm_group([jw, j3, jd], [split, 9, 1])
+    assert rel(o3, A2.double() @ B2.double().T) < 1e-4 and rel(dW, dY.double().T @ X.double()) < 2e-4
