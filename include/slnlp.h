@@ -78,7 +78,8 @@ typedef struct slnlp_gemm_args {
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
-/* Grouped launch: up to 4 independent pre-split (plane) GEMMs in ONE kernel launch -- e.g. the data gradient
+/* Grouped launch: up to 4 independent GEMMs (all with pre-split plane operands, or all with fp32 operands -- then
+ * split_k / scratch are ignored) in ONE kernel launch -- e.g. the data gradient
  * and the weight gradient of one dY, which replace autograd's separate mm calls for nn.Linear
  * (transformer.py:40-48 -> torch).  split_k[i] > 1 (or NULL = all 1) divides job i's K loop over that many
  * workgroups per output tile; the partial tiles meet in `scratch` and are added in split order by the last

@@ -137,6 +137,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------- internal kernel launchers
 namespace slnlp {
 int gemm(const slnlp_gemm_args& a, hipStream_t s);
+int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s);   // fp32-operand jobs, one launch (gemm.hip)
 int gemm_planes(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_planes_init();
 // up to 4 independent plane GEMMs in ONE launch, optional deterministic split-K per job (gemm_planes.hip)

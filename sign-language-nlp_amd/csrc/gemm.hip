@@ -183,16 +183,24 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// LDS of one tile job: A planes, B planes, 4 x 64 row-sum scratch
+template <int NSPLIT, bool AK, bool BK, int BNT>
+constexpr int tile_lds_elems() {
+    return (NSPLIT == 3 ? 2 : 1) * (TileIO<AK, BM>::PLANE + TileIO<BK, BNT>::PLANE) + 4 * BM * 2;
+}
+
+// One workgroup's tile: block (bid_x, bid_y) of a (grid_x, grid_y) grid over C.
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bid_y, int grid_x, int grid_y,
+                                          unsigned short* __restrict__ smem) {
     using TA = TileIO<AK, BM>;
     using TB = TileIO<BK, BNT>;
     constexpr int NP = (NSPLIT == 3) ? 2 : 1;
     constexpr int MT = (BNT == 16) ? 1 : 2;  // 16x16 tiles per wave along M
     constexpr int NT = (BNT == 64) ? 2 : 1;  // ... along N
-    __shared__ __attribute__((aligned(16))) unsigned short As[NP * TA::PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP * TB::PLANE];
-    __shared__ float rsum[4][BM];
+    unsigned short* As = smem;
+    unsigned short* Bs = smem + NP * TA::PLANE;
+    float (*rsum)[BM] = reinterpret_cast<float (*)[BM]>(smem + NP * (TA::PLANE + TB::PLANE));
 
     const slnlp_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,11 +212,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     // L2 then holds the whole B operand plus a few A panels instead of every panel of both.
     int bx, by;
     {
-        const int nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int nwg = grid_x * grid_y, id = bid_y * grid_x + bid_x;
         const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        by = t / gridDim.x;
-        bx = t - by * gridDim.x;
+        by = t / grid_x;
+        bx = t - by * grid_x;
     }
     const int bm0 = by * BM, bn0 = bx * BNT;
     const int M = g.M, N = g.N, K = g.K;
@@ -325,6 +333,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
 }
 
+template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[tile_lds_elems<NSPLIT, AK, BK, BNT>()];
+    gemm_tile<NSPLIT, AK, BK, BNT, VEC>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+}
+
+// Several independent fp32-operand GEMMs in ONE launch (e.g. the data- and weight-gradient of one dY in the
+// decoder, whose B-row GEMMs are pure launch latency): workgroups [block_begin, block_begin + gx*gy) run job j.
+constexpr int GEMM_GROUP_MAX = 4;
+struct GemmGroupParams {
+    GemmParams job[GEMM_GROUP_MAX];
+    int variant[GEMM_GROUP_MAX];      // (a_kmajor, b_kmajor, narrow) -> 0..5
+    int gx[GEMM_GROUP_MAX], gy[GEMM_GROUP_MAX], block_begin[GEMM_GROUP_MAX];
+    int njobs;
+};
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[tile_lds_elems<NSPLIT, false, false, 64>()];   // the largest variant
+    int j = 0;
+    for (int t = 1; t < P.njobs; ++t)
+        if ((int)blockIdx.x >= P.block_begin[t]) j = t;
+    const GemmParams& p = P.job[j];
+    const int lid = blockIdx.x - P.block_begin[j], gx = P.gx[j], gy = P.gy[j];
+    const int bx = lid % gx, by = lid / gx;
+    switch (P.variant[j]) {
+        case 0: gemm_tile<NSPLIT, true, true, 64, true>(p, bx, by, gx, gy, smem); break;
+        case 1: gemm_tile<NSPLIT, true, true, 16, true>(p, bx, by, gx, gy, smem); break;
+        case 2: gemm_tile<NSPLIT, true, false, 64, true>(p, bx, by, gx, gy, smem); break;
+        case 3: gemm_tile<NSPLIT, true, false, 16, true>(p, bx, by, gx, gy, smem); break;
+        case 4: gemm_tile<NSPLIT, false, false, 64, true>(p, bx, by, gx, gy, smem); break;
+        default: gemm_tile<NSPLIT, false, false, 16, true>(p, bx, by, gx, gy, smem); break;
+    }
+}
+
 template <int NSPLIT, bool AK, bool BK, bool VEC>
 static void launch2(const GemmParams& p, hipStream_t s) {
     // Skinny problems (one row-block) get 16-column tiles: 4x the workgroups, so a
@@ -351,8 +394,7 @@ static bool vec_ok(const float* ptr, long ld) {
     return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0);
 }
 
-int gemm(const slnlp_gemm_args& a, hipStream_t s) {
-    if (a.A_hi || a.B_hi) return gemm_planes(a, s);   // pre-split operands: LDS-DMA kernel (gemm_planes.hip)
+static int fill_params(const slnlp_gemm_args& a, GemmParams& p) {
     SLNLP_CHECK_ARG(a.A && a.B && a.C, "gemm: null operand");
     SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     SLNLP_CHECK_ARG(a.precision == 1 || a.precision == 3, "gemm: precision must be 1 or 3, got %d", a.precision);
@@ -364,12 +406,18 @@ int gemm(const slnlp_gemm_args& a, hipStream_t s) {
     SLNLP_CHECK_ARG(!a.gate || a.ldg >= a.N, "gemm: ldg too small");
     SLNLP_CHECK_ARG(!a.resid || a.ldr >= a.N, "gemm: ldr too small");
     SLNLP_CHECK_ARG(!(a.a_kmajor == 0 && a.b_kmajor != 0), "gemm: layout (A m-major, B k-major) not built");
-    GemmParams p;
     p.a = a;
     p.drop_thr = dropout_threshold(a.drop_p);
     p.drop_scale = 1.f / (1.f - a.drop_p);
     p.a_vec = vec_ok(a.A, a.lda);
     p.b_vec = vec_ok(a.B, a.ldb);
+    return 0;
+}
+
+int gemm(const slnlp_gemm_args& a, hipStream_t s) {
+    if (a.A_hi || a.B_hi) return gemm_planes(a, s);   // pre-split operands: LDS-DMA kernel (gemm_planes.hip)
+    GemmParams p;
+    SLNLP_TRY(fill_params(a, p));
     const bool ak = a.a_kmajor != 0, bk = a.b_kmajor != 0;
     if (a.precision == 3) {
         if (ak && bk) launch<3, true, true>(p, s);
@@ -381,6 +429,37 @@ int gemm(const slnlp_gemm_args& a, hipStream_t s) {
         else launch<1, false, false>(p, s);
     }
     SLNLP_CHECK_LAUNCH("gemm");
+    return SLNLP_OK;
+}
+
+// fp32-operand jobs in one launch; a job with operands that cannot take 16-B vector loads makes the whole group
+// fall back to one launch per job (same results, just not fused)
+int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
+    SLNLP_CHECK_ARG(jobs && njobs >= 1 && njobs <= GEMM_GROUP_MAX, "gemm_group: 1..%d jobs", GEMM_GROUP_MAX);
+    GemmGroupParams P;
+    P.njobs = njobs;
+    int blocks = 0;
+    bool fusable = true;
+    for (int i = 0; i < njobs; ++i) {
+        const slnlp_gemm_args& a = jobs[i];
+        SLNLP_CHECK_ARG(!a.A_hi && !a.B_hi, "gemm_group: fp32 and pre-split jobs cannot share a launch");
+        SLNLP_CHECK_ARG(a.precision == jobs[0].precision, "gemm_group: jobs of one launch share the precision");
+        SLNLP_TRY(fill_params(a, P.job[i]));
+        fusable = fusable && P.job[i].a_vec && P.job[i].b_vec;
+        const bool narrow = a.M <= BM && a.rowsum_a == nullptr;
+        P.variant[i] = (a.a_kmajor && a.b_kmajor ? 0 : a.a_kmajor ? 2 : 4) + (narrow ? 1 : 0);
+        P.gx[i] = ceil_div(a.N, narrow ? 16 : 64);
+        P.gy[i] = ceil_div(a.M, BM);
+        P.block_begin[i] = blocks;
+        blocks += P.gx[i] * P.gy[i];
+    }
+    if (!fusable || njobs == 1) {
+        for (int i = 0; i < njobs; ++i) SLNLP_TRY(gemm(jobs[i], s));
+        return SLNLP_OK;
+    }
+    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_group_kernel<3>, dim3(blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(blocks), dim3(256), 0, s, P);
+    SLNLP_CHECK_LAUNCH("gemm_group");
     return SLNLP_OK;
 }
 

@@ -412,6 +412,7 @@ extern "C" int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, c
 }
 extern "C" int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
                                 int64_t scratch_bytes, void* stream) {
+    if (jobs && njobs >= 1 && !jobs[0].A_hi && !jobs[0].B_hi) return slnlp::gemm_group(jobs, njobs, (hipStream_t)stream);
     return slnlp::gemm_planes_group(jobs, split_k, njobs, scratch, (size_t)(scratch_bytes < 0 ? 0 : scratch_bytes),
                                     (hipStream_t)stream);
 }

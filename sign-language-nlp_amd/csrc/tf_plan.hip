@@ -368,8 +368,8 @@ struct slnlp_tf_plan {
         return gemm(a, st);
     }
     // dx[M,Kin] = dy[M,Nout] W[Nout,Kin]  (*gate) (+resid)
-    int dgrad(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx, const float* gate,
-              float gate_scale, const float* resid, hipStream_t st) const {
+    slnlp_gemm_args dgrad_args(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx,
+                               const float* gate, float gate_scale, const float* resid) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = dy; a.lda = ldy; a.a_kmajor = 1;
@@ -378,11 +378,14 @@ struct slnlp_tf_plan {
         a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
         a.resid = resid; a.ldr = Kin;
         a.precision = cfg.precision;
-        return gemm(a, st);
+        return a;
+    }
+    int dgrad(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx, const float* gate,
+              float gate_scale, const float* resid, hipStream_t st) const {
+        return gemm(dgrad_args(dy, ldy, M, Nout, W, Kin, dx, gate, gate_scale, resid), st);
     }
     // dW[Nout,Kin] = dy[T,Nout]^T x[T,Kin];  db[Nout] = colsum(dy)
-    int wgrad(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db,
-              hipStream_t st) const {
+    slnlp_gemm_args wgrad_args(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = dy; a.lda = ldy; a.a_kmajor = 0;
@@ -390,7 +393,16 @@ struct slnlp_tf_plan {
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
         a.precision = cfg.precision;
-        return gemm(a, st);
+        return a;
+    }
+    int wgrad(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db,
+              hipStream_t st) const {
+        return gemm(wgrad_args(dy, ldy, T, Nout, x, Kin, dW, db), st);
+    }
+    // weight- and data-gradient of one dY (fp32 operands) in one launch
+    int wd_group_f(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, hipStream_t st) const {
+        const slnlp_gemm_args jobs[2] = {wg, dg};
+        return gemm_group(jobs, 2, st);
     }
     // ---- the same three GEMM roles over pre-split planes; weights: planes of the arena at offset woff
     int linear_p(const PP& x, int M, int K, long woff, int N, const float* bias, float* y, long ldy, int relu, float p,
@@ -695,7 +707,7 @@ int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
 int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
-    hipStream_t s0 = pl->side[0], s1 = pl->side[1], s2 = pl->side[2];
+    hipStream_t s0 = pl->side[0], s2 = pl->side[2];
     const slnlp_tf_config& c = pl->cfg;
     const Ws& w = pl->w;
     const Layout& L = pl->L;
@@ -705,13 +717,14 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     const int64_t *X = pl->last_X, *y = pl->last_y;
     const bool up = pl->use_planes;
     int nb;
-    // Main stream = the dependent chain (LN backward, dgrads, attention backward).
-    // side[1]/side[2] = weight gradients (they only feed the optimizer); side[0] = d memory accumulation.
+    // Everything runs on the main stream; the weight gradient of each dY shares a launch with its data gradient.
+    // Only the (large, independent) d memory / K|V weight-gradient groups go to side[0] and the target-embedding
+    // gradient to side[2]: graph replay places parallel branches on its own queues and every cross-queue edge
+    // costs 4-10 us, so fine-grained forks were measured slower than no forks.
 
     // generator: logits = tfin lin_w^T + lin_b
-    SLNLP_TRY(pl->fork(st, 1));
-    SLNLP_TRY(pl->wgrad(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b), s1));
-    SLNLP_TRY(pl->dgrad(w.dlogits, Vp, B, c.Vt, pl->P(L.lin_w), E, w.gfin, nullptr, 0.f, nullptr, st));
+    SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b)),
+                             pl->dgrad_args(w.dlogits, Vp, B, c.Vt, pl->P(L.lin_w), E, w.gfin, nullptr, 0.f, nullptr), st));
     SLNLP_TRY(layernorm_bwd(w.gfin, w.dec[c.N - 1].t3, pl->P(L.decn_w), w.st_fin, B, E, nullptr, w.gtl, nullptr, 0.f, 0,
                             rng, w.lnp_fin, &nb, pl->nbD, st));
     const float* dt = w.gtl;  // gradient w.r.t. the current decoder layer's output
@@ -723,53 +736,42 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, a.gA3, p > 0.f ? a.gB3 : nullptr, p,
                                 pl->dec_site(l, 5), rng, a.lnp3, &nb, pl->nbD, st));
         const float* d3 = p > 0.f ? a.gB3 : a.gA3;
-        SLNLP_TRY(pl->fork(st, 1));
-        SLNLP_TRY(pl->wgrad(d3, E, B, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
-        SLNLP_TRY(pl->dgrad(d3, E, B, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
-        SLNLP_TRY(pl->fork(st, 2));
-        SLNLP_TRY(pl->wgrad(a.gh, F, B, F, a.t2, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
-        SLNLP_TRY(pl->dgrad(a.gh, F, B, F, pl->P(q.l1_w), E, a.gt2, nullptr, 0.f, a.gA3, st));
+        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d3, E, B, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b)),
+                                 pl->dgrad_args(d3, E, B, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr), st));
+        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gh, F, B, F, a.t2, E, pl->G(q.l1_w), pl->G(q.l1_b)),
+                                 pl->dgrad_args(a.gh, F, B, F, pl->P(q.l1_w), E, a.gt2, nullptr, 0.f, a.gA3), st));
         // norm2 / cross-attention
         SLNLP_TRY(layernorm_bwd(a.gt2, a.y2, pl->P(q.n2_w), a.st2, B, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
                                 pl->dec_site(l, 3), rng, a.lnp2, &nb, pl->nbD, st));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
-        SLNLP_TRY(pl->fork(st, 1));
-        SLNLP_TRY(pl->wgrad(d2, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b), s1));
-        SLNLP_TRY(pl->dgrad(d2, E, B, E, pl->P(q.cout_w), E, a.gxctx, nullptr, 0.f, nullptr, st));
+        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d2, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b)),
+                                 pl->dgrad_args(d2, E, B, E, pl->P(q.cout_w), E, a.gxctx, nullptr, 0.f, nullptr), st));
         SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, a.gxctx, B, S, H, dh, a.gq, a.gkv, 2 * E, p, pl->dec_site(l, 2), rng, st,
                                  up ? a.gkvp.out() : PlaneOut{}));
+        // d memory accumulates over the decoder layers in a fixed order on side[0], next to its weight gradient
         SLNLP_TRY(pl->fork(st, 0));
-        SLNLP_TRY(pl->fork(st, 1));
-        SLNLP_TRY(pl->fork(st, 2));
-        // d memory accumulates over decoder layers in a fixed order on side[0]
         if (up) {
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gkvp, 2 * E, M, 2 * E, w.memp, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E),
                                    pl->dgrad_p_args(a.gkvp, 2 * E, M, 2 * E, q.cin_w + (long)E * E, E, w.gmem, nullptr, 0.f,
                                                     l == c.N - 1 ? nullptr : w.gmem, nullptr), 1, s0));
         } else {
-            SLNLP_TRY(pl->dgrad(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
-                                l == c.N - 1 ? nullptr : w.gmem, s0));
-            SLNLP_TRY(pl->wgrad(a.gkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E, s1));
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E),
+                                     pl->dgrad_args(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
+                                                    l == c.N - 1 ? nullptr : w.gmem), s0));
         }
-        SLNLP_TRY(pl->wgrad(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b), s2));
-        SLNLP_TRY(pl->dgrad(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2, st));
+        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b)),
+                                 pl->dgrad_args(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2), st));
         // norm1 / self-attention (single key)
         SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
                                 pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, st));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
-        SLNLP_TRY(pl->fork(st, 2));
-        SLNLP_TRY(pl->wgrad(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b), s2));
-        SLNLP_TRY(pl->dgrad(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr, st));
+        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b)),
+                                 pl->dgrad_args(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr), st));
         if (p > 0.f) SLNLP_TRY(head_dropout(a.gv, B, H, dh, p, pl->dec_site(l, 0), rng, st));
-        SLNLP_TRY(pl->fork(st, 2));
-        // softmax over one element has zero gradient: q/k rows of in_proj get exactly 0
-        if (hipMemsetAsync(pl->G(q.sin_w), 0, 2L * E * E * sizeof(float), s2) != hipSuccess ||
-            hipMemsetAsync(pl->G(q.sin_b), 0, 2L * E * sizeof(float), s2) != hipSuccess) {
-            set_error("tf_backward: memset failed");
-            return SLNLP_ERR_LAUNCH;
-        }
-        SLNLP_TRY(pl->wgrad(a.gv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E, s2));
-        SLNLP_TRY(pl->dgrad(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1, st));
+        // softmax over one element has zero gradient: the q/k rows of in_proj (weight and bias) get exactly 0.
+        // Nothing ever writes them, and the gradient arena is zeroed at plan creation, so they stay zero.
+        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E),
+                                 pl->dgrad_args(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1), st));
         dt = a.gt0;
     }
     SLNLP_TRY(pl->fork(st, 2));
@@ -798,12 +800,10 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.ghp, F, M, F, a.x1p, E, pl->G(q.l1_w), pl->G(q.l1_b)),
                                    pl->dgrad_p_args(a.ghp, F, M, F, q.l1_w, E, a.gx1, nullptr, 0.f, a.gA2, nullptr), 0, st));
         } else {
-            SLNLP_TRY(pl->fork(st, 1));
-            SLNLP_TRY(pl->wgrad(d2, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b), s1));
-            SLNLP_TRY(pl->dgrad(d2, E, M, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr, st));
-            SLNLP_TRY(pl->fork(st, 2));
-            SLNLP_TRY(pl->wgrad(a.gh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b), s2));
-            SLNLP_TRY(pl->dgrad(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2, st));
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d2, E, M, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b)),
+                                     pl->dgrad_args(d2, E, M, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr), st));
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b)),
+                                     pl->dgrad_args(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2), st));
         }
         SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
                                 pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st, (up && p == 0.f) ? a.d1p.out() : none,
@@ -816,13 +816,11 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, xp_in, E, pl->G(q.in_w), pl->G(q.in_b)),
                                    pl->dgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, q.in_w, E, a.gx0, nullptr, 0.f, a.gA1, nullptr), 0, st));
         } else {
-            SLNLP_TRY(pl->fork(st, 0));
-            SLNLP_TRY(pl->wgrad(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b), s0));
-            SLNLP_TRY(pl->dgrad(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr, st));
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b)),
+                                     pl->dgrad_args(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr), st));
             SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st));
-            SLNLP_TRY(pl->fork(st, 1));
-            SLNLP_TRY(pl->wgrad(a.gqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b), s1));
-            SLNLP_TRY(pl->dgrad(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1, st));
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b)),
+                                     pl->dgrad_args(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1), st));
         }
         dx = a.gx0;
     }
