@@ -567,46 +567,99 @@ __global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
 // ------------------------------------------------------------------ cross ---
 constexpr int XDH = 256;  // max head dim
 
+// One workgroup per (batch, head).  The work is a handful of 48 x 64 matrix-vector products, so the kernel is
+// pure memory latency: every global load of a phase is issued at once (K and V tiles go to LDS with 16-B loads,
+// three per thread), and the arithmetic then runs out of LDS.  Head dims above 64 loop over 64-wide chunks.
+__device__ __forceinline__ void xload_tile(float* __restrict__ T, const float* __restrict__ src, long ld, int B, int b,
+                                           int S, int col0, int dc, int tid) {
+    float4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u, s = idx >> 4, c = (idx & 15) << 2;
+        const bool ok = s < S && c < dc;
+        r[u] = *reinterpret_cast<const float4*>(src + ((long)(ok ? s : 0) * B + b) * ld + col0 + (ok ? c : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u, s = idx >> 4, c = (idx & 15) << 2;
+        const bool ok = s < S && c < dc;
+        *reinterpret_cast<float4*>(T + s * TLD + c) = ok ? r[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// dot of tile row j = tid >> 2 with vec over the 16 columns owned by part = tid & 3, reduced over the 4 parts
+__device__ __forceinline__ float xrow_dot(const float* __restrict__ T, const float* __restrict__ vec, int tid) {
+    const int j = tid >> 2, c0 = (tid & 3) << 4;
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 t = *reinterpret_cast<const float4*>(T + j * TLD + c0 + 4 * u);
+        const float4 v = *reinterpret_cast<const float4*>(vec + c0 + 4 * u);
+        a += t.x * v.x + t.y * v.y + t.z * v.z + t.w * v.w;
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    return a;
+}
+// sum_j w[j] * T[j][d] for d = tid & 63: rows split over the 4 waves, combined through red[4][64]
+__device__ __forceinline__ float xcol_sum(const float* __restrict__ T, const float* __restrict__ wj, float* __restrict__ red,
+                                          int tid) {
+    const int d = tid & 63, g = tid >> 6;
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a += wj[16 * g + u] * T[(16 * g + u) * TLD + d];
+    red[g * 64 + d] = a;
+    __syncthreads();
+    return red[d] + red[64 + d] + red[128 + d] + red[192 + d];
+}
+
 __global__ __launch_bounds__(256) void attn_cross_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ kv, long ld_kv, int B, int S, int H, int dh,
     float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr, int drop_site,
     const unsigned long long* __restrict__ rng) {
-    __shared__ __attribute__((aligned(16))) float qs[4][XDH];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bh = blockIdx.x * 4 + wave;
-    if (bh >= B * H) return;
-    const int b = bh / H, h = bh % H, E = H * dh;
-    for (int d = lane; d < dh; d += 64) qs[wave][d] = q[(long)b * E + h * dh + d];
-    __builtin_amdgcn_wave_barrier();
-    float sc = -INFINITY;
-    if (lane < S) {
-        const float* kr = kv + ((long)lane * B + b) * ld_kv + h * dh;
-        float a = 0.f;
-        for (int d = 0; d < dh; d += 4) {
-            const float4 k4 = *reinterpret_cast<const float4*>(kr + d);
-            const float4 q4 = *reinterpret_cast<const float4*>(&qs[wave][d]);
-            a += k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w;
-        }
-        sc = a * rsqrtf((float)dh);
+    __shared__ __attribute__((aligned(16))) float Ks[SMAX * TLD];
+    __shared__ __attribute__((aligned(16))) float Vs[SMAX * TLD];
+    __shared__ __attribute__((aligned(16))) float qs[DCH];
+    __shared__ float sc[SMAX], pd[SMAX], red[4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, E = H * dh;
+    const int nch = (dh + DCH - 1) / DCH;
+    float acc = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, dc = dh - d0 < DCH ? dh - d0 : DCH;
+        if (ch > 0) __syncthreads();
+        if (tid < DCH) qs[tid] = tid < dc ? q[(long)b * E + h * dh + d0 + tid] : 0.f;
+        xload_tile(Ks, kv, ld_kv, B, b, S, h * dh + d0, dc, tid);
+        if (nch == 1) xload_tile(Vs, kv, ld_kv, B, b, S, E + h * dh, dc, tid);
+        __syncthreads();
+        acc += xrow_dot(Ks, qs, tid);
     }
-    const float m = wave_max(sc);
-    const float e = expf(sc - m);
-    const float p = e / wave_sum(e);
-    float pd = 0.f;
-    if (lane < S) {
-        probs[(long)bh * S + lane] = p;
-        pd = p;
-        if (drop_p > 0.f) pd = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)lane, drop_thr) ? p / (1.f - drop_p) : 0.f;
-    }
-    for (int d0 = 0; d0 < dh; d0 += 64) {  // wave-uniform trip count: __shfl needs every lane active
-        const int d = d0 + lane;
-        const bool act = d < dh;
-        float a = 0.f;
-        for (int j = 0; j < S; ++j) {
-            const float pj = __shfl(pd, j, 64);
-            if (act) a += pj * kv[((long)j * B + b) * ld_kv + E + h * dh + d];
+    if ((tid & 3) == 0) sc[tid >> 2] = acc * rsqrtf((float)dh);
+    __syncthreads();
+    {   // softmax over the S keys: every wave computes it (no masks here), wave 0 publishes
+        const float v = lane < S ? sc[lane] : -INFINITY;
+        const float m = wave_max(v);
+        const float e = expf(v - m);
+        const float p = e / wave_sum(e);
+        if (tid < 64) {
+            float d = 0.f;
+            if (lane < S) {
+                probs[(long)bh * S + lane] = p;
+                d = p;
+                if (drop_p > 0.f) d = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)lane, drop_thr) ? p / (1.f - drop_p) : 0.f;
+            }
+            pd[lane] = d;
         }
-        if (act) ctx[(long)b * E + h * dh + d] = a;
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, dc = dh - d0 < DCH ? dh - d0 : DCH;
+        if (nch > 1) {
+            __syncthreads();
+            xload_tile(Vs, kv, ld_kv, B, b, S, E + h * dh + d0, dc, tid);
+            __syncthreads();
+        }
+        const float o = xcol_sum(Vs, pd, red, tid);
+        if (tid < dc) ctx[(long)b * E + h * dh + d0 + tid] = o;
     }
 }
 
@@ -615,51 +668,73 @@ __global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
     const float* __restrict__ dctx, int B, int S, int H, int dh, float* __restrict__ dq, float* __restrict__ dkv,
     long ld_dkv, float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* __restrict__ rng,
     PlaneOut po) {
-    __shared__ __attribute__((aligned(16))) float gs[4][XDH];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bh = blockIdx.x * 4 + wave;
-    if (bh >= B * H) return;
-    const int b = bh / H, h = bh % H, E = H * dh;
-    for (int d = lane; d < dh; d += 64) gs[wave][d] = dctx[(long)b * E + h * dh + d];
-    __builtin_amdgcn_wave_barrier();
-    float p = 0.f, pd = 0.f, dp = 0.f;
-    if (lane < S) {
-        p = probs[(long)bh * S + lane];
-        const float* vr = kv + ((long)lane * B + b) * ld_kv + E + h * dh;
-        float a = 0.f;
-        for (int d = 0; d < dh; d += 4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(vr + d);
-            const float4 g4 = *reinterpret_cast<const float4*>(&gs[wave][d]);
-            a += v4.x * g4.x + v4.y * g4.y + v4.z * g4.z + v4.w * g4.w;
-        }
-        dp = a;
-        pd = p;
-        if (drop_p > 0.f) {
+    __shared__ __attribute__((aligned(16))) float Ks[SMAX * TLD];
+    __shared__ __attribute__((aligned(16))) float Vs[SMAX * TLD];
+    __shared__ __attribute__((aligned(16))) float qs[DCH];
+    __shared__ __attribute__((aligned(16))) float gs[DCH];
+    __shared__ float dpv[SMAX], dss[SMAX], pds[SMAX], red[4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, E = H * dh;
+    const int nch = (dh + DCH - 1) / DCH;
+    const float pj = lane < S ? probs[(long)bh * S + lane] : 0.f;
+    // dP[j] = dctx . V[j]
+    float acc = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, dc = dh - d0 < DCH ? dh - d0 : DCH;
+        if (ch > 0) __syncthreads();
+        if (tid < DCH) gs[tid] = tid < dc ? dctx[(long)b * E + h * dh + d0 + tid] : 0.f;
+        else if (tid < 2 * DCH && nch == 1) qs[tid - DCH] = tid - DCH < dc ? q[(long)b * E + h * dh + tid - DCH] : 0.f;
+        xload_tile(Vs, kv, ld_kv, B, b, S, E + h * dh + d0, dc, tid);
+        if (nch == 1) xload_tile(Ks, kv, ld_kv, B, b, S, h * dh, dc, tid);
+        __syncthreads();
+        acc += xrow_dot(Vs, gs, tid);
+    }
+    if ((tid & 3) == 0) dpv[tid >> 2] = acc;
+    __syncthreads();
+    {   // softmax backward (every wave; wave 0 publishes): ds = p (dp - sum dp p) / sqrt(dh), pd = dropped p
+        float dp = lane < S ? dpv[lane] : 0.f, d = pj;
+        if (drop_p > 0.f && lane < S) {
             const bool keep = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)lane, drop_thr);
             const float ik = 1.f / (1.f - drop_p);
-            pd = keep ? p * ik : 0.f;
+            d = keep ? pj * ik : 0.f;
             dp = keep ? dp * ik : 0.f;
         }
+        const float ssum = wave_sum(dp * pj);
+        if (tid < 64) {
+            dss[lane] = pj * (dp - ssum) * rsqrtf((float)dh);
+            pds[lane] = d;
+        }
     }
-    const float s = wave_sum(dp * p);
-    const float ds = p * (dp - s) * rsqrtf((float)dh);
-    for (int d0 = 0; d0 < dh; d0 += 64) {  // wave-uniform trip count: __shfl needs every lane active
-        const int d = d0 + lane;
-        const bool act = d < dh;
-        const float qd = act ? q[(long)b * E + h * dh + d] : 0.f, gd = act ? gs[wave][d] : 0.f;
-        float a = 0.f;
-        for (int j = 0; j < S; ++j) {
-            const float dsj = __shfl(ds, j, 64), pdj = __shfl(pd, j, 64);
-            const long row = ((long)j * B + b);
-            if (act) {
-                a += dsj * kv[row * ld_kv + h * dh + d];
-                dkv[row * ld_dkv + h * dh + d] = dsj * qd;
-                dkv[row * ld_dkv + E + h * dh + d] = pdj * gd;
-                store_planes1(po, row * ld_dkv + h * dh + d, dsj * qd);
-                store_planes1(po, row * ld_dkv + E + h * dh + d, pdj * gd);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, dc = dh - d0 < DCH ? dh - d0 : DCH;
+        if (nch > 1) {
+            __syncthreads();
+            if (tid < DCH) gs[tid] = tid < dc ? dctx[(long)b * E + h * dh + d0 + tid] : 0.f;
+            else if (tid < 2 * DCH) qs[tid - DCH] = tid - DCH < dc ? q[(long)b * E + h * dh + d0 + tid - DCH] : 0.f;
+            xload_tile(Ks, kv, ld_kv, B, b, S, h * dh + d0, dc, tid);
+            __syncthreads();
+        }
+        const float o = xcol_sum(Ks, dss, red, tid);                 // dq = sum_j ds[j] K[j]
+        if (tid < dc) dq[(long)b * E + h * dh + d0 + tid] = o;
+        // dK[j] = ds[j] q,  dV[j] = pd[j] dctx : 16 rows x 64 columns per pass, 16-B stores
+        const int c = (tid & 15) << 2;
+        if (c < dc) {
+            const float4 q4 = *reinterpret_cast<const float4*>(qs + c), g4 = *reinterpret_cast<const float4*>(gs + c);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int j = (tid >> 4) + 16 * ps;
+                if (j >= S) continue;
+                const float dsj = dss[j], pdj = pds[j];
+                const long at = ((long)j * B + b) * ld_dkv + h * dh + d0 + c;
+                const float4 dk = make_float4(dsj * q4.x, dsj * q4.y, dsj * q4.z, dsj * q4.w);
+                const float4 dv = make_float4(pdj * g4.x, pdj * g4.y, pdj * g4.z, pdj * g4.w);
+                *reinterpret_cast<float4*>(dkv + at) = dk;
+                *reinterpret_cast<float4*>(dkv + at + E) = dv;
+                store_planes4(po, at, dk);
+                store_planes4(po, at + E, dv);
             }
         }
-        if (act) dq[(long)b * E + h * dh + d] = a;
     }
 }
 
@@ -758,7 +833,7 @@ int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S,
     SLNLP_CHECK_ARG(q && kv && ctx && probs, "attn_cross_fwd: null pointer");
     SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh, "attn_cross_fwd: ld_kv=%ld", (long)ld_kv);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_fwd: bad dropout args");
-    hipLaunchKernelGGL(attn_cross_fwd_kernel, dim3(ceil_div(B * H, 4)), dim3(256), 0, st, q, kv, (long)ld_kv, B, S, H,
+    hipLaunchKernelGGL(attn_cross_fwd_kernel, dim3(B * H), dim3(256), 0, st, q, kv, (long)ld_kv, B, S, H,
                        dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng);
     SLNLP_CHECK_LAUNCH("attn_cross_fwd");
     return 0;
@@ -769,9 +844,9 @@ int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* 
                    const unsigned long long* rng, hipStream_t st, PlaneOut po) {
     SLNLP_TRY(check_attn("attn_cross_bwd", B, S, H, dh));
     SLNLP_CHECK_ARG(q && kv && probs && dctx && dq && dkv, "attn_cross_bwd: null pointer");
-    SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh && ld_dkv >= 2L * H * dh, "attn_cross_bwd: bad ld");
+    SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh && ld_dkv >= 2L * H * dh && ld_dkv % 4 == 0, "attn_cross_bwd: bad ld");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_bwd: bad dropout args");
-    hipLaunchKernelGGL(attn_cross_bwd_kernel, dim3(ceil_div(B * H, 4)), dim3(256), 0, st, q, kv, (long)ld_kv, probs,
+    hipLaunchKernelGGL(attn_cross_bwd_kernel, dim3(B * H), dim3(256), 0, st, q, kv, (long)ld_kv, probs,
                        dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_cross_bwd");
     return 0;

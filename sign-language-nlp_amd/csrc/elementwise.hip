@@ -65,40 +65,40 @@ __global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __rest
                                                               float* __restrict__ partial, int* __restrict__ pid,
                                                               float drop_p, unsigned drop_thr, int drop_site,
                                                               const unsigned long long* __restrict__ rng) {
-    const int M = B * S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * EMB_CHUNK, mine = m0 + lane;
+    // one workgroup per token: almost all exit at once (not the first of their id in the 64-token chunk); the
+    // chunk-first of an id sums the chunk's rows of that id in increasing-m order, all 256 threads across columns
+    const int M = B * S, lane = threadIdx.x & 63;
+    const int m = blockIdx.x, m0 = (m / EMB_CHUNK) * EMB_CHUNK, t = m - m0, mine = m0 + lane;
     int my_id = -1;                        // lane l holds the id of token m0 + l (or -1)
     if (mine < M) {
         const long v = ids[(long)(mine % B) * ld_ids + (mine / B)];
         my_id = (v < 0 || v >= V) ? -1 : (int)v;
     }
     const float ik = 1.f / (1.f - drop_p);
-    for (int t = wave; t < EMB_CHUNK && m0 + t < M; t += 4) {      // wave-uniform trip count
-        const int id = __shfl(my_id, t, 64);
-        unsigned long long mask = __ballot(my_id == id && id >= 0);
-        const bool first = id >= 0 && (mask & ((1ull << t) - 1ull)) == 0ull;
-        if (lane == 0) pid[m0 + t] = first ? id : -1;
-        if (!first) continue;
-        for (int c = lane * 4; c < E; c += 256) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            unsigned long long bits = mask;
-            while (bits) {                 // 4 independent loads in flight, summed in increasing-m order
-                int k[4];
+    const int id = __shfl(my_id, t, 64);
+    const unsigned long long mask = __ballot(my_id == id && id >= 0);
+    const bool first = id >= 0 && (mask & ((1ull << t) - 1ull)) == 0ull;
+    if (threadIdx.x == 0) pid[m] = first ? id : -1;
+    if (!first) return;
+    for (int c = threadIdx.x * 4; c < E; c += 1024) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long bits = mask;
+        while (bits) {                 // 4 independent loads in flight, summed in increasing-m order
+            int k[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    k[u] = bits ? __ffsll((long long)bits) - 1 : -1;
-                    bits &= bits - 1;      // 0 & anything stays 0
-                }
-                float4 g[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+            for (int u = 0; u < 4; ++u) {
+                k[u] = bits ? __ffsll((long long)bits) - 1 : -1;
+                bits &= bits - 1;      // 0 & anything stays 0
             }
-            *reinterpret_cast<float4*>(partial + (long)(m0 + t) * E + c) = acc;
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
         }
+        *reinterpret_cast<float4*>(partial + (long)m * E + c) = acc;
     }
 }
 
@@ -187,7 +187,7 @@ int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     const int M = B * S;
     float* partial = (float*)scratch;
     int* pid = (int*)(partial + (size_t)M * E);
-    hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3(ceil_div(M, EMB_CHUNK)), dim3(256), 0, st, (const long*)ids,
+    hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3(M), dim3(256), 0, st, (const long*)ids,
                        (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng);
     SLNLP_CHECK_LAUNCH("embed_bwd_chunk");
     hipLaunchKernelGGL(embed_bwd_combine_kernel, dim3(M), dim3(256), 0, st, pid, M, E, partial, dtable, scale);
