@@ -75,6 +75,11 @@ typedef struct slnlp_gemm_args {
     const uint16_t* A_hi; const uint16_t* A_lo; int64_t lda_p;
     const uint16_t* B_hi; const uint16_t* B_lo; int64_t ldb_p;
     uint16_t* C_hi; uint16_t* C_lo; int64_t ldc_p;
+    /* > 0: the dropout of this GEMM is per (row, head) instead of per element -- element (m, n) keeps or drops
+     * with site element (m * (N / drop_head_dim) + n / drop_head_dim, 0).  That is nn.MultiheadAttention's
+     * attention-weight dropout when there is a single key (decoder self-attention, tgt length 1): the softmax
+     * weight is the scalar 1 per (row, head).  fp32-operand GEMMs only. */
+    int32_t drop_head_dim;
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);

@@ -314,11 +314,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
             if (gn >= N || gm0 >= M) continue;
             const float bias = g.bias ? g.bias[gn] : 0.f;
             uint4 bits = make_uint4(0, 0, 0, 0);
-            if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+            const bool per_head = g.drop_head_dim > 0;
+            if (g.drop_p > 0.f && !per_head) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = gm0 + r;
                 if (gm >= M) break;
+                if (g.drop_p > 0.f && per_head) {   // one keep/drop decision per (row, head), see slnlp.h
+                    const unsigned rh = (unsigned)gm * (unsigned)(N / g.drop_head_dim) + (unsigned)(gn / g.drop_head_dim);
+                    const uint4 hb = dropout_bits4(g.rng, g.drop_site, rh >> 2, 0u);
+                    const unsigned wsel = pick_word(hb, rh & 3);
+                    bits = make_uint4(wsel, wsel, wsel, wsel);
+                }
                 float v = acc[i][j][r] + bias;
                 if (g.relu == 1) v = fmaxf(v, 0.f);
                 else if (g.relu == 2) v = tanhf(v);
@@ -406,6 +413,8 @@ static int fill_params(const slnlp_gemm_args& a, GemmParams& p) {
     SLNLP_CHECK_ARG(!a.gate || a.ldg >= a.N, "gemm: ldg too small");
     SLNLP_CHECK_ARG(!a.resid || a.ldr >= a.N, "gemm: ldr too small");
     SLNLP_CHECK_ARG(!(a.a_kmajor == 0 && a.b_kmajor != 0), "gemm: layout (A m-major, B k-major) not built");
+    SLNLP_CHECK_ARG(a.drop_head_dim >= 0 && (a.drop_head_dim == 0 || a.N % a.drop_head_dim == 0),
+                    "gemm: drop_head_dim %d does not divide N %d", a.drop_head_dim, a.N);
     p.a = a;
     p.drop_thr = dropout_threshold(a.drop_p);
     p.drop_scale = 1.f / (1.f - a.drop_p);

@@ -303,6 +303,7 @@ static int check_plane_job(const slnlp_gemm_args& a) {
     SLNLP_CHECK_ARG(!a.C_hi || a.ldc_p >= a.N, "gemm_planes: ldc_p < N");
     SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "gemm_planes: bad dropout args");
     SLNLP_CHECK_ARG(!(a.a_kmajor == 0 && a.b_kmajor != 0), "gemm_planes: layout (A m-major, B k-major) not built");
+    SLNLP_CHECK_ARG(a.drop_head_dim == 0, "gemm_planes: per-head dropout is only built for fp32-operand GEMMs");
     return 0;
 }
 

@@ -355,7 +355,7 @@ struct slnlp_tf_plan {
 
     // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
     int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
-               float p, int site, const float* resid, hipStream_t st) const {
+               float p, int site, const float* resid, hipStream_t st, int drop_head_dim = 0) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = x; a.lda = K; a.a_kmajor = 1;
@@ -365,6 +365,7 @@ struct slnlp_tf_plan {
         a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
         a.resid = resid; a.ldr = ldy;
         a.precision = cfg.precision;
+        a.drop_head_dim = drop_head_dim;
         return gemm(a, st);
     }
     // dx[M,Kin] = dy[M,Nout] W[Nout,Kin]  (*gate) (+resid)
@@ -656,8 +657,8 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
         // self-attention over ONE key: softmax == 1 -> out_proj(v_proj(t)); q/k rows of in_proj are dead
-        SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, 0.f, 0, nullptr, st));
-        if (p > 0.f) SLNLP_TRY(head_dropout(a.v, B, H, dh, p, pl->dec_site(l, 0), rng, st));
+        // (train mode: the weight-1 "attention" is still dropped per (row, head) -- fused into the V projection)
+        SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, st, dh));
         SLNLP_TRY(pl->linear(a.v, B, E, pl->P(q.sout_w), E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, st));
         SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
         // cross-attention: q from tgt, k|v from memory, no masks (transformer.py:82-87)
@@ -765,9 +766,11 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
                                 pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, st));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
-        SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b)),
-                                 pl->dgrad_args(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr), st));
-        if (p > 0.f) SLNLP_TRY(head_dropout(a.gv, B, H, dh, p, pl->dec_site(l, 0), rng, st));
+        {
+            slnlp_gemm_args dg = pl->dgrad_args(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr);
+            if (p > 0.f) { dg.drop_p = p; dg.drop_site = pl->dec_site(l, 0); dg.rng = rng; dg.drop_head_dim = dh; }   // same mask as forward
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b)), dg, st));
+        }
         // softmax over one element has zero gradient: the q/k rows of in_proj (weight and bias) get exactly 0.
         // Nothing ever writes them, and the gradient arena is zeroed at plan creation, so they stay zero.
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E),

@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("resid", vp), ("ldr", i64),
                 ("rowsum_a", vp), ("precision", i32), ("gate_mode", i32),
                 ("A_hi", vp), ("A_lo", vp), ("lda_p", i64), ("B_hi", vp), ("B_lo", vp), ("ldb_p", i64),
-                ("C_hi", vp), ("C_lo", vp), ("ldc_p", i64)]
+                ("C_hi", vp), ("C_lo", vp), ("ldc_p", i64), ("drop_head_dim", i32)]
 
 
 class TfConfig(C.Structure):
