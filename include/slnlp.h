@@ -226,6 +226,9 @@ typedef struct slnlp_rnn_cell_bwd_dir {
     const float* acts; const float* cprev_save; const float* hprev_save; const float* hn_save;
     float* dgx; float* dgh; float* carry;
     int32_t t, out_row0, out_col0;
+    /* optional: dh_state arrives as a sum of partial products (the caller split the K loop of dgh W_hh over
+     * several GEMM jobs of one launch): dh = dh_state + sum_{e < n_extra} dh_extra[e * extra_stride + i] */
+    const float* dh_extra; int64_t extra_stride; int32_t n_extra;
 } slnlp_rnn_cell_bwd_dir;
 int slnlp_rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, int Hd,
                        const int64_t* lengths, int64_t ld_dout,

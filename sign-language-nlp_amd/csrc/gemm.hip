@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
 // Several independent fp32-operand GEMMs in ONE launch (e.g. the data- and weight-gradient of one dY in the
 // decoder, whose B-row GEMMs are pure launch latency): workgroups [block_begin, block_begin + gx*gy) run job j.
-constexpr int GEMM_GROUP_MAX = 4;
+constexpr int GEMM_GROUP_MAX = 8;
 struct GemmGroupParams {
     GemmParams job[GEMM_GROUP_MAX];
     int variant[GEMM_GROUP_MAX];      // (a_kmajor, b_kmajor, narrow) -> 0..5

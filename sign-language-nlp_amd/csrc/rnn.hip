@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void rnn_cell_bwd_kernel(slnlp_rnn_cell_bwd_di
         const int b = (int)(idx / Hd), j = (int)(idx % Hd);
         const bool valid = lengths ? (d.t < lengths[b]) : true;
         float dh = d.dh_state[idx];
+        for (int e = 0; e < d.n_extra; ++e) dh += d.dh_extra[e * d.extra_stride + idx];   // fixed order
         float* gx = d.dgx + (long)b * G * Hd;
         float* gh = LSTM ? gx : d.dgh + (long)b * G * Hd;
         if (!valid) {

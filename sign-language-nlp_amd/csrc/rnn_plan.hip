@@ -114,7 +114,7 @@ struct RBump {
 
 struct EncDirA {   // per (layer, direction)
     float *xproj, *acts, *hprev, *cprev, *hn, *h, *c, *hproj;
-    float *dgx, *dgh, *dh, *dc, *carry;
+    float *dgx, *dgh, *dh, *dc, *carry, *dhx;   // dhx: partial products of the K-sliced recurrent dgrad
 };
 struct EncLayerA { EncDirA d[2]; float *out, *dout; };    // out [M,2Hd]; dout = grad w.r.t. out
 struct DecLayerA {
@@ -154,6 +154,7 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
             e.dh = b.take<float>(B * Hd);
             e.dc = b.take<float>(B * Hd);
             e.carry = b.take<float>(B * Hd);
+            e.dhx = b.take<float>(3 * B * Hd);
         }
         a.out = b.take<float>(M * 2 * Hd);
         a.dout = b.take<float>(M * 2 * Hd);
@@ -225,8 +226,8 @@ struct slnlp_rnn_plan {
     float* Gd(long off) const { return buf.grads + off; }
 
     // y[M,N] = x[M,K](lda) W[N,K](ldb)^T + bias, act (0 none / 2 tanh), + resid
-    int lin(const float* x, long lda, int M, int K, const float* W, long ldb, int N, const float* bias, float* y, long ldy,
-            int act, const float* resid, hipStream_t st) const {
+    slnlp_gemm_args lin_args(const float* x, long lda, int M, int K, const float* W, long ldb, int N, const float* bias,
+                             float* y, long ldy, int act, const float* resid) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = x; a.lda = lda; a.a_kmajor = 1;
@@ -234,11 +235,15 @@ struct slnlp_rnn_plan {
         a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
         a.bias = bias; a.relu = act; a.resid = resid; a.ldr = ldy;
         a.precision = cfg.precision;
-        return gemm(a, st);
+        return a;
+    }
+    int lin(const float* x, long lda, int M, int K, const float* W, long ldb, int N, const float* bias, float* y, long ldy,
+            int act, const float* resid, hipStream_t st) const {
+        return gemm(lin_args(x, lda, M, K, W, ldb, N, bias, y, ldy, act, resid), st);
     }
     // dx[M,Kin](ldx) = dy[M,Nout](ldy) W[Nout,Kin](ldw)  (+resid, same ld as dx)
-    int dgr(const float* dy, long ldy, int M, int Nout, const float* W, long ldw, int Kin, float* dx, long ldx,
-            const float* resid, hipStream_t st) const {
+    slnlp_gemm_args dgr_args(const float* dy, long ldy, int M, int Nout, const float* W, long ldw, int Kin, float* dx,
+                             long ldx, const float* resid) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = dy; a.lda = ldy; a.a_kmajor = 1;
@@ -246,8 +251,15 @@ struct slnlp_rnn_plan {
         a.C = dx; a.ldc = ldx; a.M = M; a.N = Kin; a.K = Nout;
         a.resid = resid; a.ldr = ldx;
         a.precision = cfg.precision;
-        return gemm(a, st);
+        return a;
     }
+    int dgr(const float* dy, long ldy, int M, int Nout, const float* W, long ldw, int Kin, float* dx, long ldx,
+            const float* resid, hipStream_t st) const {
+        return gemm(dgr_args(dy, ldy, M, Nout, W, ldw, Kin, dx, ldx, resid), st);
+    }
+    // the recurrent dgrad dh(t-1) = dgh W_hh + carry contracts over the G*Hd gate columns: one K-slice per gate
+    // (each its own GEMM job, partial products summed by the next cell kernel) keeps the serial K loop at Hd
+    int kslices() const { const int G = cfg.lstm ? 4 : 3; return (cfg.Hd >= 256 && cfg.Hd % 4 == 0) ? G : 1; }
     // dW[Nout,Kin](ldw) = dy[T,Nout](ldy)^T x[T,Kin](ldx);  db = colsum(dy)
     int wgr(const float* dy, long ldy, int T, int Nout, const float* x, long ldx, int Kin, float* dW, long ldw, float* db,
             hipStream_t st) const {
@@ -354,11 +366,12 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
         const bool last = l == N - 1;
         for (int step = 0; step < S; ++step) {
             slnlp_rnn_cell_dir dirs[2];
+            slnlp_gemm_args rec[2];   // h W_hh^T of both directions: one launch
             for (int d = 0; d < 2; ++d) {
                 const int t = d == 0 ? step : S - 1 - step;
                 const RnnW& q = L.enc[d][l];
                 const EncDirA& e = a.d[d];
-                SLNLP_TRY(pl->lin(e.h, Hd, B, Hd, pl->P(q.w_hh), Hd, GH, pl->P(q.b_hh), e.hproj, GH, 0, nullptr, st));
+                rec[d] = pl->lin_args(e.h, Hd, B, Hd, pl->P(q.w_hh), Hd, GH, pl->P(q.b_hh), e.hproj, GH, 0, nullptr);
                 slnlp_rnn_cell_dir& k = dirs[d];
                 k.xproj = e.xproj + (long)t * B * GH;
                 k.hproj = e.hproj;
@@ -370,6 +383,7 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
                 k.out = a.out + (long)t * B * 2 * Hd + d * Hd;
                 k.t = t; k.out_row0 = t * B; k.out_col0 = d * Hd;
             }
+            SLNLP_TRY(gemm_group(rec, 2, st));
             // inter-layer dropout (not after the last layer); padded outputs of the LAST layer = float(pad_idx)
             SLNLP_TRY(rnn_cell_fwd(lstm, dirs, 2, B, Hd, lengths, last ? (float)c.pad_src : 0.f, 2 * Hd, last ? 0.f : p,
                                    RSITE_ENC0 + l, rng, st));
@@ -451,7 +465,7 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
         const DecLayerA& a = w.dec[l];
         if (hipMemsetAsync(a.dh, 0, bh, st) != hipSuccess || hipMemsetAsync(a.dc, 0, bh, st) != hipSuccess)
             return fail_memset();
-        slnlp_rnn_cell_bwd_dir k;
+        slnlp_rnn_cell_bwd_dir k = {};
         k.dh_state = a.dh; k.dc_state = a.dc; k.dout = a.dout; k.acts = a.acts; k.cprev_save = a.cprev;
         k.hprev_save = a.hprev; k.hn_save = a.hn; k.dgx = a.dgx; k.dgh = a.dgh; k.carry = a.carry;
         k.t = 0; k.out_row0 = 0; k.out_col0 = 0;
@@ -498,12 +512,15 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
             SLNLP_TRY(add_rows(w.denc_final + (long)l * B * 2 * Hd + d * Hd, 2 * Hd, a.d[d].dh, Hd, B, Hd, 0, st));
             if (hipMemsetAsync(a.d[d].dc, 0, bh, st) != hipSuccess) return fail_memset();
         }
+        const int nsl = pl->kslices(), Ks = GH / nsl;
         for (int step = S - 1; step >= 0; --step) {
-            slnlp_rnn_cell_bwd_dir dirs[2];
+            slnlp_rnn_cell_bwd_dir dirs[2] = {};
             for (int d = 0; d < 2; ++d) {
                 const int t = d == 0 ? step : S - 1 - step;
                 const EncDirA& e = a.d[d];
                 slnlp_rnn_cell_bwd_dir& k = dirs[d];
+                k.dh_extra = e.dhx; k.extra_stride = (int64_t)B * Hd;
+                k.n_extra = step == S - 1 ? 0 : nsl - 1;   // the first step starts from the final-state gradient only
                 k.dh_state = e.dh; k.dc_state = e.dc;
                 k.dout = a.dout + (long)t * B * 2 * Hd + d * Hd;
                 k.acts = e.acts + (long)t * B * GH;
@@ -516,10 +533,16 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
                 k.t = t; k.out_row0 = t * B; k.out_col0 = d * Hd;
             }
             SLNLP_TRY(rnn_cell_bwd(lstm, dirs, 2, B, Hd, lengths, 2 * Hd, last ? 0.f : p, RSITE_ENC0 + l, rng, st));
+            slnlp_gemm_args rec[8];
+            int nj = 0;
             for (int d = 0; d < 2; ++d) {
                 const RnnW& q = L.enc[d][l];
-                SLNLP_TRY(pl->dgr(dirs[d].dgh, GH, B, GH, pl->P(q.w_hh), Hd, Hd, a.d[d].dh, Hd, a.d[d].carry, st));
+                for (int sl = 0; sl < nsl; ++sl)
+                    rec[nj++] = pl->dgr_args(dirs[d].dgh + sl * Ks, GH, B, Ks, pl->P(q.w_hh) + (long)sl * Ks * Hd, Hd, Hd,
+                                             sl == 0 ? a.d[d].dh : a.d[d].dhx + (long)(sl - 1) * B * Hd, Hd,
+                                             sl == 0 ? a.d[d].carry : nullptr);
             }
+            SLNLP_TRY(gemm_group(rec, nj, st));
         }
         float* dx = l > 0 ? w.enc[l - 1].dout : w.demb;
         for (int d = 0; d < 2; ++d) {

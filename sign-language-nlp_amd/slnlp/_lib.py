@@ -51,7 +51,8 @@ class RnnCellDir(C.Structure):
 class RnnCellBwdDir(C.Structure):
     _fields_ = [("dh_state", vp), ("dc_state", vp), ("dout", vp), ("acts", vp), ("cprev_save", vp),
                 ("hprev_save", vp), ("hn_save", vp), ("dgx", vp), ("dgh", vp), ("carry", vp),
-                ("t", i32), ("out_row0", i32), ("out_col0", i32)]
+                ("t", i32), ("out_row0", i32), ("out_col0", i32),
+                ("dh_extra", vp), ("extra_stride", i64), ("n_extra", i32)]
 
 
 class LnReduceEntry(C.Structure):
