@@ -107,7 +107,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", type=int, default=3, choices=[1, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")
+    ap.add_argument("--eager", action="store_true", help="same as --launch eager")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,10 +142,15 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
 
+    launch = {"auto": "auto", "graph": True, "eager": False}["eager" if args.eager else args.launch]
+    from slnlp.launch import PROBE
+    if launch == "auto" and args.warmup < 2 + 2 * PROBE:
+        launch = False                       # not enough warmup steps to time both modes: plain launches
+
     def run(k0, k):
         for i in range(k0, k0 + k):
             j = (i % n_batches) * B
-            eng.step(Xd[j:j + B], yd[j:j + B], Ld[j:j + B], MOMENTUM, MAX_NORM, graph=not args.eager)
+            eng.step(Xd[j:j + B], yd[j:j + B], Ld[j:j + B], MOMENTUM, MAX_NORM, graph=launch)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -171,6 +178,11 @@ def main():
     out = None
     if rank == 0:
         seqs = world * B * args.steps
+        if launch == "auto":
+            chosen = eng._launch.mode((B, float(MOMENTUM), float(MAX_NORM)))
+            launch_used = f"{'hipGraph replay' if chosen == 'graph' else 'eager stream launches'} (auto: timed both in warmup)"
+        else:
+            launch_used = "hipGraph replay" if launch else "eager stream launches"
         step_flops = 3.0 * fwd_flops_per_seq(c) * B
         ms_event = ev_ms / args.steps           # HIP events on the launch stream, rank 0
         achieved = step_flops / (ms_event * 1e-3) / 1e12
@@ -201,10 +213,10 @@ def main():
                                     f"{args.workload}: Transformer train step E{c['E']} H{c['H']} N{c['N']} F{c['F']} ") +
                                    f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
-                       "launch": "eager" if args.eager else "hipGraph replay", "per_gpu": "independent fit (grid shard)"},
+                       "launch": launch_used, "per_gpu": "independent fit (grid shard)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": None,
-                         "launch": "one graph replay = one train step", "flops_per_launch": step_flops,
+                         "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
                          "ms_per_launch_hip_events": round(ms_event, 4)},
             "parity": parity, "final_loss": round(loss_end, 5),
         }

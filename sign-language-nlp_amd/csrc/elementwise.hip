@@ -80,25 +80,45 @@ __global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __rest
     const bool first = id >= 0 && (mask & ((1ull << t) - 1ull)) == 0ull;
     if (threadIdx.x == 0) pid[m] = first ? id : -1;
     if (!first) return;
-    for (int c = threadIdx.x * 4; c < E; c += 1024) {
+    // The matching rows are summed as a FIXED tree: wave w adds the rows at chunk positions [16w, 16w+16) in
+    // increasing order, then the four wave sums are added in wave order -- bit-reproducible, and the serial
+    // load -> add chain is a quarter as long as one running sum (the <pad> id matches ~half of every chunk).
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long wmask = mask & (0xFFFFull << (16 * wave));
+    for (int c0 = 0; c0 < E; c0 += 256) {
+        const int c = c0 + lane * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned long long bits = mask;
-        while (bits) {                 // 4 independent loads in flight, summed in increasing-m order
-            int k[4];
+        if (c < E) {
+            unsigned long long bits = wmask;
+            while (bits) {                 // 4 independent loads in flight
+                int k[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                k[u] = bits ? __ffsll((long long)bits) - 1 : -1;
-                bits &= bits - 1;      // 0 & anything stays 0
+                for (int u = 0; u < 4; ++u) {
+                    k[u] = bits ? __ffsll((long long)bits) - 1 : -1;
+                    bits &= bits - 1;      // 0 & anything stays 0
+                }
+                float4 g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
             }
-            float4 g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
         }
-        *reinterpret_cast<float4*>(partial + (long)m * E + c) = acc;
+        if (c0 > 0) __syncthreads();
+        *reinterpret_cast<float4*>(&red[wave][lane * 4]) = acc;
+        __syncthreads();
+        if (wave == 0 && c < E) {
+            float4 r = *reinterpret_cast<const float4*>(&red[0][lane * 4]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 q = *reinterpret_cast<const float4*>(&red[w][lane * 4]);
+                r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            }
+            *reinterpret_cast<float4*>(partial + (long)m * E + c) = r;
+        }
     }
 }
 
@@ -138,19 +158,37 @@ __global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __res
         __syncthreads();
     }
     const int n = nlist;
-    for (int c = tid * 4; c < E; c += 1024) {
+    // same fixed tree: wave w adds list entries [w*q, (w+1)*q), then the wave sums are added in wave order
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    const int wave = tid >> 6, lane = tid & 63, per = (n + 3) / 4;
+    const int i0 = wave * per, i1 = (i0 + per < n) ? i0 + per : n;
+    for (int c0 = 0; c0 < E; c0 += 256) {
+        const int c = c0 + lane * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < n; i += 4) {
-            float4 g[4];
+        if (c < E) {
+            for (int i = i0; i < i1; i += 4) {
+                float4 g[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                g[u] = (i + u < n) ? *reinterpret_cast<const float4*>(partial + (long)list[i + u] * E + c)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < 4; ++u)
+                    g[u] = (i + u < i1) ? *reinterpret_cast<const float4*>(partial + (long)list[i + u] * E + c)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+                for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+            }
         }
-        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
-        *reinterpret_cast<float4*>(dtable + (long)id * E + c) = acc;
+        if (c0 > 0) __syncthreads();
+        *reinterpret_cast<float4*>(&red[wave][lane * 4]) = acc;
+        __syncthreads();
+        if (wave == 0 && c < E) {
+            float4 r = *reinterpret_cast<const float4*>(&red[0][lane * 4]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 q = *reinterpret_cast<const float4*>(&red[w][lane * 4]);
+                r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            }
+            r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+            *reinterpret_cast<float4*>(dtable + (long)id * E + c) = r;
+        }
     }
 }
 

@@ -112,8 +112,11 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         const int nwg = job.tiles_x * job.tiles_y * nks;
         const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
-        tile = t / nks;
-        ks = t - tile * nks;
+        // split-major unit order: the units of one XCD share a K-slice, so its 4 MiB L2 holds that slice of a few
+        // A / B panels instead of whole panels (measured 5x over-fetch with tile-major order on the weight gradient)
+        const int ntiles = job.tiles_x * job.tiles_y;
+        ks = t / ntiles;
+        tile = t - ks * ntiles;
         by = tile / job.tiles_x;
         bx = tile - by * job.tiles_x;
     }

@@ -87,7 +87,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
     def __init__(self, module, criterion="torch.nn.CrossEntropyLoss", optimizer="torch.optim.SGD", lr=0.01,
                  max_epochs=10, batch_size=128, device="cuda", warm_start=False, verbose=0,
                  predict_nonlinearity="auto", scoring=None, labels=None, early_stopping=None,
-                 gradient_clipping=None, lr_scheduler=None, checkpoint_dir=None, train_split=5, use_graph=True,
+                 gradient_clipping=None, lr_scheduler=None, checkpoint_dir=None, train_split=5, use_graph="auto",
                  callbacks=None, dataset=None, **kwargs):
         loc = locals()
         self._params = {k: loc[k] for k in self._OWN}
@@ -250,7 +250,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             if train and self._fused:
                 eng = self.module_.engine(xb.shape[0], xb.shape[1])
                 eng.set_lr(self.lr_)
-                logp = eng.step(xb, yb, lb, momentum, max_norm, graph=bool(self.use_graph))
+                logp = eng.step(xb, yb, lb, momentum, max_norm, graph=self.use_graph if self.use_graph == "auto" else bool(self.use_graph))
                 losses.append(eng.scalars[0].clone())
             elif train:
                 self.optimizer_.zero_grad()

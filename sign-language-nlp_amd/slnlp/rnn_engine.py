@@ -6,6 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .launch import LaunchPolicy
 from ._lib import RnnConfig, TfBuffers, check, load, ptr, stream_ptr
 
 
@@ -51,6 +52,7 @@ class RnnEngine:
         check(load().slnlp_rnn_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "rnn_create")
         self.handle = handle
         self._graph_keys = {}
+        self._launch = LaunchPolicy()
         self._xbuf = self._ybuf = self._lbuf = None
 
     def __del__(self):
@@ -139,6 +141,12 @@ class RnnEngine:
     def grad_norm(self):
         return float(self.scalars[1])
 
-    def step(self, X, y, lengths, momentum=0.9, max_norm=0.5, graph=True):
-        """Uniform fused-step entry (estimator)."""
+    def step(self, X, y, lengths, momentum=0.9, max_norm=0.5, graph="auto"):
+        """Uniform fused-step entry (estimator).  graph: True / False / "auto" (see launch.py)."""
+        if graph == "auto" and stream_ptr() == 0:
+            graph = False                    # graph capture needs a non-default stream
+        if graph == "auto":
+            return self._launch.run((X.shape[0], float(momentum), float(max_norm)),
+                                    lambda: self.train_step_graph(X, y, lengths, momentum, max_norm),
+                                    lambda: self.train_step(X, y, lengths, momentum, max_norm))
         return (self.train_step_graph if graph else self.train_step)(X, y, lengths, momentum, max_norm)

@@ -10,6 +10,7 @@ import math
 import torch
 
 from . import _lib
+from .launch import LaunchPolicy
 from ._lib import TfBuffers, TfConfig, check, load, ptr, stream_ptr
 
 
@@ -75,6 +76,7 @@ class TransformerEngine:
         check(load().slnlp_tf_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "tf_create")
         self.handle = handle
         self._graph_keys = {}
+        self._launch = LaunchPolicy()
         self._xbuf = self._ybuf = None
 
     def __del__(self):
@@ -175,6 +177,13 @@ class TransformerEngine:
     def grad_norm(self):
         return float(self.scalars[1])
 
-    def step(self, X, y, lengths=None, momentum=0.9, max_norm=0.5, graph=True):
-        """Uniform fused-step entry (estimator): the Transformer ignores ``lengths`` (transformer.py:60)."""
+    def step(self, X, y, lengths=None, momentum=0.9, max_norm=0.5, graph="auto"):
+        """Uniform fused-step entry (estimator): the Transformer ignores ``lengths`` (transformer.py:60).
+        graph: True (hipGraph replay) / False (eager launches) / "auto" (time both, keep the faster; launch.py)."""
+        if graph == "auto" and stream_ptr() == 0:
+            graph = False                    # graph capture needs a non-default stream
+        if graph == "auto":
+            return self._launch.run((X.shape[0], float(momentum), float(max_norm)),
+                                    lambda: self.train_step_graph(X, y, momentum, max_norm),
+                                    lambda: self.train_step(X, y, momentum, max_norm))
         return (self.train_step_graph if graph else self.train_step)(X, y, momentum, max_norm)
