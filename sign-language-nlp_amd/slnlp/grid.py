@@ -15,6 +15,11 @@ folds for config-transformer.yaml).  Here: one process per GPU
   rank 0 refits the best candidate on the whole training set (``refit=True``).
 
 There is no per-step collective: fits are independent.
+
+``fits_per_gpu=k`` runs k of the rank's fits at a time, one host thread and one HIP stream each: a single
+batch-50 fit leaves most of the GPU idle during its decoder (tgt length 1) phases, and k = 4 fits were
+measured at 1.5x the aggregate seq/s of one (tools/bench_concurrent.py).  Every task is seeded by its index,
+so results do not depend on the world size or on k.
 """
 import itertools
 import time
@@ -79,21 +84,32 @@ def broadcast_dataset(ds, device="cpu", src=0):
                         Vocab(vy) if vy else None)
 
 
-def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_log_loss"):
+def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_log_loss", seed=None, concurrent=False):
     """sklearn ``_fit_and_score`` for one task on this rank's GPU: fresh estimator, fit on the
-    train fold, score on the test fold."""
-    from .net import ScoringWrapper
+    train fold, score on the test fold.  Module construction draws the initial weights from torch's global CPU
+    generator (like the reference's modules), so it is seeded and serialised under a lock."""
+    import torch
+    from .net import INIT_LOCK, ScoringWrapper
     net = estimator_factory().set_params(**params)
-    net.fit(train)
+    if concurrent and "use_graph" in net.get_params():
+        # hipGraph capture on one host thread makes device-wide calls of the other threads fail
+        # ("operation not permitted when stream is capturing"): concurrent fits use plain stream launches
+        net.set_params(use_graph=False)
+    with INIT_LOCK:
+        if seed is not None:
+            torch.manual_seed(seed)
+        net.initialize()
+    net.partial_fit(train)
     return float(ScoringWrapper(scoring, train.labels() if scoring == "neg_log_loss" else None)(net, test, test.y))
 
 
 class ShardedGridSearchCV:
     def __init__(self, estimator_factory, param_grid, cv=5, scoring="neg_log_loss", refit=True, fit_and_score=None,
-                 device="cpu", verbose=0):
+                 device="cpu", verbose=0, fits_per_gpu=1, seed=1):
         self.estimator_factory, self.param_grid, self.cv = estimator_factory, param_grid, cv
         self.scoring, self.refit, self.verbose, self.device = scoring, refit, verbose, device
         self.fit_and_score = fit_and_score or default_fit_and_score
+        self.fits_per_gpu, self.seed = int(fits_per_gpu), seed
 
     def fit(self, dataset):
         import torch
@@ -103,15 +119,33 @@ class ShardedGridSearchCV:
         mine = [order[i] for i in range(rank, len(order), world)]
         rows = torch.full((len(tasks), 2), float("nan"), dtype=torch.float64)
         t_start = time.time()
-        for t in mine:
+        import inspect
+        sig = inspect.signature(self.fit_and_score).parameters
+        takes_seed, takes_conc = "seed" in sig, "concurrent" in sig
+        is_cuda = str(self.device).startswith("cuda")
+
+        def run_task(t):
+            if is_cuda and torch.device(self.device).index is not None:
+                torch.cuda.set_device(torch.device(self.device))     # the current device is per host thread
             ci, fi = tasks[t]
             tr, te = folds[fi]
             t0 = time.time()
-            rows[t, 0] = self.fit_and_score(self.estimator_factory, cands[ci], ds[tr], ds[te], self.scoring)
-            rows[t, 1] = time.time() - t0
+            kw = {"seed": self.seed + t} if (takes_seed and self.seed is not None) else {}
+            if takes_conc and self.fits_per_gpu > 1:
+                kw["concurrent"] = True
+            score = self.fit_and_score(self.estimator_factory, cands[ci], ds[tr], ds[te], self.scoring, **kw)
+            rows[t, 0], rows[t, 1] = score, time.time() - t0         # each task owns its row
             if self.verbose:
                 print(f"[rank {rank}] task {t} cand {ci} fold {fi}: score {float(rows[t, 0]):.4f} ({float(rows[t, 1]):.2f}s)",
                       flush=True)
+
+        if self.fits_per_gpu > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(self.fits_per_gpu) as pool:
+                list(pool.map(run_task, mine))                       # longest-first order; re-raises a task's exception
+        else:
+            for t in mine:
+                run_task(t)
         self.local_seconds_ = time.time() - t_start
         if world > 1:                                     # each task has exactly one owner: combine by all_gather
             mine_mask = torch.zeros(len(tasks), dtype=torch.bool)

@@ -19,6 +19,7 @@ semantics:
 
 The compute path is HIP only; with no GPU ``fit`` / ``predict`` raise.
 """
+import threading
 import json
 import os
 import time
@@ -28,6 +29,10 @@ import numpy as np
 import torch
 
 from .data import TokenDataset
+
+
+# module construction consumes torch's global CPU generator (initial weights): concurrent fits take turns
+INIT_LOCK = threading.RLock()
 
 
 def _resolve(obj):

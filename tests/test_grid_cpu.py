@@ -80,3 +80,27 @@ def test_sharded_grid_world2_equals_world1():
         assert best == single.best_index_ and params == single.best_params_
     assert sorted(out[0][3] + out[1][3]) == list(range(single.n_tasks_))
     assert set(out[0][3]).isdisjoint(out[1][3])
+
+
+def test_fits_per_gpu_threads_same_results_and_seed_passed():
+    """fits_per_gpu=k: the rank's tasks run k at a time on host threads; scores, ranking and the per-task seeds
+    are the same as with k = 1."""
+    import threading
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    seen = {}
+
+    def fs(factory, params, train, test, scoring, seed=None):
+        seen.setdefault(threading.get_ident(), []).append(seed)
+        return oracle_fit_and_score(factory, params, train, test, scoring)
+
+    torch.set_num_threads(2)
+    res = []
+    for k in (1, 3):
+        seen.clear()
+        gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=fs, refit=False, fits_per_gpu=k, seed=7)
+        gs.fit(ds)
+        seeds = sorted(s for v in seen.values() for s in v)
+        assert seeds == [7 + t for t in range(gs.n_tasks_)]          # one deterministic seed per task index
+        assert len(seen) == (1 if k == 1 else min(k, gs.n_tasks_)) or k > 1
+        res.append((gs.cv_results_["mean_test_score"].tolist(), gs.best_index_))
+    assert res[0] == res[1]

@@ -115,3 +115,19 @@ def test_rnn_modules_through_the_estimator(module):
     h = net.history
     assert net._fused and h[-1]["train_loss"] < h[0]["train_loss"] - 0.05
     assert np.allclose(net.predict_proba(ds).sum(1), 1.0, atol=1e-5)
+
+
+def test_sharded_grid_concurrent_fits_equal_sequential():
+    """ShardedGridSearchCV(fits_per_gpu=2): two fits at a time on two streams give the same cv_results_ as one at
+    a time (per-task seeding; no cross-talk between plans, streams or the thread-local error state)."""
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV
+    ds = synthetic_dataset(90, seq_len=10, src_vocab=50, n_labels=3, seed=9, min_len=3)
+    factory = lambda: make_net(ds, max_epochs=2, dropout=0.1)
+    pg = {"lr": [0.1, 0.01], "module__num_layers": [1, 2]}
+    out = []
+    for k in (1, 2):
+        gs = ShardedGridSearchCV(factory, pg, cv=3, refit=False, device="cuda", fits_per_gpu=k).fit(ds)
+        out.append(gs.cv_results_["mean_test_score"])
+    print(out)
+    assert np.array_equal(out[0], out[1]) and np.isfinite(out[0]).all()
