@@ -7,7 +7,8 @@ One "step" = one full training step (forward + CrossEntropyLoss + backward +
 clip_grad_norm_(0.5) + SGD-momentum) of BASELINE.json configs[1]
 (Transformer d_model=512, 6 layers, 8 heads, dim_feedforward=512, batch=50,
 len=48, |src|=3000, |tgt|=202, dropout 0.1) on one batch of synthetic ASL-Phono
-token ids that is already resident in HBM, replayed from a captured hipGraph.
+token ids that is already resident in HBM (hipGraph replay or plain stream launches,
+whichever a short probe during warmup finds faster -- slnlp/launch.py).
 N>1: one process per GPU, each running its own independent fit (the reference's
 only parallelism is the embarrassingly parallel (candidate x fold) grid,
 SURVEY.md section 8e) -> weak scaling, no data-path collective.
@@ -69,6 +70,51 @@ def build_sd(c, seed):
     ents, _ = te.layout(cfg)
     w = synth.make_weights([(n, s) for n, s, _ in ents], seed=seed)
     return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
+
+
+def dominant_kernel_roofline(c, precision, dev):
+    """The step's dominant kernel on its own: one grouped plane-GEMM launch = data gradient + weight gradient of
+    one [B*S, E] dY against a [E, F] weight (FFN / out-proj pair of the encoder backward; 18 of them per cfg2 step
+    plus 6 larger in_proj ones = ~45 % of the step's GPU time).  Timed live with HIP events on the launch stream."""
+    from slnlp import ops
+    M, E, F = c["B"] * c["S"], c["E"], c["F"]
+    if E % 64 or F % 64:
+        return None
+    g = torch.Generator().manual_seed(0)
+    dY, X, W = [torch.randn(*sh, generator=g).to(dev) for sh in ((M, E), (M, F), (E, F))]
+    dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+    rs = torch.empty(E, device=dev)
+    jw, _ = ops.plane_job(dYp, Xp, M=E, N=F, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=precision)
+    jd, _ = ops.plane_job(dYp, Wp, M=M, N=F, K=E, a_kmajor=True, b_kmajor=False, precision=precision)
+    cd = lambda a, b: (a + b - 1) // b
+    tw, td, kw, kd = cd(E, 64) * cd(F, 64), cd(M, 64) * cd(F, 64), cd(M, 64), cd(E, 64)
+    split = min(range(1, min(8, kw) + 1), key=lambda n: cd(tw * n + td, 512) * max(cd(kw, n) + (n > 1), kd))   # tf_plan.hip wd_group
+    scr = ops.gemm_group([jw, jd], [split, 1])
+    for _ in range(20):
+        ops.gemm_group([jw, jd], [split, 1], scr)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 200
+    e0.record()
+    for _ in range(n):
+        ops.gemm_group([jw, jd], [split, 1], scr)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the 3 split-bf16 MFMA passes are not counted)
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": f"gemm_planes_kernel<{precision}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}",
+            "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "us_per_launch_hip_events": round(us, 2),
+            "flops_per_launch": flops, "note": "back-to-back launches on one stream; includes launch gaps"}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), or None."""
+    f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}_step_traffic.json")
+    try:
+        return float(json.load(open(f))["hbm_bytes_per_step"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(c, sd, X, y, Ln, budget_s=20.0):
@@ -215,11 +261,16 @@ def main():
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
                        "launch": launch_used, "per_gpu": "independent fit (grid shard)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload),
                          "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
                          "ms_per_launch_hip_events": round(ms_event, 4)},
             "parity": parity, "final_loss": round(loss_end, 5),
         }
+        if "rnn" not in c:
+            with torch.cuda.stream(stream):
+                dk = dominant_kernel_roofline(c, args.precision, dev)
+            if dk:
+                out["roofline_dominant_kernel"] = dk
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))
             out["gpu_over_cpu"] = round(out["value"] / world / out["cpu_baseline"]["value"], 1)
