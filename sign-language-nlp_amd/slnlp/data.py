@@ -54,12 +54,14 @@ class TokenDataset:
         return self[np.arange(min(n, len(self)))]
 
     def split(self, test_size=0.15, seed=1):
-        """(test, train) like ``AslDataset.split(lengths=0.15, seed)`` (asl_dataset.py:220-253): a seeded
-        random permutation, the first ``test_size`` share is the test set."""
-        rs = np.random.RandomState(seed)
-        perm = rs.permutation(len(self))
-        n_test = int(round(len(self) * test_size))
-        return self[np.sort(perm[:n_test])], self[np.sort(perm[n_test:])]
+        """(test, train) like ``AslDataset.split(lengths=0.15, seed)`` (asl_dataset.py:220-253): that is
+        ``torch.utils.data.random_split`` with ``Generator().manual_seed(seed)``, i.e. one ``torch.randperm`` whose
+        first ``round(test_size * N)`` entries are the test set and the rest the train set, both in permutation order."""
+        import torch
+        n_test = int(round(len(self) * test_size)) if isinstance(test_size, float) else int(test_size)
+        gen = torch.Generator().manual_seed(seed) if seed else None
+        perm = torch.randperm(len(self), generator=gen).numpy()
+        return self[perm[:n_test]], self[perm[n_test:]]
 
 
 def collate_data(data):

@@ -91,6 +91,8 @@ def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_l
     import torch
     from .net import INIT_LOCK, ScoringWrapper
     net = estimator_factory().set_params(**params)
+    if "checkpoint_dir" in net.get_params():
+        net.set_params(checkpoint_dir=None)      # CV fits leave no files; the refit of the best candidate does
     if concurrent and "use_graph" in net.get_params():
         # hipGraph capture on one host thread makes device-wide calls of the other threads fail
         # ("operation not permitted when stream is capturing"): concurrent fits use plain stream launches

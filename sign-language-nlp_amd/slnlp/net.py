@@ -305,7 +305,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
 
     # ------------------------------------------------------------ checkpoint
     def save_params(self, dirname):
-        """skorch ``Checkpoint`` artefacts: params.pt (state_dict), optimizer.pt, history.json."""
+        """skorch ``Checkpoint`` artefacts: params.pt (state_dict), optimizer.pt, criterion.pt, history.json."""
         os.makedirs(dirname, exist_ok=True)
         torch.save({k: v.detach().cpu() for k, v in self.module_.state_dict().items()}, os.path.join(dirname, "params.pt"))
         if self._fused:
@@ -313,6 +313,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             torch.save({"momentum_arena": bufs, "lr": self.lr_}, os.path.join(dirname, "optimizer.pt"))
         else:
             torch.save(self.optimizer_.state_dict(), os.path.join(dirname, "optimizer.pt"))
+        torch.save(self.criterion_.state_dict(), os.path.join(dirname, "criterion.pt"))
         with open(os.path.join(dirname, "history.json"), "w") as f:
             json.dump(self.history, f, indent=1)
 

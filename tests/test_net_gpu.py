@@ -131,3 +131,59 @@ def test_sharded_grid_concurrent_fits_equal_sequential():
         out.append(gs.cv_results_["mean_test_score"])
     print(out)
     assert np.array_equal(out[0], out[1]) and np.isfinite(out[0]).all()
+
+
+def test_cli_end_to_end_on_a_synthetic_corpus(tmp_path):
+    """python -m slnlp.cli: reference-style YAML -> ingest -> balancing -> split -> sharded grid search -> test metrics,
+    with the reference's artefact files in workdir."""
+    import json
+    import pandas as pd
+    from test_pipeline_cpu import FIELDS, make_corpus
+    from slnlp import cli
+    corpus = tmp_path / "corpus"
+    corpus.mkdir()
+    make_corpus(str(corpus), per_label=(8, 9, 7, 10, 8, 9))
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(f"""
+debug: False
+cuda: True
+seed: 1
+workdir: '{tmp_path}/work/{{model}}'
+verbose: 0
+cv: 2
+lr:
+scoring: [neg_log_loss, accuracy, f1_weighted]
+max_epochs: 3
+batch_size: 16
+test_size: 0.15
+early_stopping: {{patience: 30, threshold: 1e-4, threshold_mode: rel}}
+gradient_clipping: {{gradient_clip_value: 0.5}}
+lr_scheduler: {{policy: ReduceLROnPlateau, factor: 0.2, patience: 5}}
+model: model.Transformer
+model_args: {{embedding_size: , hidden_size: 32, num_layers: 1, dropout: 0.1, num_heads: 2}}
+criterion: torch.nn.CrossEntropyLoss
+optimizer: torch.optim.SGD
+optimizer_args: {{nesterov: False, momentum: 0.9}}
+grid_args:
+  lr: [0.1, 0.01]
+  model_args: {{embedding_size: [16, 32]}}
+dataset_args:
+  dataset_dir: {corpus}
+  fields: {FIELDS}
+  samples_min_freq: 2
+  composition_strategy: as_words
+  balance_dataset: True
+""")
+    cli.main(["--config", str(cfg)])
+    work = tmp_path / "work" / "model.Transformer"
+    for f in ("config.yaml", "grid_search_grid_params.csv", "grid_search_output.json", "grid_search_results.csv",
+              "test_output.json", "params.pt", "optimizer.pt", "criterion.pt", "history.json"):
+        assert (work / f).exists(), f
+    out = json.load(open(work / "grid_search_output.json"))
+    assert set(out) == {"best_score", "best_params", "best_index", "scoring"} and set(out["best_params"]) == {"lr", "module__embedding_size"}
+    res = pd.read_csv(work / "grid_search_results.csv", index_col=0)
+    assert len(res) == 4 and {"mean_test_score", "rank_test_score", "split0_test_score", "split1_test_score"} <= set(res.columns)
+    test_out = json.load(open(work / "test_output.json"))
+    assert set(test_out) == {"test_neg_log_loss", "test_accuracy", "test_f1_weighted"} and all(np.isfinite(v) for v in test_out.values())
+    hist = json.load(open(work / "history.json"))
+    assert len(hist) == 3 and {"train_f1_weighted", "valid_f1_weighted", "valid_accuracy", "lr"} <= set(hist[0])
