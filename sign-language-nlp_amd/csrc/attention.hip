@@ -1,14 +1,14 @@
 // attention.hip -- attention cores for the short (S <= 64) ASL-Phono sequences.
 //
 // Self-attention (encoder; /root/reference/model/transformer.py:68-73,82-87 ->
-// nn.MultiheadAttention slow path): one workgroup per (batch, head); the whole
-// S x S score tile lives in LDS, Q/K/V/dO are streamed through LDS in
-// head-dim chunks of <= 64 so any head_dim in {16..256} of the reference grid
-// (config-transformer.yaml:49,53) fits.  Exact fp32 arithmetic: attention is
-// ~3 % of the step's FLOPs (4SE vs 8E^2+4EF per token), the projections
-// around it run on MFMA (gemm.hip).
+// nn.MultiheadAttention slow path): one workgroup per (batch, head); the four
+// contractions of a head (Q K^T, P V and their gradients) run on MFMA in
+// split-bf16 out of bf16 LDS images, the head dim (16 .. 256 in the reference
+// grid, config-transformer.yaml:49,53) in chunks of 64; softmax, masks and
+// dropout live in the accumulator layout.
 //
-// Cross-attention (decoder, tgt length 1, no masks): one wave per (batch, head).
+// Cross-attention (decoder, tgt length 1, no masks): one workgroup per (batch, head),
+// matrix-vector products out of LDS tiles.
 #include "common.hpp"
 
 namespace slnlp {
@@ -17,233 +17,9 @@ constexpr int SMAX = 64;   // max sequence length held in one tile
 constexpr int DCH = 64;    // head-dim chunk
 constexpr int TLD = 68;    // LDS row stride (floats): 16-B aligned rows, conflict-free b128 column access
 
-// load rows [0,S) x cols [d0, d0+dc) of a [S*B, ld] token-major matrix (row m = s*B+b) into T; zero-fill the rest
-__device__ __forceinline__ void load_chunk(float* __restrict__ T, const float* __restrict__ src, long ld,
-                                           int B, int b, int S, int col0, int dc, int tid) {
-    for (int idx = tid; idx < SMAX * (DCH / 4); idx += 256) {
-        int s = idx / (DCH / 4), c = (idx % (DCH / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < S && c < dc) v = *reinterpret_cast<const float4*>(src + ((long)s * B + b) * ld + col0 + c);
-        *reinterpret_cast<float4*>(T + s * TLD + c) = v;
-    }
-}
-
-// acc[r][c] += sum_d X[ti+16r][d] * Y[tj+16c][d]
-__device__ __forceinline__ void dot_tiles(const float* __restrict__ X, const float* __restrict__ Y, int dc,
-                                          int ti, int tj, float (&acc)[4][4]) {
-    for (int d = 0; d < dc; d += 4) {
-        float4 x[4], y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const float4*>(X + (ti + 16 * r) * TLD + d);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = *reinterpret_cast<const float4*>(Y + (tj + 16 * c) * TLD + d);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[r][c] += x[r].x * y[c].x + x[r].y * y[c].y + x[r].z * y[c].z + x[r].w * y[c].w;
-    }
-}
-
-// out[r] (float4 over d = td*4..) = sum_j W[ti+16r][j] * V[j][d]      (W row-major S x S, j < Sp)
-__device__ __forceinline__ void rows_times_tile(const float* __restrict__ W, const float* __restrict__ V, int Sp,
-                                                int ti, int td, float4 (&o)[4]) {
-    for (int j = 0; j < Sp; j += 4) {
-        float4 w[4], v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const float4*>(W + (ti + 16 * r) * TLD + j);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) v[jj] = *reinterpret_cast<const float4*>(V + (j + jj) * TLD + td * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ww[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                o[r].x += ww[jj] * v[jj].x; o[r].y += ww[jj] * v[jj].y;
-                o[r].z += ww[jj] * v[jj].z; o[r].w += ww[jj] * v[jj].w;
-            }
-        }
-    }
-}
-
-// out[r] (float4 over d) = sum_i W[i][tj+16r] * X[i][d]        (transposed use of W; i < S)
-__device__ __forceinline__ void cols_times_tile(const float* __restrict__ W, const float* __restrict__ X, int S,
-                                                int tj, int td, float4 (&o)[4]) {
-    for (int i = 0; i < S; ++i) {
-        const float4 x = *reinterpret_cast<const float4*>(X + i * TLD + td * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float w = W[i * TLD + tj + 16 * r];
-            o[r].x += w * x.x; o[r].y += w * x.y; o[r].z += w * x.z; o[r].w += w * x.w;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void attn_self_fwd_kernel(
-    const float* __restrict__ qkv, const long* __restrict__ ids, long ld_ids, long pad_idx, int causal, int B,
-    int S, int H, int dh, float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr,
-    int drop_site, const unsigned long long* __restrict__ rng, PlaneOut po) {
-    __shared__ __attribute__((aligned(16))) float Qs[SMAX * TLD];
-    __shared__ __attribute__((aligned(16))) float Ks[SMAX * TLD];
-    __shared__ __attribute__((aligned(16))) float Ps[SMAX * TLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int E = H * dh, ti = tid >> 4, tj = tid & 15;
-    const long ld = 3L * E;
-    const int dc_full = dh < DCH ? dh : DCH;
-
-    float acc[4][4] = {};
-    for (int d0 = 0; d0 < dh; d0 += DCH) {
-        __syncthreads();
-        load_chunk(Qs, qkv, ld, B, b, S, h * dh + d0, dc_full, tid);
-        load_chunk(Ks, qkv, ld, B, b, S, E + h * dh + d0, dc_full, tid);
-        __syncthreads();
-        dot_tiles(Qs, Ks, dc_full, ti, tj, acc);
-    }
-    const float scale = rsqrtf((float)dh);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = ti + 16 * r, j = tj + 16 * c;
-            float v = acc[r][c] * scale;
-            bool blocked = (j >= S) || (causal && j > i);
-            if (!blocked && ids) blocked = ids[(long)b * ld_ids + j] == pad_idx;
-            Ps[i * TLD + j] = blocked ? -INFINITY : v;
-        }
-    __syncthreads();
-    // softmax: one wave per row, one key per lane (S <= 64)
-    const float inv_keep = 1.f / (1.f - drop_p);
-    for (int i = wave; i < SMAX; i += 4) {
-        float p = 0.f;
-        if (i < S) {
-            const float v = Ps[i * TLD + lane];  // -inf for lane >= S
-            const float m = wave_max(v);
-            const float e = expf(v - m);       // all-masked row: (-inf) - (-inf) = NaN, as torch
-            const float sum = wave_sum(e);
-            p = e / sum;
-            if (lane < S) {
-                const long row = ((long)b * H + h) * S + i;
-                probs[row * S + lane] = p;
-                if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)row, (unsigned)lane, drop_thr) ? p * inv_keep : 0.f;
-            } else {
-                p = 0.f;
-            }
-        }
-        Ps[i * TLD + lane] = p;
-    }
-    // ctx = P_dropped @ V, chunk by chunk
-    const int Sp = (S + 3) & ~3, td = tid & 15;
-    for (int d0 = 0; d0 < dh; d0 += DCH) {
-        __syncthreads();
-        load_chunk(Ks, qkv, ld, B, b, S, 2 * E + h * dh + d0, dc_full, tid);
-        __syncthreads();
-        float4 o[4] = {};
-        if (td * 4 < dc_full) {
-            rows_times_tile(Ps, Ks, Sp, ti, td, o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti + 16 * r;
-                if (i < S) {
-                    const long at = ((long)i * B + b) * E + h * dh + d0 + td * 4;
-                    *reinterpret_cast<float4*>(ctx + at) = o[r];
-                    store_planes4(po, at, o[r]);
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void attn_self_bwd_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dctx, int B, int S,
-    int H, int dh, float* __restrict__ dqkv, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng, PlaneOut po) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ta = smem;                 // dO chunk / Q chunk
-    float* Tb = Ta + SMAX * TLD;      // V chunk / K chunk
-    float* Tc = Tb + SMAX * TLD;      // dP scratch / dO chunk
-    float* Ps = Tc + SMAX * TLD;      // P -> dS
-    float* Pd = Ps + SMAX * TLD;      // dropped P
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int E = H * dh, ti = tid >> 4, tj = tid & 15, td = tid & 15;
-    const long ld = 3L * E;
-    const int dc_full = dh < DCH ? dh : DCH;
-    const float inv_keep = 1.f / (1.f - drop_p);
-
-    // pass 1: dPd = dO V^T
-    float acc[4][4] = {};
-    for (int d0 = 0; d0 < dh; d0 += DCH) {
-        __syncthreads();
-        load_chunk(Ta, dctx, E, B, b, S, h * dh + d0, dc_full, tid);
-        load_chunk(Tb, qkv, ld, B, b, S, 2 * E + h * dh + d0, dc_full, tid);
-        __syncthreads();
-        dot_tiles(Ta, Tb, dc_full, ti, tj, acc);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Tc[(ti + 16 * r) * TLD + tj + 16 * c] = acc[r][c];
-    __syncthreads();
-    // softmax backward per row; Ps <- dS * scale, Pd <- dropped P
-    const float scale = rsqrtf((float)dh);
-    for (int i = wave; i < SMAX; i += 4) {
-        float ds = 0.f, pd = 0.f;
-        if (i < S) {
-            const long row = ((long)b * H + h) * S + i;
-            float p = 0.f, dp = 0.f;
-            if (lane < S) {
-                p = probs[row * S + lane];
-                dp = Tc[i * TLD + lane];
-                pd = p;
-                if (drop_p > 0.f) {
-                    const bool keep = dropout_keep(rng, drop_site, (unsigned)row, (unsigned)lane, drop_thr);
-                    pd = keep ? p * inv_keep : 0.f;
-                    dp = keep ? dp * inv_keep : 0.f;
-                }
-            }
-            const float s = wave_sum(dp * p);
-            ds = p * (dp - s) * scale;
-        }
-        Ps[i * TLD + lane] = ds;
-        Pd[i * TLD + lane] = pd;
-    }
-    // pass 2: dQ = dS K, dK = dS^T Q, dV = Pd^T dO
-    const int Sp = (S + 3) & ~3;
-    for (int d0 = 0; d0 < dh; d0 += DCH) {
-        __syncthreads();
-        load_chunk(Ta, qkv, ld, B, b, S, h * dh + d0, dc_full, tid);
-        load_chunk(Tb, qkv, ld, B, b, S, E + h * dh + d0, dc_full, tid);
-        load_chunk(Tc, dctx, E, B, b, S, h * dh + d0, dc_full, tid);
-        __syncthreads();
-        if (td * 4 < dc_full) {
-            float4 dq[4] = {}, dk[4] = {}, dv[4] = {};
-            rows_times_tile(Ps, Tb, Sp, ti, td, dq);
-            cols_times_tile(Ps, Ta, S, ti, td, dk);
-            cols_times_tile(Pd, Tc, S, ti, td, dv);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti + 16 * r;
-                if (i < S) {
-                    float* dst = dqkv + ((long)i * B + b) * ld + h * dh + d0 + td * 4;
-                    *reinterpret_cast<float4*>(dst) = dq[r];
-                    *reinterpret_cast<float4*>(dst + E) = dk[r];
-                    *reinterpret_cast<float4*>(dst + 2 * E) = dv[r];
-                    const long at = dst - dqkv;
-                    store_planes4(po, at, dq[r]);
-                    store_planes4(po, at + E, dk[r]);
-                    store_planes4(po, at + 2 * E, dv[r]);
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------- MFMA self-attention ---
-// head_dim <= 64 (every Transformer config of the reference grid except E512/H4 and E1024): the four
-// 64x64x64 contractions of one (batch, head) run on v_mfma_f32_16x16x32_bf16 in split-bf16 (hi/lo, 3 passes,
-// same arithmetic as the GEMMs).  All operand tiles live in LDS as bf16 [row][col] images with a 72-element row
+// The 64x64x64 contractions of one (batch, head) run on v_mfma_f32_16x16x32_bf16 in split-bf16 (hi/lo, 3 passes,
+// same arithmetic as the GEMMs); head dims above 64 are walked in 64-wide chunks.  All operand tiles live in LDS as bf16 [row][col] images with a 72-element row
 // stride; an operand whose contraction index runs along the rows is read with ds_read_b64_tr_b16, so one image
 // serves both orientations and nothing is transposed in HBM.  Softmax / softmax-backward / dropout happen in
 // the MFMA accumulator layout (lane -> 4 consecutive rows x 1 column; a row's 64 columns sit in 16 lanes).
@@ -254,7 +30,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int ALD = 72;            // bf16 row stride: 144 B -> the 16 rows of a b128 fragment read hit 16 distinct 16-B slots
 constexpr int ATILE = SMAX * ALD;  // one plane of one tile
-constexpr int MFMA_DH = 64;        // largest head dim of the MFMA path
+constexpr int MFMA_DH = 64;        // head-dim chunk of the MFMA path
 
 // issue the loads of a [S x dh] slice (token-major rows m = s*B + b); no use of the values here (see gemm.hip)
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ src, long ld, int B, int b, int S, int col0,
@@ -346,31 +122,35 @@ __global__ __launch_bounds__(256) void attn_self_fwd_mfma_kernel(
     const int b = blockIdx.x / H, h = blockIdx.x % H, E = H * dh;
     const long ld = 3L * E;
     const int jc = lane & 15, i0 = wave * 16 + ((lane >> 4) << 2);
+    const int nch = (dh + MFMA_DH - 1) / MFMA_DH;                           // head dim in chunks of 64
 
     long idv[4] = {0, 0, 0, 0};
     if (ids) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) { const int j = 16 * n + jc; idv[n] = ids[(long)b * ld_ids + (j < S ? j : 0)]; }
     }
-    float4 rq[4], rk[4], rv[4];
-    fetch_tile(qkv, ld, B, b, S, h * dh, dh, tid, rq);
-    fetch_tile(qkv, ld, B, b, S, E + h * dh, dh, tid, rk);
-    fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh, dh, tid, rv);
-    stash_tile(TQ, S, dh, tid, rq);
-    stash_tile(TK, S, dh, tid, rk);
-    stash_tile(TV, S, dh, tid, rv);
-    __syncthreads();
-
-    // scores: rows 16w..16w+15 of Q K^T
+    // scores: rows 16w..16w+15 of Q K^T, accumulated over the head-dim chunks
     f32x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = (dh + 31) >> 5;
-    for (int kk = 0; kk < nk; ++kk) {
-        const bf16x8 ah = frag_rows(TQ, wave * 16, kk, lane), al = frag_rows(TQ + ATILE, wave * 16, kk, lane);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * MFMA_DH, dc = dh - d0 < MFMA_DH ? dh - d0 : MFMA_DH;
+        float4 rq[4], rk[4], rv[4];
+        fetch_tile(qkv, ld, B, b, S, h * dh + d0, dc, tid, rq);
+        fetch_tile(qkv, ld, B, b, S, E + h * dh + d0, dc, tid, rk);
+        if (nch == 1) fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh, dc, tid, rv);
+        if (ch > 0) __syncthreads();                                        // every wave is done with the previous chunk
+        stash_tile(TQ, S, dc, tid, rq);
+        stash_tile(TK, S, dc, tid, rk);
+        if (nch == 1) stash_tile(TV, S, dc, tid, rv);
+        __syncthreads();
+        const int nk = (dc + 31) >> 5;
+        for (int kk = 0; kk < nk; ++kk) {
+            const bf16x8 ah = frag_rows(TQ, wave * 16, kk, lane), al = frag_rows(TQ + ATILE, wave * 16, kk, lane);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            acc[n] = mfma3(ah, al, frag_rows(TK, 16 * n, kk, lane), frag_rows(TK + ATILE, 16 * n, kk, lane), acc[n]);
+            for (int n = 0; n < 4; ++n)
+                acc[n] = mfma3(ah, al, frag_rows(TK, 16 * n, kk, lane), frag_rows(TK + ATILE, 16 * n, kk, lane), acc[n]);
+        }
     }
     // softmax + dropout in the accumulator layout; P (dropped) replaces this wave's own Q rows
     const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
@@ -408,33 +188,43 @@ __global__ __launch_bounds__(256) void attn_self_fwd_mfma_kernel(
             put_planes(TQ, i * ALD + j, p);
         }
     }
-    __syncthreads();
-    // ctx = P V
-    const int nd = (dh + 15) >> 4, nkk = (S + 31) >> 5;
+    // ctx = P V, one head-dim chunk at a time
+    const int nkk = (S + 31) >> 5;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * MFMA_DH, dc = dh - d0 < MFMA_DH ? dh - d0 : MFMA_DH, nd = (dc + 15) >> 4;
+        if (nch > 1) {
+            float4 rv[4];
+            fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh + d0, dc, tid, rv);
+            __syncthreads();                                                // previous V chunk consumed
+            stash_tile(TV, S, dc, tid, rv);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < nkk; ++kk) {
-        const bf16x8 ah = frag_rows(TQ, wave * 16, kk, lane), al = frag_rows(TQ + ATILE, wave * 16, kk, lane);
+        for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < nkk; ++kk) {
+            const bf16x8 ah = frag_rows(TQ, wave * 16, kk, lane), al = frag_rows(TQ + ATILE, wave * 16, kk, lane);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TV, 16 * n, kk, lane), frag_cols(TV + ATILE, 16 * n, kk, lane), acc[n]);
-    }
+            for (int n = 0; n < 4; ++n)
+                if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TV, 16 * n, kk, lane), frag_cols(TV + ATILE, 16 * n, kk, lane), acc[n]);
+        }
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int d = 16 * n + jc;
-        if (d >= dh) continue;
+        for (int n = 0; n < 4; ++n) {
+            const int d = 16 * n + jc;
+            if (d >= dc) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + r;
-            if (i >= S) continue;
-            const long at = ((long)i * B + b) * E + h * dh + d;
-            ctx[at] = acc[n][r];
-            store_planes1(po, at, acc[n][r]);
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r;
+                if (i >= S) continue;
+                const long at = ((long)i * B + b) * E + h * dh + d0 + d;
+                ctx[at] = acc[n][r];
+                store_planes1(po, at, acc[n][r]);
+            }
         }
     }
 }
 
-// Backward.  Tiles: TQ | TK | TO (dO, later dS) | TV (V, later dropped P), hi+lo each = 73 728 B dynamic LDS.
+// Backward.  Tiles (hi+lo each): TQ | TK | TO (dO) | TV (V, later dropped P) | TS (dS; only when the head dim needs
+// more than one 64-wide chunk, else dS reuses TO): 73 728 B or 92 160 B of dynamic LDS.
 __global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
     const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dctx, int B, int S,
     int H, int dh, float* __restrict__ dqkv, float drop_p, unsigned drop_thr, int drop_site,
@@ -449,12 +239,9 @@ __global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
     const long ld = 3L * E;
     const int jc = lane & 15, i0 = wave * 16 + ((lane >> 4) << 2);
     const long prow0 = ((long)b * H + h) * S + i0;
+    const int nch = (dh + MFMA_DH - 1) / MFMA_DH;
+    unsigned short* TS = nch > 1 ? TQ + 8 * ATILE : TO;
 
-    float4 ro[4], rv[4], rq[4], rk[4];
-    fetch_tile(dctx, E, B, b, S, h * dh, dh, tid, ro);
-    fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh, dh, tid, rv);
-    fetch_tile(qkv, ld, B, b, S, h * dh, dh, tid, rq);
-    fetch_tile(qkv, ld, B, b, S, E + h * dh, dh, tid, rk);
     float pr[4][4];   // [n][r]: probs of (row i0 + r, key 16n + jc); clamped address, masked after the loads
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -464,22 +251,36 @@ __global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
             const bool ok = (i0 + r) < S && j < S;
             pr[n][r] = probs[ok ? (prow0 + r) * S + j : 0];
         }
-    stash_tile(TO, S, dh, tid, ro);
-    stash_tile(TV, S, dh, tid, rv);
-    __syncthreads();
-    // dP = dO V^T  (rows 16w..)
+    // dP = dO V^T  (rows 16w..), accumulated over the head-dim chunks
     f32x4 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = (dh + 31) >> 5;
-    for (int kk = 0; kk < nk; ++kk) {
-        const bf16x8 ah = frag_rows(TO, wave * 16, kk, lane), al = frag_rows(TO + ATILE, wave * 16, kk, lane);
+    float4 rq[4], rk[4];
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * MFMA_DH, dc = dh - d0 < MFMA_DH ? dh - d0 : MFMA_DH;
+        float4 ro[4], rv[4];
+        fetch_tile(dctx, E, B, b, S, h * dh + d0, dc, tid, ro);
+        fetch_tile(qkv, ld, B, b, S, 2 * E + h * dh + d0, dc, tid, rv);
+        if (nch == 1) {
+            fetch_tile(qkv, ld, B, b, S, h * dh, dc, tid, rq);
+            fetch_tile(qkv, ld, B, b, S, E + h * dh, dc, tid, rk);
+        }
+        if (ch > 0) __syncthreads();
+        stash_tile(TO, S, dc, tid, ro);
+        stash_tile(TV, S, dc, tid, rv);
+        __syncthreads();
+        const int nk = (dc + 31) >> 5;
+        for (int kk = 0; kk < nk; ++kk) {
+            const bf16x8 ah = frag_rows(TO, wave * 16, kk, lane), al = frag_rows(TO + ATILE, wave * 16, kk, lane);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            acc[n] = mfma3(ah, al, frag_rows(TV, 16 * n, kk, lane), frag_rows(TV + ATILE, 16 * n, kk, lane), acc[n]);
+            for (int n = 0; n < 4; ++n)
+                acc[n] = mfma3(ah, al, frag_rows(TV, 16 * n, kk, lane), frag_rows(TV + ATILE, 16 * n, kk, lane), acc[n]);
+        }
     }
-    stash_tile(TQ, S, dh, tid, rq);
-    stash_tile(TK, S, dh, tid, rk);
+    if (nch == 1) {
+        stash_tile(TQ, S, dh, tid, rq);
+        stash_tile(TK, S, dh, tid, rk);
+    }
     // softmax backward in registers: ds = p (dp - sum_j dp p) scale;  pd = dropped p
     const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
     float ds[4][4], pd[4][4];
@@ -508,60 +309,78 @@ __global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
             for (int n = 0; n < 4; ++n) ds[n][r] = pr[n][r] * (dp[n] - s) * scale;
         }
     }
-    __syncthreads();   // every wave is done with V; Q / K tiles are complete
+    __syncthreads();   // every wave is done with V (and, single chunk, Q / K tiles are complete)
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) put_planes(TV, (i0 + r) * ALD + 16 * n + jc, pd[n][r]);
-    __syncthreads();
-    const int nd = (dh + 15) >> 4, nkk = (S + 31) >> 5;
-    auto store = [&](const f32x4 (&o)[4], int part) {   // rows 16w.. of dQ (0) / dK (1) / dV (2)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int d = 16 * n + jc;
-            if (d >= dh) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + r;
-                if (i >= S) continue;
-                const long at = ((long)i * B + b) * ld + (long)part * E + h * dh + d;
-                dqkv[at] = o[n][r];
-                store_planes1(po, at, o[n][r]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            put_planes(TV, (i0 + r) * ALD + 16 * n + jc, pd[n][r]);
+            if (nch > 1) put_planes(TS, (i0 + r) * ALD + 16 * n + jc, ds[n][r]);
         }
-    };
-    // dV = Pd^T dO   (rows = keys 16w..; contraction over s)
+    const int nkk = (S + 31) >> 5;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * MFMA_DH, dc = dh - d0 < MFMA_DH ? dh - d0 : MFMA_DH, nd = (dc + 15) >> 4;
+        auto store = [&](const f32x4 (&o)[4], int part) {   // rows 16w.. of dQ (0) / dK (1) / dV (2), this chunk's columns
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < nkk; ++kk) {
-        const bf16x8 ah = frag_cols(TV, wave * 16, kk, lane), al = frag_cols(TV + ATILE, wave * 16, kk, lane);
+            for (int n = 0; n < 4; ++n) {
+                const int d = 16 * n + jc;
+                if (d >= dc) continue;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TO, 16 * n, kk, lane), frag_cols(TO + ATILE, 16 * n, kk, lane), acc[n]);
-    }
-    store(acc, 2);
-    __syncthreads();   // every wave is done with dO
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) put_planes(TO, (i0 + r) * ALD + 16 * n + jc, ds[n][r]);
-    __syncthreads();
-    // dQ = dS K  (rows 16w.., contraction over keys);  dK = dS^T Q  (rows = keys 16w.., contraction over s)
-    f32x4 acq[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acq[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int kk = 0; kk < nkk; ++kk) {
-        const bf16x8 qh = frag_rows(TO, wave * 16, kk, lane), ql = frag_rows(TO + ATILE, wave * 16, kk, lane);
-        const bf16x8 kh = frag_cols(TO, wave * 16, kk, lane), kl = frag_cols(TO + ATILE, wave * 16, kk, lane);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            if (n < nd) {
-                acq[n] = mfma3(qh, ql, frag_cols(TK, 16 * n, kk, lane), frag_cols(TK + ATILE, 16 * n, kk, lane), acq[n]);
-                acc[n] = mfma3(kh, kl, frag_cols(TQ, 16 * n, kk, lane), frag_cols(TQ + ATILE, 16 * n, kk, lane), acc[n]);
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r;
+                    if (i >= S) continue;
+                    const long at = ((long)i * B + b) * ld + (long)part * E + h * dh + d0 + d;
+                    dqkv[at] = o[n][r];
+                    store_planes1(po, at, o[n][r]);
+                }
             }
+        };
+        if (nch > 1) {   // this chunk's dO, Q, K columns
+            float4 ro[4];
+            fetch_tile(dctx, E, B, b, S, h * dh + d0, dc, tid, ro);
+            fetch_tile(qkv, ld, B, b, S, h * dh + d0, dc, tid, rq);
+            fetch_tile(qkv, ld, B, b, S, E + h * dh + d0, dc, tid, rk);
+            __syncthreads();                                // previous chunk's tiles consumed
+            stash_tile(TO, S, dc, tid, ro);
+            stash_tile(TQ, S, dc, tid, rq);
+            stash_tile(TK, S, dc, tid, rk);
+        }
+        __syncthreads();
+        // dV = Pd^T dO   (rows = keys 16w..; contraction over s)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < nkk; ++kk) {
+            const bf16x8 ah = frag_cols(TV, wave * 16, kk, lane), al = frag_cols(TV + ATILE, wave * 16, kk, lane);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TO, 16 * n, kk, lane), frag_cols(TO + ATILE, 16 * n, kk, lane), acc[n]);
+        }
+        store(acc, 2);
+        if (nch == 1) {   // dS takes dO's tile
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put_planes(TS, (i0 + r) * ALD + 16 * n + jc, ds[n][r]);
+            __syncthreads();
+        }
+        // dQ = dS K  (rows 16w.., contraction over keys);  dK = dS^T Q  (rows = keys 16w.., contraction over s)
+        f32x4 acq[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; acq[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kk = 0; kk < nkk; ++kk) {
+            const bf16x8 qh = frag_rows(TS, wave * 16, kk, lane), ql = frag_rows(TS + ATILE, wave * 16, kk, lane);
+            const bf16x8 kh = frag_cols(TS, wave * 16, kk, lane), kl = frag_cols(TS + ATILE, wave * 16, kk, lane);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < nd) {
+                    acq[n] = mfma3(qh, ql, frag_cols(TK, 16 * n, kk, lane), frag_cols(TK + ATILE, 16 * n, kk, lane), acq[n]);
+                    acc[n] = mfma3(kh, kl, frag_cols(TQ, 16 * n, kk, lane), frag_cols(TQ + ATILE, 16 * n, kk, lane), acc[n]);
+                }
+        }
+        store(acq, 0);
+        store(acc, 1);
     }
-    store(acq, 0);
-    store(acc, 1);
 }
 
 // ------------------------------------------------------------------ cross ---
@@ -762,18 +581,12 @@ int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site,
     return 0;
 }
 
-constexpr size_t ATTN_BWD_LDS = 5 * SMAX * TLD * sizeof(float);  // 87 040 B of dynamic LDS (> 64 KiB default cap)
-constexpr size_t ATTN_BWD_MFMA_LDS = 8 * ATILE * sizeof(unsigned short);  // 73 728 B
+constexpr size_t ATTN_BWD_MFMA_LDS = 10 * ATILE * sizeof(unsigned short);  // up to 92 160 B (head dim > 64)
 
 // one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
 int attn_init() {
     static int state = 0;  // 0 = not yet, 1 = ok
     if (state == 1) return 0;
-    if (hipFuncSetAttribute((const void*)attn_self_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)ATTN_BWD_LDS) != hipSuccess) {
-        set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
-        return SLNLP_ERR_LAUNCH;
-    }
     if (hipFuncSetAttribute((const void*)attn_self_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)ATTN_BWD_MFMA_LDS) != hipSuccess) {
         set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
@@ -798,14 +611,8 @@ int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t 
     SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
-    if (dh <= MFMA_DH)
-        hipLaunchKernelGGL(attn_self_fwd_mfma_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids,
-                           (long)ld_ids, (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p,
-                           dropout_threshold(drop_p), drop_site, rng, po);
-    else
-        hipLaunchKernelGGL(attn_self_fwd_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
-                           (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p),
-                           drop_site, rng, po);
+    hipLaunchKernelGGL(attn_self_fwd_mfma_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
+                       (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_self_fwd");
     return 0;
 }
@@ -815,14 +622,10 @@ int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B
     SLNLP_TRY(check_attn("attn_self_bwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && probs && dctx && dqkv, "attn_self_bwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
-    const size_t lds = ATTN_BWD_LDS;
     SLNLP_TRY(attn_init());
-    if (dh <= MFMA_DH)
-        hipLaunchKernelGGL(attn_self_bwd_mfma_kernel, dim3(B * H), dim3(256), ATTN_BWD_MFMA_LDS, st, qkv, probs, dctx,
-                           B, S, H, dh, dqkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
-    else
-        hipLaunchKernelGGL(attn_self_bwd_kernel, dim3(B * H), dim3(256), lds, st, qkv, probs, dctx, B, S, H, dh, dqkv,
-                           drop_p, dropout_threshold(drop_p), drop_site, rng, po);
+    hipLaunchKernelGGL(attn_self_bwd_mfma_kernel, dim3(B * H), dim3(256),
+                       (dh <= MFMA_DH ? 8 : 10) * ATILE * sizeof(unsigned short), st, qkv, probs, dctx, B, S, H, dh, dqkv,
+                       drop_p, dropout_threshold(drop_p), drop_site, rng, po);
     SLNLP_CHECK_LAUNCH("attn_self_bwd");
     return 0;
 }

@@ -133,7 +133,7 @@ def test_attn_self(ops, B, S, H, dh, p):
     ctx_ref.backward(dctx.double())
     qc = qkv.detach().float().cuda()
     ctx, probs = ops.attn_self_fwd(qc, ids.cuda(), 1, B=B, S=S, H=H, dh=dh, causal=True, drop_p=p, drop_site=17, rng=rng)
-    # head_dim <= 64 runs on split-bf16 MFMA (3 passes, ~2^-16 per product), larger heads on the fp32 VALU kernel
+    # split-bf16 MFMA (3 passes, ~2^-16 per product); head dims above 64 in chunks of 64
     e_p, e_c = rel(probs, pr_ref), rel(ctx, ctx_ref)
     dqkv = ops.attn_self_bwd(qc, probs, dctx.cuda(), B=B, S=S, H=H, dh=dh, drop_p=p, drop_site=17, rng=rng)
     e_g = rel(dqkv, qkv.grad)
