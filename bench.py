@@ -197,14 +197,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only compute path")
+    ndev = torch.cuda.device_count()
+    shared = world > ndev                      # rehearsal on a box with fewer GPUs than ranks: ranks share GPUs, gloo barrier
+    dev_index = local_rank % ndev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path is the only compute path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if shared:
+            dist.init_process_group("gloo")    # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from slnlp import synth, tf_engine as te
     c = dict(WORKLOADS[args.workload], precision=args.precision)
@@ -253,7 +259,7 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
     loss_end = eng.loss
     if world > 1:
-        t = torch.tensor([wall], device=dev)
+        t = torch.tensor([wall], device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t)
 
@@ -295,7 +301,7 @@ def main():
                                     f"{args.workload}: Transformer train step E{c['E']} H{c['H']} N{c['N']} F{c['F']} ") +
                                    f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
-                       "launch": launch_used, "per_gpu": "independent fit (grid shard)"},
+                       "launch": launch_used, "per_gpu": "independent fit (grid shard)" + (f"; REHEARSAL: {world} ranks share {ndev} GPU(s)" if shared else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload),
                          "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
