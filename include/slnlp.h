@@ -216,6 +216,26 @@ typedef struct slnlp_rnn_cell_dir {
 int slnlp_rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int Hd,
                        const int64_t* lengths, float fill, int64_t ld_out,
                        float drop_p, int drop_site, const unsigned long long* rng, void* stream);
+/* Fused forward timestep: the recurrent GEMM h_{t-1} W_hh^T (+ b_hh) and the cell above in ONE launch (results are
+ * bit-identical to slnlp_gemm + slnlp_rnn_cell_fwd).  The new state is written to h_out, which must not alias h_in
+ * (workgroups of the same launch still read h_{t-1}): callers chain the per-timestep `hprev` slots, so h_in doubles as
+ * the saved h_{t-1} of this step. */
+typedef struct slnlp_rnn_step_dir {
+    const float* h_in;       /* [B, Hd] state before the step (= what backward needs as h_{t-1}) */
+    float* h_out;            /* [B, Hd] state after the step */
+    const float* w_hh;       /* [G*Hd, Hd] */
+    const float* b_hh;       /* [G*Hd] or NULL */
+    const float* xproj;      /* [B, G*Hd] of this timestep (x W_ih^T + b_ih) */
+    float* c;                /* LSTM: [B, Hd] running cell state, updated in place */
+    float* cprev_save;       /* LSTM */
+    float* acts;             /* [B, G*Hd] */
+    float* hn_save;          /* GRU */
+    float* out;              /* layer output rows of this timestep (row stride ld_out), or NULL */
+    int32_t t, out_row0, out_col0;
+} slnlp_rnn_step_dir;
+int slnlp_rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd,
+                       const int64_t* lengths, float fill, int64_t ld_out,
+                       float drop_p, int drop_site, const unsigned long long* rng, int precision, void* stream);
 /* Backward of one timestep: consumes the running d(state) and d(out), emits the gate
  * gradients dgx (w.r.t. xproj) / dgh (w.r.t. hproj; LSTM: same buffer as dgx) and
  * `carry`, the part of dh that bypasses the recurrent matmul; the caller forms

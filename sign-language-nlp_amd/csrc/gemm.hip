@@ -472,7 +472,186 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
     return SLNLP_OK;
 }
 
+// ------------------------------------------------------------- fused recurrent step ---
+// One forward timestep of an LSTM / GRU layer (up to two directions) in ONE launch: the recurrent GEMM
+// h_{t-1} W_hh^T and the point-wise cell (rnn.hip rnn_cell_fwd_kernel) that consumes it.  A workgroup owns 16 hidden
+// units: it computes their G gate pre-activations for all B rows (G B-tiles of 16 weight rows, one shared A tile per
+// K-step, same split-bf16 K order as gemm_tile, so results are bit-identical to GEMM + cell) and applies the cell in
+// the accumulator layout -- every lane holds all G gates of its (row, unit) pairs.  The new state goes to a DIFFERENT
+// buffer than the one read (other workgroups still read h_{t-1}): the caller chains the per-timestep `hprev` slots.
+struct RnnStepParams {
+    slnlp_rnn_step_dir d[2];
+    int B, Hd;
+    const long* lengths;
+    float fill;
+    long ld_out;
+    float drop_p;
+    unsigned drop_thr;
+    int drop_site;
+    const unsigned long long* rng;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int NSPLIT, bool LSTM, bool EDGE>
+__global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P) {
+    constexpr int G = LSTM ? 4 : 3;
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    using TA = TileIO<true, BM>;
+    using TB = TileIO<true, 16>;
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP * TA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[G * NP * TB::PLANE];
+    const slnlp_rnn_step_dir& d = P.d[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = P.B, Hd = P.Hd, j0 = blockIdx.x * 16, bm0 = blockIdx.z * BM;
+    const int K = Hd, ktiles = (K + BKT - 1) / BKT;
+
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra0[TA::NV], ra1[TA::NV], rb0[G][TB::NV], rb1[G][TB::NV];
+    auto fetch = [&](int kt, float4 (&ra)[TA::NV], float4 (&rb)[G][TB::NV]) {
+        TA::template fetch<true>(d.h_in, Hd, bm0, B, kt * BKT, K, tid, ra);
+#pragma unroll
+        for (int g = 0; g < G; ++g) TB::template fetch<true>(d.w_hh + (long)g * Hd * Hd, Hd, j0, Hd, kt * BKT, K, tid, rb[g]);
+    };
+    auto stash = [&](int kt, const float4 (&ra)[TA::NV], const float4 (&rb)[G][TB::NV]) {
+        // EDGE = false (Hd % 64 == 0): no masks at all -- rows >= B hold a clamped row's data and only feed accumulator
+        // rows that are never stored
+        TA::template stash<NSPLIT, EDGE>(As, tid, ra, bm0, B, kt * BKT, K);
+#pragma unroll
+        for (int g = 0; g < G; ++g) TB::template stash<NSPLIT, EDGE>(Bs + g * NP * TB::PLANE, tid, rb[g], j0, Hd, kt * BKT, K);
+    };
+    auto consume = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 ah = TA::frag(As, wave * 16, kk, lane);
+            bf16x8 al = ah;
+            if (NSPLIT == 3) al = TA::frag(As + TA::PLANE, wave * 16, kk, lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned short* bt = Bs + g * NP * TB::PLANE;
+                const bf16x8 bh = TB::frag(bt, 0, kk, lane);
+                if (NSPLIT == 3) {
+                    const bf16x8 bl = TB::frag(bt + TB::PLANE, 0, kk, lane);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[g], 0, 0, 0);
+                }
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[g], 0, 0, 0);
+            }
+        }
+    };
+    // the cell's own operands are requested first, so their latency hides behind the K loop
+    const int j = j0 + (lane & 15), jj = j < Hd ? j : 0;
+    float bh[G], xpv[4][G], hpv[4], cpv[4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bh[g] = d.b_hh ? d.b_hh[g * Hd + jj] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = bm0 + wave * 16 + ((lane >> 4) << 2) + r, bb = b < B ? b : 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) xpv[r][g] = d.xproj[(long)bb * G * Hd + g * Hd + jj];
+        hpv[r] = d.h_in[(long)bb * Hd + jj];
+        cpv[r] = LSTM ? d.c[(long)bb * Hd + jj] : 0.f;
+    }
+    fetch(0, ra0, rb0);
+    fetch(1, ra1, rb1);
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        lds_barrier();
+        stash(kt, ra0, rb0);
+        lds_barrier();
+        fetch(kt + 2, ra0, rb0);
+        consume();
+        if (kt + 1 >= ktiles) break;
+        lds_barrier();
+        stash(kt + 1, ra1, rb1);
+        lds_barrier();
+        fetch(kt + 3, ra1, rb1);
+        consume();
+    }
+
+    // ---- cell (same arithmetic and order as rnn_cell_fwd_kernel)
+    if (j >= Hd) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = bm0 + wave * 16 + ((lane >> 4) << 2) + r;
+        if (b >= B) break;
+        const long idx = (long)b * Hd + j;
+        const bool valid = P.lengths ? (d.t < P.lengths[b]) : true;
+        float* a = d.acts + (long)b * G * Hd;
+        const float hprev = hpv[r];
+        float hnew;
+        if (LSTM) {
+            const float cprev = cpv[r];
+            const float gi = sigm(xpv[r][0] + (acc[0][r] + bh[0]));
+            const float gf = sigm(xpv[r][1] + (acc[1][r] + bh[1]));
+            const float gg = tanhf(xpv[r][2] + (acc[2][r] + bh[2]));
+            const float go = sigm(xpv[r][3] + (acc[3][r] + bh[3]));
+            const float cnew = gf * cprev + gi * gg;
+            hnew = go * tanhf(cnew);
+            a[j] = gi; a[Hd + j] = gf; a[2 * Hd + j] = gg; a[3 * Hd + j] = go;
+            d.cprev_save[idx] = cprev;
+            d.c[idx] = valid ? cnew : cprev;
+        } else {
+            const float hn = acc[2][r] + bh[2];
+            const float rr = sigm(xpv[r][0] + (acc[0][r] + bh[0]));
+            const float z = sigm(xpv[r][1] + (acc[1][r] + bh[1]));
+            const float nn = tanhf(xpv[r][2] + rr * hn);
+            hnew = (1.f - z) * nn + z * hprev;
+            a[j] = rr; a[Hd + j] = z; a[2 * Hd + j] = nn;
+            d.hn_save[idx] = hn;
+        }
+        d.h_out[idx] = valid ? hnew : hprev;
+        if (d.out) {
+            float o = valid ? hnew : P.fill;
+            if (P.drop_p > 0.f && valid)
+                o = dropout_keep(P.rng, P.drop_site, (unsigned)(d.out_row0 + b), (unsigned)(d.out_col0 + j), P.drop_thr)
+                        ? o / (1.f - P.drop_p) : 0.f;
+            d.out[(long)b * P.ld_out + j] = o;
+        }
+    }
+}
+
+int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, float fill,
+                 int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, int precision, hipStream_t st) {
+    SLNLP_CHECK_ARG(dirs && (ndir == 1 || ndir == 2) && B > 0 && Hd > 0 && Hd % 4 == 0, "rnn_step_fwd: bad args (Hd %% 4 == 0)");
+    SLNLP_CHECK_ARG(precision == 1 || precision == 3, "rnn_step_fwd: precision must be 1 or 3");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "rnn_step_fwd: bad dropout args");
+    RnnStepParams P;
+    for (int k = 0; k < ndir; ++k) {
+        const slnlp_rnn_step_dir& d = dirs[k];
+        SLNLP_CHECK_ARG(d.h_in && d.h_out && d.h_in != d.h_out && d.w_hh && d.xproj && d.acts &&
+                            (lstm ? (d.c && d.cprev_save) : (d.hn_save != nullptr)),
+                        "rnn_step_fwd: null pointer (or h_in == h_out) in direction %d", k);
+        SLNLP_CHECK_ARG(vec_ok(d.h_in, Hd) && vec_ok(d.w_hh, Hd), "rnn_step_fwd: h_in / w_hh must be 16-byte aligned");
+        P.d[k] = d;
+    }
+    if (ndir == 1) P.d[1] = P.d[0];
+    P.B = B; P.Hd = Hd; P.lengths = (const long*)lengths; P.fill = fill; P.ld_out = ld_out;
+    P.drop_p = drop_p; P.drop_thr = dropout_threshold(drop_p); P.drop_site = drop_site; P.rng = rng;
+    const dim3 grid(ceil_div(Hd, 16), ndir, ceil_div(B, BM));
+    const bool edge = (Hd % BKT) != 0;
+#define SLNLP_STEP(NS, L, E) hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E>), grid, dim3(256), 0, st, P)
+    if (precision == 3) {
+        if (lstm) { if (edge) SLNLP_STEP(3, true, true); else SLNLP_STEP(3, true, false); }
+        else { if (edge) SLNLP_STEP(3, false, true); else SLNLP_STEP(3, false, false); }
+    } else {
+        if (lstm) { if (edge) SLNLP_STEP(1, true, true); else SLNLP_STEP(1, true, false); }
+        else { if (edge) SLNLP_STEP(1, false, true); else SLNLP_STEP(1, false, false); }
+    }
+#undef SLNLP_STEP
+    SLNLP_CHECK_LAUNCH("rnn_step_fwd");
+    return SLNLP_OK;
+}
+
 }  // namespace slnlp
+
+extern "C" int slnlp_rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
+                                  float fill, int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng,
+                                  int precision, void* stream) {
+    return slnlp::rnn_step_fwd(lstm, dirs, ndir, B, Hd, lengths, fill, ld_out, drop_p, drop_site, rng, precision,
+                               (hipStream_t)stream);
+}
 
 extern "C" int slnlp_gemm(const slnlp_gemm_args* args, void* stream) {
     if (!args) {

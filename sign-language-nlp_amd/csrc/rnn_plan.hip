@@ -359,34 +359,35 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
         for (int d = 0; d < 2; ++d) {
             const RnnW& q = L.enc[d][l];
             SLNLP_TRY(pl->lin(x_in, in, M, in, pl->P(q.w_ih), in, GH, pl->P(q.b_ih), a.d[d].xproj, GH, 0, nullptr, st));
-            if (hipMemsetAsync(a.d[d].h, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess ||
+            // the state chain lives in the per-timestep `hprev` slots: slot of the first processed timestep = h_0 = 0
+            const int t0 = d == 0 ? 0 : S - 1;
+            if (hipMemsetAsync(a.d[d].hprev + (long)t0 * B * Hd, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess ||
                 hipMemsetAsync(a.d[d].c, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess)
                 return fail_memset();
         }
         const bool last = l == N - 1;
         for (int step = 0; step < S; ++step) {
-            slnlp_rnn_cell_dir dirs[2];
-            slnlp_gemm_args rec[2];   // h W_hh^T of both directions: one launch
+            // one launch per timestep: recurrent GEMM of both directions + the cell (gemm.hip rnn_step_fwd_kernel)
+            slnlp_rnn_step_dir dirs[2];
             for (int d = 0; d < 2; ++d) {
-                const int t = d == 0 ? step : S - 1 - step;
+                const int t = d == 0 ? step : S - 1 - step, tn = d == 0 ? t + 1 : t - 1;
                 const RnnW& q = L.enc[d][l];
                 const EncDirA& e = a.d[d];
-                rec[d] = pl->lin_args(e.h, Hd, B, Hd, pl->P(q.w_hh), Hd, GH, pl->P(q.b_hh), e.hproj, GH, 0, nullptr);
-                slnlp_rnn_cell_dir& k = dirs[d];
+                slnlp_rnn_step_dir& k = dirs[d];
+                k.h_in = e.hprev + (long)t * B * Hd;
+                k.h_out = step + 1 < S ? e.hprev + (long)tn * B * Hd : e.h;
+                k.w_hh = pl->P(q.w_hh); k.b_hh = pl->P(q.b_hh);
                 k.xproj = e.xproj + (long)t * B * GH;
-                k.hproj = e.hproj;
-                k.h = e.h; k.c = e.c;
-                k.hprev_save = e.hprev + (long)t * B * Hd;
+                k.c = e.c;
                 k.cprev_save = e.cprev + (long)t * B * Hd;
                 k.acts = e.acts + (long)t * B * GH;
                 k.hn_save = e.hn + (long)t * B * Hd;
                 k.out = a.out + (long)t * B * 2 * Hd + d * Hd;
                 k.t = t; k.out_row0 = t * B; k.out_col0 = d * Hd;
             }
-            SLNLP_TRY(gemm_group(rec, 2, st));
             // inter-layer dropout (not after the last layer); padded outputs of the LAST layer = float(pad_idx)
-            SLNLP_TRY(rnn_cell_fwd(lstm, dirs, 2, B, Hd, lengths, last ? (float)c.pad_src : 0.f, 2 * Hd, last ? 0.f : p,
-                                   RSITE_ENC0 + l, rng, st));
+            SLNLP_TRY(rnn_step_fwd(lstm, dirs, 2, B, Hd, lengths, last ? (float)c.pad_src : 0.f, 2 * Hd, last ? 0.f : p,
+                                   RSITE_ENC0 + l, rng, c.precision, st));
         }
         // final states -> hidden[l] = fwd || bwd   (concatenate_directions, bkp.py:155-159)
         for (int d = 0; d < 2; ++d)

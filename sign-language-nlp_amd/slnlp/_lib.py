@@ -48,6 +48,11 @@ class RnnCellDir(C.Structure):
                 ("acts", vp), ("hn_save", vp), ("out", vp), ("t", i32), ("out_row0", i32), ("out_col0", i32)]
 
 
+class RnnStepDir(C.Structure):
+    _fields_ = [("h_in", vp), ("h_out", vp), ("w_hh", vp), ("b_hh", vp), ("xproj", vp), ("c", vp), ("cprev_save", vp),
+                ("acts", vp), ("hn_save", vp), ("out", vp), ("t", i32), ("out_row0", i32), ("out_col0", i32)]
+
+
 class RnnCellBwdDir(C.Structure):
     _fields_ = [("dh_state", vp), ("dc_state", vp), ("dout", vp), ("acts", vp), ("cprev_save", vp),
                 ("hprev_save", vp), ("hn_save", vp), ("dgx", vp), ("dgh", vp), ("carry", vp),
@@ -83,6 +88,7 @@ SIGNATURES = {
     "slnlp_clip_sgd_step": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp]),
     "slnlp_dropout_mask": (i32, [vp, i32, i32, f32, i32, vp, vp]),
     "slnlp_rnn_cell_fwd": (i32, [i32, C.POINTER(RnnCellDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, vp]),
+    "slnlp_rnn_step_fwd": (i32, [i32, C.POINTER(RnnStepDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, i32, vp]),
     "slnlp_rnn_cell_bwd": (i32, [i32, C.POINTER(RnnCellBwdDir), i32, i32, i32, vp, i64, f32, i32, vp, vp]),
     "slnlp_bahdanau_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]),
     "slnlp_bahdanau_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

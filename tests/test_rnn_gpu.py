@@ -137,3 +137,45 @@ def test_dropout_path_vs_oracle_with_same_masks(rnn_type):
         scale = float(go.abs().max())
         e = float((gv[k] - go).abs().max()) / max(scale, 1e-12) if scale > 0 else float(gv[k].abs().max())
         assert e < 2e-3, f"{k}: grad err {e:.2e}"
+
+
+@pytest.mark.parametrize("lstm", [1, 0])
+@pytest.mark.parametrize("B,Hd", [(50, 512), (7, 40), (70, 64)])
+def test_fused_step_equals_gemm_plus_cell(lstm, B, Hd):
+    """slnlp_rnn_step_fwd (recurrent GEMM + cell in one launch) against slnlp_gemm + slnlp_rnn_cell_fwd on the same
+    inputs: identical split-bf16 K order -> bit-identical state, gate activations and (dropped, length-masked) outputs."""
+    import ctypes as C
+    from slnlp import ops
+    from slnlp._lib import RnnCellDir, RnnStepDir, check, load, ptr, stream_ptr
+    G = 4 if lstm else 3
+    g = torch.Generator().manual_seed(B + Hd + lstm)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+    h, c, W, bh, xp = rnd(B, Hd) * 0.5, rnd(B, Hd) * 0.5, rnd(G * Hd, Hd) * 0.05, rnd(G * Hd) * 0.1, rnd(B, G * Hd)
+    lengths = torch.randint(1, 6, (B,), generator=g).cuda()
+    rng = ops.make_rng(seed=3, step=1)
+    t, p, site, fill, ld_out = 2, 0.2, 40, 1.0, 2 * Hd
+
+    def buffers():
+        return dict(acts=torch.zeros(B, G * Hd).cuda(), cprev=torch.zeros(B, Hd).cuda(), hn=torch.zeros(B, Hd).cuda(),
+                    out=torch.zeros(B, ld_out).cuda(), c=c.clone())
+    # reference: GEMM then cell
+    r = buffers()
+    hproj = ops.gemm(h, W, M=B, N=G * Hd, K=Hd, bias=bh)
+    h_ref, hprev_ref = h.clone(), torch.zeros(B, Hd).cuda()
+    d = RnnCellDir(ptr(xp), ptr(hproj), ptr(h_ref), ptr(r["c"]), ptr(hprev_ref), ptr(r["cprev"]), ptr(r["acts"]), ptr(r["hn"]),
+                   ptr(r["out"]), t, t * B, Hd)
+    check(load().slnlp_rnn_cell_fwd(lstm, C.byref(d), 1, B, Hd, ptr(lengths), fill, ld_out, p, site, ptr(rng), stream_ptr()), "cell")
+    # fused
+    f = buffers()
+    h_out = torch.zeros(B, Hd).cuda()
+    s = RnnStepDir(ptr(h), ptr(h_out), ptr(W), ptr(bh), ptr(xp), ptr(f["c"]), ptr(f["cprev"]), ptr(f["acts"]), ptr(f["hn"]),
+                   ptr(f["out"]), t, t * B, Hd)
+    check(load().slnlp_rnn_step_fwd(lstm, C.byref(s), 1, B, Hd, ptr(lengths), fill, ld_out, p, site, ptr(rng), 3, stream_ptr()), "step")
+    torch.cuda.synchronize()
+    assert torch.equal(h_out, h_ref) and torch.equal(hprev_ref, h)
+    assert torch.equal(f["acts"], r["acts"]) and torch.equal(f["out"], r["out"])
+    if lstm:
+        assert torch.equal(f["c"], r["c"]) and torch.equal(f["cprev"], r["cprev"])
+    else:
+        assert torch.equal(f["hn"], r["hn"])
+    assert (lengths <= t).any() and (lengths > t).any()          # both masked and live rows were exercised
