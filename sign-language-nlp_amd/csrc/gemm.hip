@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P
         float* a = d.acts + (long)b * G * Hd;
         const float hprev = hpv[r];
         float hnew;
-        if (LSTM) {
+        if constexpr (LSTM) {
             const float cprev = cpv[r];
             const float gi = sigm(xpv[r][0] + (acc[0][r] + bh[0]));
             const float gf = sigm(xpv[r][1] + (acc[1][r] + bh[1]));
