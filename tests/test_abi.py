@@ -85,3 +85,11 @@ def test_product_path_fails_loudly_without_gpu():
         ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4), M=4, N=4, K=4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         te.TransformerEngine(te.make_config(32, 4, 2, 64, 64, 16, 4, 12))
+
+
+def test_bench_flop_contract():
+    """bench.py prices a step with SURVEY.md section 8d's algorithmic-FLOP formula (forward per sequence; x3 for training)."""
+    import bench
+    f = {k: bench.fwd_flops_per_seq(bench.WORKLOADS[k]) for k in ("cfg1", "cfg2", "e1024", "cfg5")}
+    assert abs(f["cfg1"] / 3.46e7 - 1) < 0.01 and abs(f["cfg2"] / 1.26e9 - 1) < 0.01
+    assert abs(f["e1024"] / 4.37e9 - 1) < 0.01 and abs(f["cfg5"] / 5.83e9 - 1) < 0.01

@@ -26,7 +26,7 @@ def test_masks_and_pe():
         assert np.array_equal(got, ref), f"pe{E} not bit-identical"
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "e1024"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "e1024", "cfg5"])
 def test_transformer_forward(name):
     g, c, sd, X, L, y = gold.tf_case(name)
     taps = {}

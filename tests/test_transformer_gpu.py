@@ -28,7 +28,7 @@ def make_engine(c, sd, dropout=0.0, precision=3, B=None, seed=0):
     return eng
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "e1024"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "e1024", "cfg5"])
 def test_forward_vs_golden(name):
     g, c, sd, X, L, y = gold.tf_case(name)
     eng = make_engine(c, sd)

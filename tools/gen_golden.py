@@ -31,6 +31,8 @@ TF_CASES = {
     "cfg1": dict(Vs=3000, Vt=202, E=128, H=4, N=2, F=256, B=50, S=48, min_len=8, steps=5),
     "cfg2": dict(Vs=3000, Vt=202, E=512, H=8, N=6, F=512, B=50, S=48, min_len=8, steps=1),
     "e1024": dict(Vs=3000, Vt=202, E=1024, H=4, N=2, F=128, B=50, S=48, min_len=8, steps=0),
+    # BASELINE.json configs[4] shape (d_model 1024, 6 layers, batch 256, len 64; F = grid max 512, fp32 reference weights)
+    "cfg5": dict(Vs=3000, Vt=202, E=1024, H=8, N=6, F=512, B=256, S=64, min_len=8, steps=0),
 }
 RNN_CASES = {
     "tiny": dict(Vs=64, Vt=16, E=24, Hd=32, N=2, B=4, S=12, min_len=3, steps=5),
@@ -203,14 +205,18 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     model = import_reference_model()
     torch.set_num_threads(8)
-    gen_masks_pe(model)
+    only = set(sys.argv[1:])                     # e.g. `gen_golden.py tf_cfg5`: regenerate just those fixtures
+    if not only:
+        gen_masks_pe(model)
     for name, c in TF_CASES.items():
-        gen_transformer(model, name, c)
+        if not only or f"tf_{name}" in only:
+            gen_transformer(model, name, c)
     for rnn_type in ("lstm", "gru"):
         for name, c in RNN_CASES.items():
             if name == "cfg3" and rnn_type == "gru":
                 continue
-            gen_rnn(model, rnn_type, name, c)
+            if not only or f"rnn_{rnn_type}_{name}" in only:
+                gen_rnn(model, rnn_type, name, c)
 
 
 if __name__ == "__main__":
