@@ -557,30 +557,6 @@ __global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
     }
 }
 
-// Decoder self-attention with a single key: softmax == 1, but in train mode
-// nn.MultiheadAttention still applies dropout to that weight, i.e. each
-// (row, head) slice of the value projection is scaled by keep/(1-p).
-// Site tensor is [rows*H, 1].  Self-inverse in backward (same mask on dv).
-__global__ void head_dropout_kernel(float* __restrict__ x, int rows, int H, int dh, float ik, unsigned thr, int site,
-                                    const unsigned long long* __restrict__ rng) {
-    const long total = (long)rows * H * dh;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const unsigned rh = (unsigned)(i / dh);
-        x[i] = dropout_keep(rng, site, rh, 0u, thr) ? x[i] * ik : 0.f;
-    }
-}
-
-int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site, const unsigned long long* rng,
-                 hipStream_t st) {
-    SLNLP_CHECK_ARG(x && rng && rows > 0 && H > 0 && dh > 0 && drop_p > 0.f && drop_p < 1.f, "head_dropout: bad args");
-    int grid = ceil_div((long)rows * H * dh, 256);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(head_dropout_kernel, dim3(grid), dim3(256), 0, st, x, rows, H, dh, 1.f / (1.f - drop_p),
-                       dropout_threshold(drop_p), drop_site, rng);
-    SLNLP_CHECK_LAUNCH("head_dropout");
-    return 0;
-}
-
 constexpr size_t ATTN_BWD_MFMA_LDS = 10 * ATILE * sizeof(unsigned short);  // up to 92 160 B (head dim > 64)
 
 // one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture

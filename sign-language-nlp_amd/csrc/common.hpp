@@ -162,8 +162,6 @@ int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S,
 int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
                    int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
                    const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
-int head_dropout(float* x, int rows, int H, int dh, float drop_p, int drop_site, const unsigned long long* rng,
-                 hipStream_t st);
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                   float* stats, hipStream_t st, PlaneOut po = {});
 int ln_bwd_blocks(int rows);

@@ -113,7 +113,7 @@ struct RBump {
 };
 
 struct EncDirA {   // per (layer, direction)
-    float *xproj, *acts, *hprev, *cprev, *hn, *h, *c, *hproj;
+    float *xproj, *acts, *hprev, *cprev, *hn, *h, *c;
     float *dgx, *dgh, *dh, *dc, *carry, *dhx;   // dhx: partial products of the K-sliced recurrent dgrad
 };
 struct EncLayerA { EncDirA d[2]; float *out, *dout; };    // out [M,2Hd]; dout = grad w.r.t. out
@@ -148,7 +148,6 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
             e.hn = b.take<float>(M * Hd);
             e.h = b.take<float>(B * Hd);
             e.c = b.take<float>(B * Hd);
-            e.hproj = b.take<float>(B * G * Hd);
             e.dgx = b.take<float>(M * G * Hd);
             e.dgh = c.lstm ? e.dgx : b.take<float>(M * G * Hd);
             e.dh = b.take<float>(B * Hd);

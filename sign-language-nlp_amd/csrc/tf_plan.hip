@@ -300,7 +300,7 @@ using namespace slnlp;
 // dropout site ids
 enum { SITE_SRC_EMB = 1, SITE_TGT_EMB = 2, SITE_LAYER0 = 16, SITE_PER_LAYER = 8 };
 
-constexpr int NSIDE = 3;
+constexpr int NSIDE = 2;
 
 struct slnlp_tf_plan {
     slnlp_tf_config cfg;
@@ -317,10 +317,10 @@ struct slnlp_tf_plan {
     // gradients, the scalar loss) is forked off the dependent chain with events and joined before the
     // optimizer.  A single B=50 fit cannot fill 256 CUs with one kernel at a time; under stream
     // capture the forks become parallel branches of the hipGraph.
-    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
+    hipStream_t side[NSIDE] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_kv;
-    bool side_dirty[NSIDE] = {false, false, false};
+    bool side_dirty[NSIDE] = {false, false};
     bool use_planes = false;   // E, F multiples of 64: M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
     int planes_B = -1;         // batch size the activation planes' zero padding is valid for
 
@@ -678,8 +678,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     side_dirty[0] = false;  // every ev_kv has been waited for: side[0] is joined
     SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
     SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
-    // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70); the
-    // scalar-loss reduction is off the dependent chain (side[1])
+    // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70)
     SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp,
                       w.row_nll, st, nullptr));
     if (logp_out &&
@@ -708,7 +707,7 @@ int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
 int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
-    hipStream_t s0 = pl->side[0], s2 = pl->side[2];
+    hipStream_t s0 = pl->side[0], s1 = pl->side[1];
     const slnlp_tf_config& c = pl->cfg;
     const Ws& w = pl->w;
     const Layout& L = pl->L;
@@ -720,7 +719,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     int nb;
     // Everything runs on the main stream; the weight gradient of each dY shares a launch with its data gradient.
     // Only the (large, independent) d memory / K|V weight-gradient groups go to side[0] and the target-embedding
-    // gradient to side[2]: graph replay places parallel branches on its own queues and every cross-queue edge
+    // gradient to side[1]: graph replay places parallel branches on its own queues and every cross-queue edge
     // costs 4-10 us, so fine-grained forks were measured slower than no forks.
 
     // generator: logits = tfin lin_w^T + lin_b
@@ -777,8 +776,8 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                  pl->dgrad_args(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1), st));
         dt = a.gt0;
     }
-    SLNLP_TRY(pl->fork(st, 2));
-    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s2));
+    SLNLP_TRY(pl->fork(st, 1));
+    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s1));
 
     // encoder: needs the complete d memory
     SLNLP_TRY(pl->join(st, 0));
