@@ -144,6 +144,31 @@ def concurrent_fits(c, precision, dev, k=4, steps=40):
             "ms_per_round": round(dt / steps * 1e3, 3), "note": f"{k} independent fits, {steps} steps each, one stream per fit"}
 
 
+def grid_folds_per_hour(dev, fits_per_gpu=4):
+    """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
+    on a bounded sample -- 6 candidates x cv 2 = 12 fits of 10 epochs over 2000 synthetic samples
+    (batch 50, len 48, |src| 3000, 200 labels), run by ShardedGridSearchCV the way a rank runs its shard."""
+    import warnings
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV
+    from slnlp.net import NeuralNetClassifier
+    warnings.filterwarnings("ignore", message="enable_nested_tensor")        # torch modules built only to draw the initial weights
+    warnings.filterwarnings("ignore", message="The least populated class")    # 1000 samples over 200 labels
+    ds = synthetic_dataset(2000, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8)
+    factory = lambda: NeuralNetClassifier(
+        module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
+        module__embedding_size=128, module__num_heads=4, module__num_layers=2, module__hidden_size=256, module__dropout=0.1,
+        criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=10, batch_size=50,
+        device=str(dev), gradient_clipping={"gradient_clip_value": 0.5})
+    grid = {"lr": [0.1, 0.01, 0.001], "module__embedding_size": [128, 512]}
+    t0 = time.perf_counter()
+    gs = ShardedGridSearchCV(factory, grid, cv=2, refit=False, device=str(dev), fits_per_gpu=fits_per_gpu).fit(ds)
+    dt = time.perf_counter() - t0
+    return {"value": round(gs.n_tasks_ / dt * 3600.0, 0), "unit": "folds/hr", "fits": gs.n_tasks_, "seconds": round(dt, 2),
+            "fits_per_gpu": fits_per_gpu,
+            "sample": "6 candidates (lr x embedding_size) x cv 2, 10 epochs, 2000 samples; E128/E512 N2 H4 F256"}
+
+
 def pmc_traffic(workload):
     """HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), or None."""
     f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}_step_traffic.json")
@@ -315,6 +340,7 @@ def main():
                 out["roofline_dominant_kernel"] = dk
             if world == 1 and not args.no_cpu_baseline:
                 out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
+                out["grid"] = grid_folds_per_hour(dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))
             out["gpu_over_cpu"] = round(out["value"] / world / out["cpu_baseline"]["value"], 1)
