@@ -236,6 +236,33 @@ typedef struct slnlp_rnn_step_dir {
 int slnlp_rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd,
                        const int64_t* lengths, float fill, int64_t ld_out,
                        float drop_p, int drop_site, const unsigned long long* rng, int precision, void* stream);
+/* Persistent forward of ALL S timesteps of one (bi)directional layer in ONE launch: each workgroup keeps its slice
+ * of W_hh in LDS for the whole sequence and the Hd/16 x ndir co-resident workgroups meet at a device-wide barrier
+ * between timesteps (results bit-identical to S calls of slnlp_rnn_step_fwd).  Covered shapes: B <= 64,
+ * Hd % 64 == 0, G * Hd * 64 bytes + 16 KiB of LDS <= 156 KiB (LSTM: Hd <= 512); otherwise *launched = 0 and nothing
+ * was done -- use the per-timestep entry point.  The per-timestep arrays are indexed by time t; `hprev` is the state
+ * chain: slot t holds the state BEFORE time t is processed (slot of the first processed timestep: zeros, set by the
+ * caller), the last state goes to h_final.  sync: 3 device words {barrier count, barrier generation, error flag},
+ * zero before the first use; a non-zero error flag afterwards means a workgroup gave up waiting (bounded spin) and
+ * the results are invalid.  Do not run more such launches concurrently than fit the GPU (one workgroup per CU). */
+typedef struct slnlp_rnn_layer_dir {
+    float* hprev;            /* [S][B, Hd] state chain (input slot zeroed by the caller; the rest is written) */
+    float* h_final;          /* [B, Hd] */
+    const float* w_hh;       /* [G*Hd, Hd] */
+    const float* b_hh;       /* [G*Hd] or NULL */
+    const float* xproj;      /* [S][B, G*Hd] */
+    float* c;                /* LSTM: [B, Hd] running cell state (zeroed by the caller), updated in place */
+    float* cprev;            /* LSTM: [S][B, Hd] */
+    float* acts;             /* [S][B, G*Hd] */
+    float* hn;               /* GRU: [S][B, Hd] */
+    float* out;              /* layer output [S*B, ld_out] at column out_col0, or NULL */
+    int32_t out_col0;
+    int32_t reverse;         /* 0: t = 0..S-1, 1: t = S-1..0 */
+} slnlp_rnn_layer_dir;
+int slnlp_rnn_layer_fwd(int lstm, const slnlp_rnn_layer_dir* dirs, int ndir, int B, int Hd, int S,
+                        const int64_t* lengths, float fill, int64_t ld_out,
+                        float drop_p, int drop_site, const unsigned long long* rng, int precision,
+                        uint32_t* sync, int* launched, void* stream);
 /* Backward of one timestep: consumes the running d(state) and d(out), emits the gate
  * gradients dgx (w.r.t. xproj) / dgh (w.r.t. hproj; LSTM: same buffer as dgx) and
  * `carry`, the part of dh that bypasses the recurrent matmul; the caller forms
@@ -350,6 +377,13 @@ void slnlp_rnn_destroy(slnlp_rnn_plan* plan);
 /* X int64 [B,S], y int64 [B] (only the criterion reads it: the decoder consumes <bos>), lengths int64 [B] */
 int slnlp_rnn_forward(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, const int64_t* lengths, int B,
                       int train, float* logp, void* stream);
+/* on = 1: run each encoder layer's S timesteps as ONE persistent launch (slnlp_rnn_layer_fwd) instead of one launch
+ * per timestep.  Default 0: measured no faster in round 1, and its Hd/16 x 2 workgroups must all be resident at
+ * once, so never enable it when several fits share the GPU. */
+int slnlp_rnn_set_persistent(slnlp_rnn_plan* plan, int on);
+/* *status = 0 when every device-wide barrier of the plan's persistent kernels completed, 1 if a workgroup timed out
+ * (bounded spin; that step's results are invalid).  Synchronises the device. */
+int slnlp_rnn_health(slnlp_rnn_plan* plan, int* status);
 int slnlp_rnn_seed_dlogp(slnlp_rnn_plan* plan, const float* dlogp, void* stream);
 int slnlp_rnn_backward(slnlp_rnn_plan* plan, void* stream);
 int slnlp_rnn_optim(slnlp_rnn_plan* plan, float momentum, float max_norm, void* stream);

@@ -178,6 +178,10 @@ int rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int 
                  int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
 int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, float fill,
                  int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, int precision, hipStream_t st);
+int rnn_layer_init();
+int rnn_layer_fwd(int lstm, const slnlp_rnn_layer_dir* dirs, int ndir, int B, int Hd, int S, const int64_t* lengths,
+                  float fill, int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, int precision,
+                  unsigned* bar, int* err, int* launched, hipStream_t st);
 int rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
                  int64_t ld_dout, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
 int bahdanau_fwd(const float* q, const float* pk, const float* val, const float* we, const int64_t* ids,

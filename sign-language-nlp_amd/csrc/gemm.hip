@@ -644,7 +644,249 @@ int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int 
     return SLNLP_OK;
 }
 
+// ------------------------------------------------------- persistent recurrent layer ---
+// ALL S timesteps of one bidirectional LSTM / GRU layer in ONE launch.  The per-timestep kernel above is ~5 us of
+// launch latency plus a K loop that re-reads and re-converts the same W_hh slice 48 times; here a workgroup keeps its
+// slice of W_hh (the G x 16 rows of its 16 hidden units, all K) in LDS as bf16 hi/lo for the whole sequence
+// (128 KiB at Hd = 512) and only streams h_{t-1} per step.  The Hd/16 x ndir co-resident workgroups meet at a
+// device-wide barrier between steps (sense-reversing counter, agent-scope atomics, bounded spin: 1.35 us for 64
+// workgroups, tools/micro/grid_barrier.hip); the new state is written with sc1 (write-through) stores and drained
+// before the barrier, and every h slot is written once and read only afterwards, so no workgroup can see a stale
+// L1 / L2 line -- no fences (an agent-scope fence is a whole-L2 write-back on this part).
+// Same K order and split as rnn_step_fwd_kernel -> bit-identical results.
+// Measured (round 1): 13.9 us per timestep, no faster than the per-timestep launches (13.4 us) -- with one wave per SIMD
+// the K loop (convert h_{t-1}, two block barriers per K tile, LDS fragment reads exposed in front of every MFMA group)
+// costs ~8 us, and h_{t-1} arrives from the memory side.  It is therefore OPT-IN (slnlp_rnn_set_persistent); the plan
+// for it: 8 waves (two per SIMD, gates split over wave pairs) and the state exchanged as bf16 planes via LDS-DMA.
+struct RnnLayerParams {
+    slnlp_rnn_layer_dir d[2];
+    int B, Hd, S;
+    const long* lengths;
+    float fill;
+    long ld_out;
+    float drop_p;
+    unsigned drop_thr;
+    int drop_site;
+    const unsigned long long* rng;
+    unsigned* bar;      // {count, generation}
+    int* err;
+};
+
+__device__ __forceinline__ void grid_barrier_sr(unsigned* bar, int* err, unsigned nblocks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's sc1 stores have reached the memory side
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the reset lands before anyone is released
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            long spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 4000000) { *err = 1; break; }     // never hang: flag the step as invalid and move on
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int NSPLIT, bool LSTM>
+__global__ __launch_bounds__(256) void rnn_layer_fwd_kernel(const RnnLayerParams P) {
+    constexpr int G = LSTM ? 4 : 3;
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    using TA = TileIO<true, BM>;
+    using TB = TileIO<true, 16>;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lsm[];
+    const slnlp_rnn_layer_dir& d = P.d[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = P.B, Hd = P.Hd, S = P.S, j0 = blockIdx.x * 16, GH = G * Hd;
+    const int K = Hd, ktiles = K / BKT;                          // host guarantees Hd % 64 == 0, B <= 64
+    unsigned short* Wl = lsm;                                    // [ktile][gate][plane][16 x 64]
+    unsigned short* As = lsm + (size_t)ktiles * G * NP * TB::PLANE;
+    const unsigned nblocks = gridDim.x * gridDim.y;
+
+    // ---- resident weight slice: rows g*Hd + j0 .. +15 of W_hh, every K tile, split once
+    for (int kt = 0; kt < ktiles; ++kt)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float4 rw[TB::NV];
+            TB::template fetch<true>(d.w_hh + (long)g * Hd * Hd, Hd, j0, Hd, kt * BKT, K, tid, rw);
+            TB::template stash<NSPLIT, false>(Wl + ((size_t)kt * G + g) * NP * TB::PLANE, tid, rw, j0, Hd, kt * BKT, K);
+        }
+    const int j = j0 + (lane & 15);
+    float bh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bh[g] = d.b_hh ? d.b_hh[g * Hd + j] : 0.f;
+    const bool rev = d.reverse != 0;
+
+    for (int step = 0; step < S; ++step) {
+        const int t = rev ? S - 1 - step : step, tn = rev ? t - 1 : t + 1;
+        const float* h_in = d.hprev + (long)t * B * Hd;
+        float* h_out = step + 1 < S ? d.hprev + (long)tn * B * Hd : d.h_final;
+        const float* xproj = d.xproj + (long)t * B * GH;
+        // the cell's own operands first: their latency hides behind the K loop
+        float xpv[4][G], hpv[4], cpv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = wave * 16 + ((lane >> 4) << 2) + r, bb = b < B ? b : 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) xpv[r][g] = xproj[(long)bb * GH + g * Hd + j];
+            hpv[r] = h_in[(long)bb * Hd + j];
+            cpv[r] = LSTM ? d.c[(long)bb * Hd + j] : 0.f;
+        }
+        f32x4 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 ra0[TA::NV], ra1[TA::NV];
+        TA::template fetch<true>(h_in, Hd, 0, B, 0, K, tid, ra0);
+        TA::template fetch<true>(h_in, Hd, 0, B, BKT, K, tid, ra1);
+        auto consume = [&](int kt) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 ah = TA::frag(As, wave * 16, kk, lane);
+                bf16x8 al = ah;
+                if (NSPLIT == 3) al = TA::frag(As + TA::PLANE, wave * 16, kk, lane);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const unsigned short* bt = Wl + ((size_t)kt * G + g) * NP * TB::PLANE;
+                    const bf16x8 bhf = TB::frag(bt, 0, kk, lane);
+                    if (NSPLIT == 3) {
+                        const bf16x8 blf = TB::frag(bt + TB::PLANE, 0, kk, lane);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[g], 0, 0, 0);
+                    }
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[g], 0, 0, 0);
+                }
+            }
+        };
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            lds_barrier();
+            TA::template stash<NSPLIT, false>(As, tid, ra0, 0, B, kt * BKT, K);
+            lds_barrier();
+            TA::template fetch<true>(h_in, Hd, 0, B, (kt + 2) * BKT, K, tid, ra0);
+            consume(kt);
+            if (kt + 1 >= ktiles) break;
+            lds_barrier();
+            TA::template stash<NSPLIT, false>(As, tid, ra1, 0, B, (kt + 1) * BKT, K);
+            lds_barrier();
+            TA::template fetch<true>(h_in, Hd, 0, B, (kt + 3) * BKT, K, tid, ra1);
+            consume(kt + 1);
+        }
+        // ---- cell (same arithmetic and order as rnn_cell_fwd_kernel)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = wave * 16 + ((lane >> 4) << 2) + r;
+            if (b >= B) break;
+            const long idx = (long)b * Hd + j;
+            const bool valid = P.lengths ? (t < P.lengths[b]) : true;
+            float* a = d.acts + (long)t * B * GH + (long)b * GH;
+            const float hprev = hpv[r];
+            float hnew;
+            if constexpr (LSTM) {
+                const float cprev = cpv[r];
+                const float gi = sigm(xpv[r][0] + (acc[0][r] + bh[0]));
+                const float gf = sigm(xpv[r][1] + (acc[1][r] + bh[1]));
+                const float gg = tanhf(xpv[r][2] + (acc[2][r] + bh[2]));
+                const float go = sigm(xpv[r][3] + (acc[3][r] + bh[3]));
+                const float cnew = gf * cprev + gi * gg;
+                hnew = go * tanhf(cnew);
+                a[j] = gi; a[Hd + j] = gf; a[2 * Hd + j] = gg; a[3 * Hd + j] = go;
+                d.cprev[(long)t * B * Hd + idx] = cprev;
+                d.c[idx] = valid ? cnew : cprev;
+            } else {
+                const float hn = acc[2][r] + bh[2];
+                const float rr = sigm(xpv[r][0] + (acc[0][r] + bh[0]));
+                const float z = sigm(xpv[r][1] + (acc[1][r] + bh[1]));
+                const float nn = tanhf(xpv[r][2] + rr * hn);
+                hnew = (1.f - z) * nn + z * hprev;
+                a[j] = rr; a[Hd + j] = z; a[2 * Hd + j] = nn;
+                d.hn[(long)t * B * Hd + idx] = hn;
+            }
+            // the next step's workgroups (other XCDs) read this: write-through store
+            __hip_atomic_store(h_out + idx, valid ? hnew : hprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d.out) {
+                float o = valid ? hnew : P.fill;
+                if (P.drop_p > 0.f && valid)
+                    o = dropout_keep(P.rng, P.drop_site, (unsigned)(t * B + b), (unsigned)(d.out_col0 + j), P.drop_thr)
+                            ? o / (1.f - P.drop_p) : 0.f;
+                d.out[((long)t * B + b) * P.ld_out + j] = o;
+            }
+        }
+        if (step + 1 < S) grid_barrier_sr(P.bar, P.err, nblocks);
+    }
+}
+
+// one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
+int rnn_layer_init() {
+    static bool done = false;
+    if (done) return 0;
+    const int lim = 156 * 1024;
+    const bool ok =
+        hipFuncSetAttribute((const void*)rnn_layer_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess &&
+        hipFuncSetAttribute((const void*)rnn_layer_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess &&
+        hipFuncSetAttribute((const void*)rnn_layer_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess &&
+        hipFuncSetAttribute((const void*)rnn_layer_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+    if (!ok) {
+        set_error("rnn_layer_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    done = true;
+    return 0;
+}
+
+static size_t rnn_layer_lds(int G, int Hd, int precision) {
+    const int NP = precision == 3 ? 2 : 1;
+    return ((size_t)(Hd / BKT) * G * NP * TileIO<true, 16>::PLANE + (size_t)NP * TileIO<true, BM>::PLANE) * sizeof(unsigned short);
+}
+
+// 0 = launched; 1 = shape not covered by the persistent kernel (caller uses the per-timestep path)
+int rnn_layer_fwd(int lstm, const slnlp_rnn_layer_dir* dirs, int ndir, int B, int Hd, int S, const int64_t* lengths,
+                  float fill, int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, int precision,
+                  unsigned* bar, int* err, int* launched, hipStream_t st) {
+    SLNLP_CHECK_ARG(dirs && (ndir == 1 || ndir == 2) && B > 0 && Hd > 0 && S > 0 && bar && err && launched, "rnn_layer_fwd: bad args");
+    SLNLP_CHECK_ARG(precision == 1 || precision == 3, "rnn_layer_fwd: precision must be 1 or 3");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "rnn_layer_fwd: bad dropout args");
+    const int G = lstm ? 4 : 3;
+    const size_t lds = rnn_layer_lds(G, Hd, precision);
+    *launched = 0;
+    if (B > BM || Hd % BKT != 0 || lds > 156 * 1024 || (Hd / 16) * ndir > 128) return SLNLP_OK;   // not covered
+    RnnLayerParams P;
+    for (int k = 0; k < ndir; ++k) {
+        const slnlp_rnn_layer_dir& d = dirs[k];
+        SLNLP_CHECK_ARG(d.hprev && d.h_final && d.w_hh && d.xproj && d.acts && (lstm ? (d.c && d.cprev) : (d.hn != nullptr)),
+                        "rnn_layer_fwd: null pointer in direction %d", k);
+        SLNLP_CHECK_ARG(vec_ok(d.hprev, Hd) && vec_ok(d.w_hh, Hd) && ((long)B * Hd) % 4 == 0, "rnn_layer_fwd: hprev / w_hh must be 16-byte aligned");
+        P.d[k] = d;
+    }
+    if (ndir == 1) P.d[1] = P.d[0];
+    P.B = B; P.Hd = Hd; P.S = S; P.lengths = (const long*)lengths; P.fill = fill; P.ld_out = ld_out;
+    P.drop_p = drop_p; P.drop_thr = dropout_threshold(drop_p); P.drop_site = drop_site; P.rng = rng;
+    P.bar = bar; P.err = err;
+    const dim3 grid(Hd / 16, ndir);
+    SLNLP_TRY(rnn_layer_init());
+#define SLNLP_LAYER(NS, L) hipLaunchKernelGGL((rnn_layer_fwd_kernel<NS, L>), grid, dim3(256), lds, st, P)
+    if (precision == 3) { if (lstm) SLNLP_LAYER(3, true); else SLNLP_LAYER(3, false); }
+    else { if (lstm) SLNLP_LAYER(1, true); else SLNLP_LAYER(1, false); }
+#undef SLNLP_LAYER
+    SLNLP_CHECK_LAUNCH("rnn_layer_fwd");
+    *launched = 1;
+    return SLNLP_OK;
+}
+
 }  // namespace slnlp
+
+extern "C" int slnlp_rnn_layer_fwd(int lstm, const slnlp_rnn_layer_dir* dirs, int ndir, int B, int Hd, int S,
+                                   const int64_t* lengths, float fill, int64_t ld_out, float drop_p, int drop_site,
+                                   const unsigned long long* rng, int precision, uint32_t* sync, int* launched, void* stream) {
+    if (!sync) {
+        slnlp::set_error("slnlp_rnn_layer_fwd: sync words required");
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    return slnlp::rnn_layer_fwd(lstm, dirs, ndir, B, Hd, S, lengths, fill, ld_out, drop_p, drop_site, rng, precision, sync,
+                                reinterpret_cast<int*>(sync + 2), launched, (hipStream_t)stream);
+}
 
 extern "C" int slnlp_rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
                                   float fill, int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng,

@@ -125,6 +125,7 @@ struct RWs {
     float *emb, *demb, *enc_final, *denc_final, *h0, *dh0, *dz, *pk, *dpk, *q, *dq, *alphas, *ctx, *dctx, *emb_bos,
         *demb_bos, *dwe_part, *logits, *dlogits, *logp, *row_nll, *opt_partials;
     int64_t* bos_ids;
+    unsigned* sync;          // {barrier count, generation, error flag} of the persistent layer kernel
     void *emb_scratch_src, *emb_scratch_tgt;
     std::vector<EncLayerA> enc;
     std::vector<DecLayerA> dec;
@@ -199,6 +200,7 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
     w.row_nll = b.take<float>(B);
     w.opt_partials = b.take<float>(1024);
     w.bos_ids = b.take<int64_t>(B);
+    w.sync = b.take<unsigned>(64);
     w.emb_scratch_src = b.take<char>(embed_bwd_scratch_bytes(c.B, c.S, c.E));
     w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
     w.bytes = (b.cur + 255) & ~(size_t)255;
@@ -220,6 +222,7 @@ struct slnlp_rnn_plan {
     float last_p = 0.f;
     const int64_t *last_X = nullptr, *last_y = nullptr, *last_len = nullptr;
     std::map<int, hipGraphExec_t> graphs;
+    bool persistent = false;  // opt-in: all timesteps of an encoder layer in one launch (not yet faster; needs one fit per GPU)
 
     float* P(long off) const { return buf.params + off; }
     float* Gd(long off) const { return buf.grads + off; }
@@ -326,7 +329,8 @@ int slnlp_rnn_create(const slnlp_rnn_config* cfg, const slnlp_tf_buffers* buf, s
     p->w = rcarve(*cfg, buf->workspace);
     std::vector<int64_t> bos(cfg->B, (int64_t)cfg->bos_idx);
     if (hipMemcpy(p->w.bos_ids, bos.data(), bos.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess) {   // pre_output_layer + pads stay 0
+        hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess ||   // pre_output_layer + pads stay 0
+        hipMemset(p->w.sync, 0, 64 * sizeof(unsigned)) != hipSuccess || rnn_layer_init() != 0) {
         set_error("rnn_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
         delete p;
         return SLNLP_ERR_LAUNCH;
@@ -365,8 +369,23 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
                 return fail_memset();
         }
         const bool last = l == N - 1;
-        for (int step = 0; step < S; ++step) {
-            // one launch per timestep: recurrent GEMM of both directions + the cell (gemm.hip rnn_step_fwd_kernel)
+        // inter-layer dropout (not after the last layer); padded outputs of the LAST layer = float(pad_idx)
+        const float fill = last ? (float)c.pad_src : 0.f, pdrop = last ? 0.f : p;
+        int launched = 0;
+        if (pl->persistent) {   // all S timesteps of both directions in ONE launch (gemm.hip rnn_layer_fwd_kernel)
+            slnlp_rnn_layer_dir ld[2];
+            for (int d = 0; d < 2; ++d) {
+                const RnnW& q = L.enc[d][l];
+                const EncDirA& e = a.d[d];
+                ld[d].hprev = e.hprev; ld[d].h_final = e.h; ld[d].w_hh = pl->P(q.w_hh); ld[d].b_hh = pl->P(q.b_hh);
+                ld[d].xproj = e.xproj; ld[d].c = e.c; ld[d].cprev = e.cprev; ld[d].acts = e.acts; ld[d].hn = e.hn;
+                ld[d].out = a.out + d * Hd; ld[d].out_col0 = d * Hd; ld[d].reverse = d;
+            }
+            SLNLP_TRY(rnn_layer_fwd(lstm, ld, 2, B, Hd, S, lengths, fill, 2 * Hd, pdrop, RSITE_ENC0 + l, rng, c.precision,
+                                    w.sync, reinterpret_cast<int*>(w.sync + 2), &launched, st));
+        }
+        for (int step = 0; step < S && !launched; ++step) {
+            // shapes the persistent kernel does not cover: one launch per timestep (recurrent GEMM of both directions + cell)
             slnlp_rnn_step_dir dirs[2];
             for (int d = 0; d < 2; ++d) {
                 const int t = d == 0 ? step : S - 1 - step, tn = d == 0 ? t + 1 : t - 1;
@@ -384,9 +403,7 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
                 k.out = a.out + (long)t * B * 2 * Hd + d * Hd;
                 k.t = t; k.out_row0 = t * B; k.out_col0 = d * Hd;
             }
-            // inter-layer dropout (not after the last layer); padded outputs of the LAST layer = float(pad_idx)
-            SLNLP_TRY(rnn_step_fwd(lstm, dirs, 2, B, Hd, lengths, last ? (float)c.pad_src : 0.f, 2 * Hd, last ? 0.f : p,
-                                   RSITE_ENC0 + l, rng, c.precision, st));
+            SLNLP_TRY(rnn_step_fwd(lstm, dirs, 2, B, Hd, lengths, fill, 2 * Hd, pdrop, RSITE_ENC0 + l, rng, c.precision, st));
         }
         // final states -> hidden[l] = fwd || bwd   (concatenate_directions, bkp.py:155-159)
         for (int d = 0; d < 2; ++d)
@@ -433,6 +450,29 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
         set_error("rnn_forward: copy of log-probs failed");
         return SLNLP_ERR_LAUNCH;
     }
+    return 0;
+}
+
+// on = 1: all timesteps of an encoder layer in ONE persistent launch (gemm.hip rnn_layer_fwd_kernel) instead of one
+// launch per timestep.  Off by default: measured no faster yet, and its workgroups must all be resident at once, so it
+// must not be used when several fits share the GPU.
+int slnlp_rnn_set_persistent(slnlp_rnn_plan* pl, int on) {
+    SLNLP_CHECK_ARG(pl, "rnn_set_persistent: null plan");
+    pl->persistent = on != 0;
+    return 0;
+}
+
+// *status = 0: every device-wide barrier of the persistent layer kernels completed; 1: a workgroup timed out (bounded
+// spin) and that step's results are invalid.  Synchronises the device.
+int slnlp_rnn_health(slnlp_rnn_plan* pl, int* status) {
+    SLNLP_CHECK_ARG(pl && status, "rnn_health: null argument");
+    unsigned flag = 0;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&flag, pl->w.sync + 2, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("rnn_health: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    *status = (int)flag;
     return 0;
 }
 

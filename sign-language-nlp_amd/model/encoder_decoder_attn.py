@@ -93,8 +93,11 @@ class EncoderDecoderAttnBase(ArenaModule):
     def _make_engine(self, B, S, old):
         from slnlp import rnn_engine as re_
         cfg = re_.make_config(B=B, S=S, **self._cfg_args)
-        return re_.RnnEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
-                             grads=old.grads if old else None, momentum=old.momentum if old else None)
+        eng = re_.RnnEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
+                            grads=old.grads if old else None, momentum=old.momentum if old else None)
+        if getattr(self, "persistent_kernels", False):        # opt-in (never when several fits share the GPU)
+            eng.set_persistent(True)
+        return eng
 
     def forward(self, X, y, lengths, **kwargs):
         dev = self._arena.device

@@ -53,6 +53,11 @@ class RnnStepDir(C.Structure):
                 ("acts", vp), ("hn_save", vp), ("out", vp), ("t", i32), ("out_row0", i32), ("out_col0", i32)]
 
 
+class RnnLayerDir(C.Structure):
+    _fields_ = [("hprev", vp), ("h_final", vp), ("w_hh", vp), ("b_hh", vp), ("xproj", vp), ("c", vp), ("cprev", vp),
+                ("acts", vp), ("hn", vp), ("out", vp), ("out_col0", i32), ("reverse", i32)]
+
+
 class RnnCellBwdDir(C.Structure):
     _fields_ = [("dh_state", vp), ("dc_state", vp), ("dout", vp), ("acts", vp), ("cprev_save", vp),
                 ("hprev_save", vp), ("hn_save", vp), ("dgx", vp), ("dgh", vp), ("carry", vp),
@@ -88,6 +93,8 @@ SIGNATURES = {
     "slnlp_clip_sgd_step": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp]),
     "slnlp_dropout_mask": (i32, [vp, i32, i32, f32, i32, vp, vp]),
     "slnlp_rnn_cell_fwd": (i32, [i32, C.POINTER(RnnCellDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, vp]),
+    "slnlp_rnn_layer_fwd": (i32, [i32, C.POINTER(RnnLayerDir), i32, i32, i32, i32, vp, f32, i64, f32, i32, vp, i32, vp,
+                                  C.POINTER(i32), vp]),
     "slnlp_rnn_step_fwd": (i32, [i32, C.POINTER(RnnStepDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, i32, vp]),
     "slnlp_rnn_cell_bwd": (i32, [i32, C.POINTER(RnnCellBwdDir), i32, i32, i32, vp, i64, f32, i32, vp, vp]),
     "slnlp_bahdanau_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]),
@@ -106,6 +113,8 @@ SIGNATURES = {
     "slnlp_rnn_train_step": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_rnn_graph_capture_train": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_rnn_graph_launch": (i32, [vp, i32, vp]),
+    "slnlp_rnn_set_persistent": (i32, [vp, i32]),
+    "slnlp_rnn_health": (i32, [vp, C.POINTER(i32)]),
     "slnlp_rnn_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
     "slnlp_tf_num_params": (i32, [C.POINTER(TfConfig)]),
     "slnlp_tf_param_info": (i32, [C.POINTER(TfConfig), i32, C.c_char_p, C.POINTER(i64 * 2), C.POINTER(i32),

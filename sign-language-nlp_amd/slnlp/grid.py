@@ -101,6 +101,10 @@ def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_l
         if seed is not None:
             torch.manual_seed(seed)
         net.initialize()
+    if concurrent and hasattr(net.module_, "_make_engine"):
+        # persistent kernels (all their workgroups co-resident, spinning at device-wide barriers) need the GPU to
+        # themselves: concurrent fits must use the per-timestep launches
+        net.module_.persistent_kernels = False
     net.partial_fit(train)
     return float(ScoringWrapper(scoring, train.labels() if scoring == "neg_log_loss" else None)(net, test, test.y))
 

@@ -133,6 +133,16 @@ class RnnEngine:
         assert n.value == rows * cols, (name, n.value, rows, cols)
         return out
 
+    def set_persistent(self, on):
+        """True: each encoder layer's timesteps in one persistent launch (opt-in; one fit per GPU only)."""
+        check(load().slnlp_rnn_set_persistent(self.handle, int(bool(on))), "rnn_set_persistent")
+
+    def health(self):
+        """0 = every device-wide barrier of the persistent layer kernels completed; synchronises."""
+        st = C.c_int32(-1)
+        check(load().slnlp_rnn_health(self.handle, C.byref(st)), "rnn_health")
+        return st.value
+
     @property
     def loss(self):
         return float(self.scalars[0])

@@ -179,3 +179,81 @@ def test_fused_step_equals_gemm_plus_cell(lstm, B, Hd):
     else:
         assert torch.equal(f["hn"], r["hn"])
     assert (lengths <= t).any() and (lengths > t).any()          # both masked and live rows were exercised
+
+
+@pytest.mark.parametrize("lstm", [1, 0])
+@pytest.mark.parametrize("B,Hd,S", [(50, 512, 48), (9, 64, 5), (64, 128, 12)])
+def test_persistent_layer_equals_stepwise(lstm, B, Hd, S):
+    """slnlp_rnn_layer_fwd (all S timesteps of a bidirectional layer in one launch, W_hh slice resident in LDS,
+    device-wide barrier between steps) against S calls of slnlp_rnn_step_fwd: bit-identical state chain, gate
+    activations, outputs; barrier words back to rest, error flag clear."""
+    import ctypes as C
+    from slnlp import ops
+    from slnlp._lib import RnnLayerDir, RnnStepDir, check, load, ptr, stream_ptr
+    G = 4 if lstm else 3
+    g = torch.Generator().manual_seed(B + Hd + S + lstm)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+    W = [rnd(G * Hd, Hd) * 0.05 for _ in range(2)]
+    bh = [rnd(G * Hd) * 0.1 for _ in range(2)]
+    xp = [rnd(S, B, G * Hd) for _ in range(2)]
+    lengths = torch.randint(1, S + 1, (B,), generator=g).cuda()
+    rng = ops.make_rng(seed=3, step=1)
+    p, site, fill, ld_out = 0.2, 33, 1.0, 2 * Hd
+
+    def buffers():
+        return [dict(hprev=torch.zeros(S, B, Hd).cuda(), h=torch.zeros(B, Hd).cuda(), c=torch.zeros(B, Hd).cuda(),
+                     cprev=torch.zeros(S, B, Hd).cuda(), acts=torch.zeros(S, B, G * Hd).cuda(), hn=torch.zeros(S, B, Hd).cuda())
+                for _ in range(2)]
+    # reference: one launch per timestep
+    r, out_r = buffers(), torch.zeros(S * B, ld_out).cuda()
+    for step in range(S):
+        dirs = (RnnStepDir * 2)()
+        for d in range(2):
+            t = step if d == 0 else S - 1 - step
+            tn = t + 1 if d == 0 else t - 1
+            e = r[d]
+            h_out = e["hprev"][tn] if step + 1 < S else e["h"]
+            dirs[d] = RnnStepDir(ptr(e["hprev"][t]), ptr(h_out), ptr(W[d]), ptr(bh[d]), ptr(xp[d][t]), ptr(e["c"]), ptr(e["cprev"][t]),
+                                 ptr(e["acts"][t]), ptr(e["hn"][t]), out_r[t * B:].data_ptr() + 4 * d * Hd, t, t * B, d * Hd)
+        check(load().slnlp_rnn_step_fwd(lstm, dirs, 2, B, Hd, ptr(lengths), fill, ld_out, p, site, ptr(rng), 3, stream_ptr()), "step")
+    # persistent
+    f, out_f = buffers(), torch.zeros(S * B, ld_out).cuda()
+    sync = torch.zeros(4, dtype=torch.int32).cuda()
+    dirs = (RnnLayerDir * 2)()
+    for d in range(2):
+        e = f[d]
+        dirs[d] = RnnLayerDir(ptr(e["hprev"]), ptr(e["h"]), ptr(W[d]), ptr(bh[d]), ptr(xp[d]), ptr(e["c"]), ptr(e["cprev"]),
+                              ptr(e["acts"]), ptr(e["hn"]), out_f.data_ptr() + 4 * d * Hd, d * Hd, d)
+    launched = C.c_int32(0)
+    check(load().slnlp_rnn_layer_fwd(lstm, dirs, 2, B, Hd, S, ptr(lengths), fill, ld_out, p, site, ptr(rng), 3, ptr(sync),
+                                     C.byref(launched), stream_ptr()), "layer")
+    torch.cuda.synchronize()
+    assert launched.value == 1
+    assert sync.tolist()[0] == 0 and sync.tolist()[2] == 0          # barrier at rest, no spin timeout
+    for d in range(2):
+        for k in ("hprev", "h", "acts") + (("c", "cprev") if lstm else ("hn",)):
+            assert torch.equal(f[d][k], r[d][k]), (d, k)
+    assert torch.equal(out_f, out_r)
+
+
+def test_plan_with_persistent_layers_matches_stepwise_plan():
+    """RnnEngine.set_persistent(True): the whole train step (forward through the persistent layer kernels, same
+    backward) gives the same loss trajectory and weights as the default per-timestep plan; health() stays 0."""
+    import bench
+    from slnlp import rnn_engine as re_, synth
+    c = dict(bench.WORKLOADS["cfg3"], precision=3, N=2)
+    out = []
+    for persistent in (False, True):
+        cfg, sd = bench.build_sd(c, seed=1)
+        eng = re_.RnnEngine(cfg, seed=1)
+        eng.load_state(sd); eng.set_lr(0.01)
+        eng.set_persistent(persistent)
+        Xn, Ln, yn = synth.make_batch(3 * c["B"], c["S"], c["Vs"], c["Vt"], seed=1)
+        X, L, y = torch.from_numpy(Xn).cuda(), torch.from_numpy(Ln).cuda(), torch.from_numpy(yn).cuda()
+        B, losses = c["B"], []
+        for i in range(3):
+            eng.train_step(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B], L[i * B:(i + 1) * B], 0.9, 0.5)
+            losses.append(eng.loss)
+        assert eng.health() == 0
+        out.append((losses, eng.params.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
