@@ -268,7 +268,8 @@ def test_clip_sgd(ops):
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
 @pytest.mark.parametrize("M,N,K", [(2400, 512, 512), (50, 202, 512), (50, 512, 202), (64, 64, 64), (130, 70, 100),
-                                   (512, 512, 2400), (202, 512, 50)])
+                                   (512, 512, 2400), (202, 512, 50),
+                                   (1024, 512, 320), (512, 1024, 1000), (2048, 256, 64)])
 def test_gemm_planes_layouts(ops, layout, M, N, K, prec):
     """LDS-DMA GEMM over pre-split, zero-padded bf16 planes (gemm_planes.hip) vs fp64."""
     Al, Bl = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -333,3 +334,27 @@ def test_gemm_group_dgrad_wgrad_one_launch(ops, split):
     j3, o3 = ops.plane_job(A2p, B2p, M=70, N=50, K=130)
     ops.gemm_group([jw, j3, jd], [split, 9, 1])
     assert rel(o3, A2.double() @ B2.double().T) < 1e-4 and rel(dW, dY.double().T @ X.double()) < 2e-4
+
+
+def test_gemm_group_large_shapes_split_k_and_epilogue(ops):
+    """Plane GEMM at configs[4]-sized operands: grouped dgrad + wgrad with deterministic 8-way split-K and fused
+    bias-gradient row sums, and the epilogue (bias, ReLU, residual, output planes)."""
+    Mtok, Nout, Kin = 4096, 1024, 512
+    dY, X, W = rnd(Mtok, Nout, seed=1), rnd(Mtok, Kin, seed=2), rnd(Nout, Kin, seed=3)
+    dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
+    rs = torch.empty(Nout, device="cuda")
+    jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
+    jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+    scratch = ops.gemm_group([jw, jd], [8, 1])
+    assert rel(dW, dY.double().T @ X.double()) < 3e-4 and rel(dX, dY.double() @ W.double()) < 2e-4
+    assert rel(rs, dY.double().sum(0)) < 1e-4
+    dW1 = dW.clone(); dW.zero_()
+    ops.gemm_group([jw, jd], [8, 1], scratch)
+    assert torch.equal(dW, dW1) and int(scratch[:16384].view(torch.int32).abs().max()) == 0
+    M, N, K = 1024, 512, 256
+    A, B, bias, R = rnd(M, K, seed=4), rnd(N, K, seed=5), rnd(N, seed=6), rnd(M, N, seed=7)
+    ref = torch.relu(A.double() @ B.double().T + bias.double()) + R.double()
+    out, (hi, lo) = ops.gemm_planes(ops.split_planes(A.cuda()), ops.split_planes(B.cuda()), M=M, N=N, K=K,
+                                    bias=bias.cuda(), relu=True, resid=R.cuda(), want_planes=True)
+    assert rel(out, ref) < 1e-4
+    assert rel((hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float())[:M, :N], ref) < 1e-4
