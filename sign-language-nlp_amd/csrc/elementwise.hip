@@ -359,11 +359,24 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_red
     const slnlp_ln_reduce_entry e = table[blockIdx.x];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.y * 64 + col;
     float g = 0.f, b = 0.f;
-    if (c < e.E)
-        for (int k = grp; k < e.nblk; k += 4) {
+    if (c < e.E) {
+        // up to 64 partials per thread: 8 independent load pairs in flight per trip (the adds stay in increasing-k order)
+        int k = grp;
+        for (; k + 28 < e.nblk; k += 32) {
+            float pg[8], pb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                pg[u] = e.partial[((long)(k + 4 * u) * 2 + 0) * e.E + c];
+                pb[u] = e.partial[((long)(k + 4 * u) * 2 + 1) * e.E + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { g += pg[u]; b += pb[u]; }
+        }
+        for (; k < e.nblk; k += 4) {
             g += e.partial[((long)k * 2 + 0) * e.E + c];
             b += e.partial[((long)k * 2 + 1) * e.E + c];
         }
+    }
     red[0][grp][col] = g;
     red[1][grp][col] = b;
     __syncthreads();
