@@ -246,32 +246,43 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ beta, int rows, int E,
                                                             float eps, float* __restrict__ y,
                                                             float* __restrict__ stats, PlaneOut po) {
+    // one wave per row; the row is read ONCE and kept in registers (E <= LN_MAXU * 256) for the two-pass statistics
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const float* xr = x + (long)row * E;
-    float s = 0.f;
-    for (int c = lane * 4; c < E; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        s += v.x + v.y + v.z + v.w;
+    float4 v[LN_MAXU], g[LN_MAXU], bt[LN_MAXU];
+#pragma unroll
+    for (int u = 0; u < LN_MAXU; ++u) {
+        const int c = lane * 4 + u * 256;
+        const bool in = c < E;
+        v[u] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[u] = in ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[u] = in ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXU; ++u) s += v[u].x + v[u].y + v[u].z + v[u].w;      // out-of-range slots hold zeros
     const float mean = wave_sum(s) / (float)E;
     float q = 0.f;
-    for (int c = lane * 4; c < E; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += a * a + b * b + cc * cc + d * d;
+#pragma unroll
+    for (int u = 0; u < LN_MAXU; ++u) {
+        if (lane * 4 + u * 256 < E) {
+            const float a = v[u].x - mean, b = v[u].y - mean, cc = v[u].z - mean, d = v[u].w - mean;
+            q += a * a + b * b + cc * cc + d * d;
+        }
     }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)E + eps);
-    for (int c = lane * 4; c < E; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 b = *reinterpret_cast<const float4*>(beta + c);
-        float4 o;
-        o.x = (v.x - mean) * rstd * g.x + b.x; o.y = (v.y - mean) * rstd * g.y + b.y;
-        o.z = (v.z - mean) * rstd * g.z + b.z; o.w = (v.w - mean) * rstd * g.w + b.w;
-        *reinterpret_cast<float4*>(y + (long)row * E + c) = o;
-        store_planes4(po, (long)row * E + c, o);
+#pragma unroll
+    for (int u = 0; u < LN_MAXU; ++u) {
+        const int c = lane * 4 + u * 256;
+        if (c < E) {
+            float4 o;
+            o.x = (v[u].x - mean) * rstd * g[u].x + bt[u].x; o.y = (v[u].y - mean) * rstd * g[u].y + bt[u].y;
+            o.z = (v[u].z - mean) * rstd * g[u].z + bt[u].z; o.w = (v[u].w - mean) * rstd * g[u].w + bt[u].w;
+            *reinterpret_cast<float4*>(y + (long)row * E + c) = o;
+            store_planes4(po, (long)row * E + c, o);
+        }
     }
     if (lane == 0 && stats) {
         stats[2 * row] = mean;
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_red
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                   float* stats, hipStream_t st, PlaneOut po) {
     SLNLP_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
-    SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0, "layernorm_fwd: bad shape rows=%d E=%d", rows, E);
+    SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "layernorm_fwd: need E %% 4 == 0 and E <= %d, got rows=%d E=%d", LN_MAXU * 256, rows, E);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, gamma, beta, rows, E, eps, y,
                        stats, po);
     SLNLP_CHECK_LAUNCH("layernorm_fwd");
