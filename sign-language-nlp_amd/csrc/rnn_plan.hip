@@ -116,7 +116,11 @@ struct EncDirA {   // per (layer, direction)
     float *xproj, *acts, *hprev, *cprev, *hn, *h, *c;
     float *dgx, *dgh, *dh, *dc, *carry, *dhx;   // dhx: partial products of the K-sliced recurrent dgrad
 };
-struct EncLayerA { EncDirA d[2]; float *out, *dout; };    // out [M,2Hd]; dout = grad w.r.t. out
+struct RPP {               // bf16 hi / lo planes of a GEMM operand (gemm_planes.hip)
+    unsigned short *hi = nullptr, *lo = nullptr;
+    PlaneOut out() const { PlaneOut o; o.hi = hi; o.lo = lo; return o; }
+};
+struct EncLayerA { EncDirA d[2]; float *out, *dout; RPP xinp; };    // out [M,2Hd]; dout = grad w.r.t. out; xinp = planes of the layer input
 struct DecLayerA {
     float *xproj, *hproj, *acts, *hprev, *cprev, *hn, *h, *c, *out;
     float *dgx, *dgh, *dh, *dc, *carry, *dout;
@@ -126,6 +130,9 @@ struct RWs {
         *demb_bos, *dwe_part, *logits, *dlogits, *logp, *row_nll, *opt_partials;
     int64_t* bos_ids;
     unsigned* sync;          // {barrier count, generation, error flag} of the persistent layer kernel
+    RPP wp;                  // planes of the encoder's RNN weights (arena prefix [0, key_w)), split once per forward
+    RPP dgxp[2], dghp[2], hprevp[2];   // per direction, reused by every layer's backward
+    char *planes_begin, *planes_end;   // activation planes: zero padding rows, re-zeroed when the batch size changes
     void *emb_scratch_src, *emb_scratch_tgt;
     std::vector<EncLayerA> enc;
     std::vector<DecLayerA> dec;
@@ -203,6 +210,23 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
     w.sync = b.take<unsigned>(64);
     w.emb_scratch_src = b.take<char>(embed_bwd_scratch_bytes(c.B, c.S, c.E));
     w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
+    {   // ---- bf16 operand planes of the M = S*B GEMMs (used when E and Hd are multiples of 64)
+        const size_t Mp = (M + 63) / 64 * 64, GH = G * Hd;
+        const size_t wlen = (size_t)build_rlayout(c).key_w + 64 * (2 * Hd > E ? 2 * Hd : E);   // tail pad: tiles may over-read rows
+        w.wp.hi = b.take<unsigned short>(wlen);
+        w.wp.lo = b.take<unsigned short>(wlen);
+        b.cur = (b.cur + 255) & ~(size_t)255;
+        w.planes_begin = b.base + b.cur;
+        auto pp = [&](size_t cols) { RPP q; q.hi = b.take<unsigned short>(Mp * cols); q.lo = b.take<unsigned short>(Mp * cols); return q; };
+        for (int l = 0; l < c.N; ++l) w.enc[l].xinp = pp(l == 0 ? E : 2 * Hd);
+        for (int d = 0; d < 2; ++d) {
+            w.dgxp[d] = pp(GH);
+            w.dghp[d] = c.lstm ? w.dgxp[d] : pp(GH);
+            w.hprevp[d] = pp(Hd);
+        }
+        b.cur = (b.cur + 255) & ~(size_t)255;
+        w.planes_end = b.base + b.cur;
+    }
     w.bytes = (b.cur + 255) & ~(size_t)255;
     return w;
 }
@@ -222,6 +246,8 @@ struct slnlp_rnn_plan {
     float last_p = 0.f;
     const int64_t *last_X = nullptr, *last_y = nullptr, *last_len = nullptr;
     std::map<int, hipGraphExec_t> graphs;
+    bool use_planes = false;  // E, Hd multiples of 64: the M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
+    int planes_B = -1;        // batch size the activation planes' zero padding is valid for
     bool persistent = false;  // opt-in: all timesteps of an encoder layer in one launch (not yet faster; needs one fit per GPU)
 
     float* P(long off) const { return buf.params + off; }
@@ -258,6 +284,46 @@ struct slnlp_rnn_plan {
     int dgr(const float* dy, long ldy, int M, int Nout, const float* W, long ldw, int Kin, float* dx, long ldx,
             const float* resid, hipStream_t st) const {
         return gemm(dgr_args(dy, ldy, M, Nout, W, ldw, Kin, dx, ldx, resid), st);
+    }
+    // zero padding of the activation planes is per batch size: re-zero when it changes (outside any capture)
+    int prepare_planes(int B, hipStream_t st) {
+        if (!use_planes || B == planes_B) return 0;
+        if (hipMemsetAsync(w.planes_begin, 0, (size_t)(w.planes_end - w.planes_begin), st) != hipSuccess) {
+            set_error("rnn: zeroing operand planes failed");
+            return SLNLP_ERR_LAUNCH;
+        }
+        planes_B = B;
+        return 0;
+    }
+    // plane GEMM argument builders (weights: planes of the arena at offset woff)
+    slnlp_gemm_args lin_p(const RPP& x, int M, int K, long woff, int N, const float* bias, float* y) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
+        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; a.b_kmajor = 1;
+        a.C = y; a.ldc = N; a.M = M; a.N = N; a.K = K; a.bias = bias;
+        a.precision = cfg.precision;
+        return a;
+    }
+    slnlp_gemm_args dgr_p(const RPP& dy, int M, int Nout, long woff, int Kin, float* dx, const float* resid) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = Nout; a.a_kmajor = 1;
+        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = Kin; a.b_kmajor = 0;
+        a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
+        a.resid = resid; a.ldr = Kin;
+        a.precision = cfg.precision;
+        return a;
+    }
+    slnlp_gemm_args wgr_p(const RPP& dy, int T, int Nout, const RPP& x, int Kin, float* dW, float* db) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = Nout; a.a_kmajor = 0;
+        a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
+        a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
+        a.rowsum_a = db;
+        a.precision = cfg.precision;
+        return a;
     }
     // the recurrent dgrad dh(t-1) = dgh W_hh + carry contracts over the G*Hd gate columns: one K-slice per gate
     // (each its own GEMM job, partial products summed by the next cell kernel) keeps the serial K loop at Hd
@@ -327,10 +393,11 @@ int slnlp_rnn_create(const slnlp_rnn_config* cfg, const slnlp_tf_buffers* buf, s
     p->buf = *buf;
     p->L = build_rlayout(*cfg);
     p->w = rcarve(*cfg, buf->workspace);
+    p->use_planes = (cfg->E % 64 == 0) && (cfg->Hd % 64 == 0);
     std::vector<int64_t> bos(cfg->B, (int64_t)cfg->bos_idx);
     if (hipMemcpy(p->w.bos_ids, bos.data(), bos.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess ||   // pre_output_layer + pads stay 0
-        hipMemset(p->w.sync, 0, 64 * sizeof(unsigned)) != hipSuccess || rnn_layer_init() != 0) {
+        hipMemset(p->w.sync, 0, 64 * sizeof(unsigned)) != hipSuccess || rnn_layer_init() != 0 || gemm_planes_init() != 0) {
         set_error("rnn_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
         delete p;
         return SLNLP_ERR_LAUNCH;
@@ -354,14 +421,26 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
     pl->last_B = B; pl->last_p = p; pl->last_X = X; pl->last_y = y; pl->last_len = lengths;
 
     // src_embed (nn.Embedding(padding_idx), no scale, no positional term)  bkp.py:48-50
-    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), nullptr, w.emb, 1.f, 0.f, 0, rng, -1, st));
+    const bool up = pl->use_planes;
+    if (up) {   // the encoder's RNN weights as bf16 planes, once per forward (they changed in the optimizer step / load_state)
+        SLNLP_TRY(pl->prepare_planes(B, st));
+        SLNLP_TRY(split_planes(pl->buf.params, L.key_w, 1, (int)L.key_w, w.wp.hi, w.wp.lo, L.key_w, st));
+    }
+    SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), nullptr, w.emb, 1.f, 0.f, 0, rng, -1, st,
+                        up ? w.enc[0].xinp.out() : PlaneOut{}));
     const float* x_in = w.emb;
     for (int l = 0; l < N; ++l) {
         const EncLayerA& a = w.enc[l];
         const int in = L.enc[0][l].in;
+        if (up) {   // x W_ih^T + b_ih of both directions over all timesteps: one grouped plane-GEMM launch
+            if (l > 0) SLNLP_TRY(split_planes(x_in, in, M, in, a.xinp.hi, a.xinp.lo, in, st));
+            const slnlp_gemm_args xj[2] = {pl->lin_p(a.xinp, M, in, L.enc[0][l].w_ih, GH, pl->P(L.enc[0][l].b_ih), a.d[0].xproj),
+                                           pl->lin_p(a.xinp, M, in, L.enc[1][l].w_ih, GH, pl->P(L.enc[1][l].b_ih), a.d[1].xproj)};
+            SLNLP_TRY(gemm_planes_group(xj, nullptr, 2, nullptr, 0, st));
+        }
         for (int d = 0; d < 2; ++d) {
             const RnnW& q = L.enc[d][l];
-            SLNLP_TRY(pl->lin(x_in, in, M, in, pl->P(q.w_ih), in, GH, pl->P(q.b_ih), a.d[d].xproj, GH, 0, nullptr, st));
+            if (!up) SLNLP_TRY(pl->lin(x_in, in, M, in, pl->P(q.w_ih), in, GH, pl->P(q.b_ih), a.d[d].xproj, GH, 0, nullptr, st));
             // the state chain lives in the per-timestep `hprev` slots: slot of the first processed timestep = h_0 = 0
             const int t0 = d == 0 ? 0 : S - 1;
             if (hipMemsetAsync(a.d[d].hprev + (long)t0 * B * Hd, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess ||
@@ -588,6 +667,19 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
         for (int d = 0; d < 2; ++d) {
             const RnnW& q = L.enc[d][l];
             const EncDirA& e = a.d[d];
+            if (pl->use_planes) {
+                // both weight gradients and the input gradient of this direction: operands split to planes once, then ONE
+                // grouped plane-GEMM launch (every job has >= 256 tiles, so no split-K is needed)
+                SLNLP_TRY(split_planes(e.dgx, GH, M, GH, w.dgxp[d].hi, w.dgxp[d].lo, GH, st));
+                if (!lstm) SLNLP_TRY(split_planes(e.dgh, GH, M, GH, w.dghp[d].hi, w.dghp[d].lo, GH, st));
+                SLNLP_TRY(split_planes(e.hprev, Hd, M, Hd, w.hprevp[d].hi, w.hprevp[d].lo, Hd, st));
+                const slnlp_gemm_args jobs[3] = {
+                    pl->wgr_p(w.dgxp[d], M, GH, a.xinp, in, pl->Gd(q.w_ih), pl->Gd(q.b_ih)),
+                    pl->wgr_p(w.dghp[d], M, GH, w.hprevp[d], Hd, pl->Gd(q.w_hh), pl->Gd(q.b_hh)),
+                    pl->dgr_p(w.dgxp[d], M, GH, q.w_ih, in, dx, d == 0 ? nullptr : dx)};
+                SLNLP_TRY(gemm_planes_group(jobs, nullptr, 3, nullptr, 0, st));
+                continue;
+            }
             SLNLP_TRY(pl->wgr(e.dgx, GH, M, GH, x_in, in, in, pl->Gd(q.w_ih), in, pl->Gd(q.b_ih), st));
             SLNLP_TRY(pl->wgr(e.dgh, GH, M, GH, e.hprev, Hd, Hd, pl->Gd(q.w_hh), Hd, pl->Gd(q.b_hh), st));
             SLNLP_TRY(pl->dgr(e.dgx, GH, M, GH, pl->P(q.w_ih), in, in, dx, in, d == 0 ? nullptr : dx, st));
@@ -615,6 +707,7 @@ int slnlp_rnn_graph_capture_train(slnlp_rnn_plan* pl, const int64_t* X, const in
                                   float momentum, float max_norm, float* logp, void* stream) {
     SLNLP_CHECK_ARG(pl && stream, "rnn_graph_capture_train: needs a plan and a non-default stream");
     hipStream_t st = (hipStream_t)stream;
+    SLNLP_TRY(pl->prepare_planes(B, (hipStream_t)stream));   // must not be captured: it runs once per batch-size change
     auto old = pl->graphs.find(B);
     if (old != pl->graphs.end()) {
         (void)hipStreamSynchronize(st);
@@ -651,6 +744,7 @@ int slnlp_rnn_graph_launch(slnlp_rnn_plan* pl, int B, void* stream) {
     SLNLP_CHECK_ARG(pl, "rnn_graph_launch: null plan");
     auto it = pl->graphs.find(B);
     SLNLP_CHECK_ARG(it != pl->graphs.end(), "rnn_graph_launch: no captured graph for batch %d", B);
+    SLNLP_TRY(pl->prepare_planes(B, (hipStream_t)stream));
     if (hipGraphLaunch(it->second, (hipStream_t)stream) != hipSuccess) {
         set_error("rnn_graph_launch: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
