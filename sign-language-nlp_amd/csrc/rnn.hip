@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void bahdanau_fwd_kernel(const float* __restri
     const int V2 = 2 * Hd;
     for (int c = threadIdx.x; c < V2; c += 256) {
         float a = 0.f;
-        for (int s = 0; s < S; ++s) a += sc[s] * val[((long)s * B + b) * V2 + c];
+#pragma unroll 8
+        for (int s = 0; s < S; ++s) a += sc[s] * val[((long)s * B + b) * V2 + c];   // 8 independent loads in flight per trip
         ctx[(long)b * V2 + c] = a;
     }
 }
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256) void bahdanau_bwd_kernel(const float* __restri
     for (int j = threadIdx.x; j < Hd; j += 256) {
         const float qj = q[(long)b * Hd + j], wj = we[j];
         float accq = 0.f, accw = 0.f;
+#pragma unroll 8
         for (int s = 0; s < S; ++s) {
             const long row = ((long)s * B + b) * Hd;
             const float u = tanhf(qj + pk[row + j]);

@@ -126,6 +126,7 @@ struct DecLayerA {
     float *dgx, *dgh, *dh, *dc, *carry, *dout;
 };
 struct RWs {
+    float *zero_fwd, *zero_bwd;
     float *emb, *demb, *enc_final, *denc_final, *h0, *dh0, *dz, *pk, *dpk, *q, *dq, *alphas, *ctx, *dctx, *emb_bos,
         *demb_bos, *dwe_part, *logits, *dlogits, *logp, *row_nll, *opt_partials;
     int64_t* bos_ids;
@@ -145,6 +146,9 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
     const size_t B = c.B, S = c.S, E = c.E, Hd = c.Hd, M = B * S, G = c.lstm ? 4 : 3, Vp = align_up_r(c.Vt, 4);
     w.emb = b.take<float>(M * E);
     w.demb = b.take<float>(M * E);
+    // states that start every step at zero sit together: ONE memset per pass instead of one per (layer, direction)
+    w.zero_fwd = b.take<float>(2 * c.N * B * Hd);                 // encoder c
+    w.zero_bwd = b.take<float>((2 * c.N + 2 * c.N) * B * Hd);     // encoder dc, decoder dh, decoder dc
     for (int l = 0; l < c.N; ++l) {
         EncLayerA a;
         for (int d = 0; d < 2; ++d) {
@@ -155,11 +159,11 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
             e.cprev = b.take<float>(M * Hd);
             e.hn = b.take<float>(M * Hd);
             e.h = b.take<float>(B * Hd);
-            e.c = b.take<float>(B * Hd);
+            e.c = w.zero_fwd + (size_t)(2 * l + d) * B * Hd;
             e.dgx = b.take<float>(M * G * Hd);
             e.dgh = c.lstm ? e.dgx : b.take<float>(M * G * Hd);
             e.dh = b.take<float>(B * Hd);
-            e.dc = b.take<float>(B * Hd);
+            e.dc = w.zero_bwd + (size_t)(2 * l + d) * B * Hd;
             e.carry = b.take<float>(B * Hd);
             e.dhx = b.take<float>(3 * B * Hd);
         }
@@ -195,8 +199,8 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
         a.out = b.take<float>(B * Hd);
         a.dgx = b.take<float>(B * G * Hd);
         a.dgh = c.lstm ? a.dgx : b.take<float>(B * G * Hd);
-        a.dh = b.take<float>(B * Hd);
-        a.dc = b.take<float>(B * Hd);
+        a.dh = w.zero_bwd + (size_t)(2 * c.N + l) * B * Hd;
+        a.dc = w.zero_bwd + (size_t)(3 * c.N + l) * B * Hd;
         a.carry = b.take<float>(B * Hd);
         a.dout = b.take<float>(B * Hd);
         w.dec.push_back(a);
@@ -428,6 +432,7 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
     }
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), nullptr, w.emb, 1.f, 0.f, 0, rng, -1, st,
                         up ? w.enc[0].xinp.out() : PlaneOut{}));
+    if (hipMemsetAsync(w.zero_fwd, 0, (size_t)2 * N * c.B * Hd * sizeof(float), st) != hipSuccess) return fail_memset();   // every c_0
     const float* x_in = w.emb;
     for (int l = 0; l < N; ++l) {
         const EncLayerA& a = w.enc[l];
@@ -443,8 +448,7 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
             if (!up) SLNLP_TRY(pl->lin(x_in, in, M, in, pl->P(q.w_ih), in, GH, pl->P(q.b_ih), a.d[d].xproj, GH, 0, nullptr, st));
             // the state chain lives in the per-timestep `hprev` slots: slot of the first processed timestep = h_0 = 0
             const int t0 = d == 0 ? 0 : S - 1;
-            if (hipMemsetAsync(a.d[d].hprev + (long)t0 * B * Hd, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess ||
-                hipMemsetAsync(a.d[d].c, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess)
+            if (hipMemsetAsync(a.d[d].hprev + (long)t0 * B * Hd, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess)
                 return fail_memset();
         }
         const bool last = l == N - 1;
@@ -572,8 +576,8 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
     const unsigned long long* rng = pl->buf.rng;
     const int64_t *X = pl->last_X, *lengths = pl->last_len;
     const float* enc_out = w.enc[N - 1].out;
-    const size_t bh = (size_t)B * Hd * sizeof(float);
 
+    if (hipMemsetAsync(w.zero_bwd, 0, (size_t)4 * N * c.B * Hd * sizeof(float), st) != hipSuccess) return fail_memset();   // dc / dh seeds
     // generator (no bias)
     const float* dec_out = w.dec[N - 1].out;
     SLNLP_TRY(pl->wgr(w.dlogits, Vp, B, c.Vt, dec_out, Hd, Hd, pl->Gd(L.gen_w), Hd, nullptr, st));
@@ -582,8 +586,6 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
     for (int l = N - 1; l >= 0; --l) {
         const RnnW& q = L.dec[l];
         const DecLayerA& a = w.dec[l];
-        if (hipMemsetAsync(a.dh, 0, bh, st) != hipSuccess || hipMemsetAsync(a.dc, 0, bh, st) != hipSuccess)
-            return fail_memset();
         slnlp_rnn_cell_bwd_dir k = {};
         k.dh_state = a.dh; k.dc_state = a.dc; k.dout = a.dout; k.acts = a.acts; k.cprev_save = a.cprev;
         k.hprev_save = a.hprev; k.hn_save = a.hn; k.dgx = a.dgx; k.dgh = a.dgh; k.carry = a.carry;
@@ -629,7 +631,6 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
         const float* x_in = l > 0 ? w.enc[l - 1].out : w.emb;
         for (int d = 0; d < 2; ++d) {
             SLNLP_TRY(add_rows(w.denc_final + (long)l * B * 2 * Hd + d * Hd, 2 * Hd, a.d[d].dh, Hd, B, Hd, 0, st));
-            if (hipMemsetAsync(a.d[d].dc, 0, bh, st) != hipSuccess) return fail_memset();
         }
         const int nsl = pl->kslices(), Ks = GH / nsl;
         for (int step = S - 1; step >= 0; --step) {
