@@ -109,3 +109,15 @@ class EncoderDecoderAttnBase(ArenaModule):
     def extra_repr(self):
         return (f"rnn_type={self.rnn_type}, embedding_size={self.embedding_size}, hidden_size={self.hidden_size}, "
                 f"num_layers={self.num_layers}, dropout={self.dropout_p}, precision={self.precision}")
+
+
+def _recurrent_variant(name, rnn_type, ref):
+    """The reference ships one two-line subclass per cell type (model/encoder_decoder_{lstm,gru}_attn.py); both are generated here."""
+    def __init__(self, **kwargs):
+        EncoderDecoderAttnBase.__init__(self, rnn_type=rnn_type, **kwargs)
+    doc = f"Bastings encoder-decoder with Bahdanau attention over a bidirectional {rnn_type.upper()} ({ref})."
+    return type(name, (EncoderDecoderAttnBase,), {"__init__": __init__, "__doc__": doc, "__module__": __name__})
+
+
+EncoderDecoderLSTMAttn = _recurrent_variant("EncoderDecoderLSTMAttn", "lstm", "/root/reference/model/encoder_decoder_lstm_attn.py:4-6")
+EncoderDecoderGRUAttn = _recurrent_variant("EncoderDecoderGRUAttn", "gru", "/root/reference/model/encoder_decoder_gru_attn.py:4-6")
