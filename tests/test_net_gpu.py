@@ -187,3 +187,21 @@ dataset_args:
     assert set(test_out) == {"test_neg_log_loss", "test_accuracy", "test_f1_weighted"} and all(np.isfinite(v) for v in test_out.values())
     hist = json.load(open(work / "history.json"))
     assert len(hist) == 3 and {"train_f1_weighted", "valid_f1_weighted", "valid_accuracy", "lr"} <= set(hist[0])
+
+
+def test_sharded_grid_concurrent_rnn_fits_equal_sequential():
+    """Same as above for the recurrent models: two GRU fits at a time on two streams == one at a time."""
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV
+    from slnlp.net import NeuralNetClassifier
+    ds = synthetic_dataset(90, seq_len=10, src_vocab=50, n_labels=3, seed=9, min_len=3)
+    factory = lambda: NeuralNetClassifier(
+        module="model.EncoderDecoderGRUAttn", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
+        module__embedding_size=64, module__hidden_size=64, module__num_layers=2, module__dropout=0.1, criterion__ignore_index=1,
+        optimizer__momentum=0.9, lr=0.1, max_epochs=2, batch_size=20, gradient_clipping={"gradient_clip_value": 0.5})
+    pg = {"lr": [0.1, 0.01], "module__hidden_size": [64, 128]}
+    out = []
+    for k in (1, 2):
+        gs = ShardedGridSearchCV(factory, pg, cv=2, refit=False, device="cuda", fits_per_gpu=k).fit(ds)
+        out.append(gs.cv_results_["mean_test_score"])
+    assert np.array_equal(out[0], out[1]) and np.isfinite(out[0]).all()
