@@ -147,10 +147,10 @@ size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k,
 int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, unsigned short* lo, int64_t ldp, hipStream_t st);
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
-              hipStream_t st, PlaneOut po = {});
+              hipStream_t st, PlaneOut po = {}, unsigned char* keep_mask = nullptr);   // keep_mask: [B*S*E/4] bytes or null
 int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
               float scale, int64_t zero_row, float drop_p, int drop_site, const unsigned long long* rng, void* scratch,
-              hipStream_t st);
+              hipStream_t st, const unsigned char* keep_mask = nullptr);   // keep bits recorded by embed_fwd, or null: regenerate
 size_t embed_bwd_scratch_bytes(int B, int S, int E);
 int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,

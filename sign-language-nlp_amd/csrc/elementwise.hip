@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
                                                         const float* __restrict__ pe, float* __restrict__ out,
                                                         float scale, float drop_p, unsigned drop_thr, int drop_site,
                                                         const unsigned long long* __restrict__ rng, long nan_idx,
-                                                        PlaneOut po) {
+                                                        PlaneOut po, unsigned char* __restrict__ keep_mask) {
     const int e4 = E >> 2;
     const long total = (long)B * S * e4;
     const float ik = 1.f / (1.f - drop_p);
@@ -25,10 +25,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
         const float4 p = pe ? *reinterpret_cast<const float4*>(pe + (long)s * E + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = v.x * scale + p.x; v.y = v.y * scale + p.y; v.z = v.z * scale + p.z; v.w = v.w * scale + p.w;
         if (drop_p > 0.f) {
-            v.x = dropout_keep(rng, drop_site, m, c + 0, drop_thr) ? v.x * ik : 0.f;
-            v.y = dropout_keep(rng, drop_site, m, c + 1, drop_thr) ? v.y * ik : 0.f;
-            v.z = dropout_keep(rng, drop_site, m, c + 2, drop_thr) ? v.z * ik : 0.f;
-            v.w = dropout_keep(rng, drop_site, m, c + 3, drop_thr) ? v.w * ik : 0.f;
+            const bool k0 = dropout_keep(rng, drop_site, m, c + 0, drop_thr), k1 = dropout_keep(rng, drop_site, m, c + 1, drop_thr);
+            const bool k2 = dropout_keep(rng, drop_site, m, c + 2, drop_thr), k3 = dropout_keep(rng, drop_site, m, c + 3, drop_thr);
+            v.x = k0 ? v.x * ik : 0.f; v.y = k1 ? v.y * ik : 0.f; v.z = k2 ? v.z * ik : 0.f; v.w = k3 ? v.w * ik : 0.f;
+            // optional 4-bit keep record per float4: the backward of a 2400 x 512 embedding spent 54 us regenerating
+            // these Philox words (one call per element there: its rows are gathered by token id)
+            if (keep_mask) keep_mask[idx] = (unsigned char)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));
         }
         // decoder input token == <pad>: its single self-attention key is masked
         // (transformer.py:72-73) -> softmax over an empty set -> NaN row in torch.
@@ -47,9 +49,14 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
 //           and writes the table row.  Rows of ids that do not occur were zeroed by a memset.
 __device__ __forceinline__ float4 load_dx_row(const float* __restrict__ dx, int t, int E, int c, float drop_p,
                                               float ik, unsigned thr, int site,
-                                              const unsigned long long* __restrict__ rng) {
+                                              const unsigned long long* __restrict__ rng,
+                                              const unsigned char* __restrict__ keep_mask) {
     float4 g = *reinterpret_cast<const float4*>(dx + (long)t * E + c);
-    if (drop_p > 0.f) {
+    if (drop_p > 0.f && keep_mask) {          // keep bits recorded by embed_fwd
+        const unsigned k = keep_mask[((long)t * E + c) >> 2];
+        g.x = (k & 1u) ? g.x * ik : 0.f; g.y = (k & 2u) ? g.y * ik : 0.f;
+        g.z = (k & 4u) ? g.z * ik : 0.f; g.w = (k & 8u) ? g.w * ik : 0.f;
+    } else if (drop_p > 0.f) {
         g.x = dropout_keep(rng, site, t, c + 0, thr) ? g.x * ik : 0.f;
         g.y = dropout_keep(rng, site, t, c + 1, thr) ? g.y * ik : 0.f;
         g.z = dropout_keep(rng, site, t, c + 2, thr) ? g.z * ik : 0.f;
@@ -64,7 +71,8 @@ __global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __rest
                                                               int E, int V, const float* __restrict__ dx,
                                                               float* __restrict__ partial, int* __restrict__ pid,
                                                               float drop_p, unsigned drop_thr, int drop_site,
-                                                              const unsigned long long* __restrict__ rng) {
+                                                              const unsigned long long* __restrict__ rng,
+                                                              const unsigned char* __restrict__ keep_mask) {
     // one workgroup per token: almost all exit at once (not the first of their id in the 64-token chunk); the
     // chunk-first of an id sums the chunk's rows of that id in increasing-m order, all 256 threads across columns
     const int M = B * S, lane = threadIdx.x & 63;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __rest
                 float4 g[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng)
+                    g[u] = k[u] >= 0 ? load_dx_row(dx, m0 + k[u], E, c, drop_p, ik, drop_thr, drop_site, rng, keep_mask)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __res
 
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
-              hipStream_t st, PlaneOut po) {
+              hipStream_t st, PlaneOut po, unsigned char* keep_mask) {
     SLNLP_CHECK_ARG(ids && table && out, "embed_fwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_fwd: bad shape B=%d S=%d E=%d V=%d", B, S, E, V);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_fwd: bad dropout args");
@@ -202,7 +210,7 @@ int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     int grid = ceil_div(total, 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V,
-                       table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx, po);
+                       table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx, po, keep_mask);
     SLNLP_CHECK_LAUNCH("embed_fwd");
     return 0;
 }
@@ -213,7 +221,7 @@ size_t embed_bwd_scratch_bytes(int B, int S, int E) {
 
 int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* dx, float* dtable,
               float scale, int64_t zero_row, float drop_p, int drop_site, const unsigned long long* rng, void* scratch,
-              hipStream_t st) {
+              hipStream_t st, const unsigned char* keep_mask) {
     SLNLP_CHECK_ARG(ids && dx && dtable && scratch, "embed_bwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_bwd: bad shape");
     SLNLP_CHECK_ARG((long)B * S <= 65536, "embed_bwd: more than 65536 tokens per batch");
@@ -226,7 +234,7 @@ int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     float* partial = (float*)scratch;
     int* pid = (int*)(partial + (size_t)M * E);
     hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3(M), dim3(256), 0, st, (const long*)ids,
-                       (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng);
+                       (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng, keep_mask);
     SLNLP_CHECK_LAUNCH("embed_bwd_chunk");
     hipLaunchKernelGGL(embed_bwd_combine_kernel, dim3(M), dim3(256), 0, st, pid, M, E, partial, dtable, scale);
     SLNLP_CHECK_LAUNCH("embed_bwd_combine");

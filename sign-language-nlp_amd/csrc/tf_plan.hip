@@ -163,6 +163,7 @@ struct Ws {
     std::vector<DecA> dec;
     float *gfin, *gtl, *gmem, *gxl;     // d tfin, d t_last, d memory, d x_last
     void *emb_scratch_src, *emb_scratch_tgt;
+    unsigned char* emb_keep;   // 4 keep bits per float4 of the source embedding's dropout (read by its backward)
     PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
     char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
     float* opt_partials;
@@ -263,6 +264,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     w.gxl = b.take<float>(M * E);
     w.emb_scratch_src = b.take<char>(embed_bwd_scratch_bytes(c.B, c.S, c.E));
     w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
+    w.emb_keep = b.take<unsigned char>(M * E / 4);
     w.opt_partials = b.take<float>(1024);
     w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
     // ---- bf16 operand planes (only used when E and F are multiples of 64)
@@ -605,7 +607,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         SLNLP_TRY(split_planes(pl->buf.params, L.total, 1, (int)L.total, w.wp.hi, w.wp.lo, L.total, st));
     }
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st,
-                        up ? w.x0p.out() : PlaneOut{}));
+                        up ? w.x0p.out() : PlaneOut{}, w.emb_keep));
     SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st));
 
     const float* x = w.x0;
@@ -826,7 +828,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         }
         dx = a.gx0;
     }
-    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st));
+    SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st, w.emb_keep));
     SLNLP_TRY(pl->join_all(st));
     SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
     return 0;
