@@ -341,7 +341,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
                 out["grid"] = grid_folds_per_hour(dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))
             out["gpu_over_cpu"] = round(out["value"] / world / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
