@@ -302,58 +302,98 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
     float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng, float* __restrict__ partial, PlaneOut po_dx, PlaneOut po_drop) {
+    const unsigned long long* __restrict__ rng, float* __restrict__ partial, PlaneOut po_dx, PlaneOut po_drop, int gs) {
+    // gs = 4 (many rows): one wave per group of 4 CONSECUTIVE rows: the loads of all four rows are issued together (one memory round trip
+    // instead of four), and the dropout mask of the group costs one Philox call per column -- its four words are the
+    // four rows' bits (common.hpp) -- instead of one per element.  gs = 1 (the decoder's B rows): one row per wave, so
+    // that the few rows spread over as many waves as possible.
     __shared__ float red[4][2][LN_MAXU * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 dg[LN_MAXU], db[LN_MAXU];
 #pragma unroll
     for (int u = 0; u < LN_MAXU; ++u) dg[u] = db[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-        const float* xr = x + (long)row * E;
-        const float* gr = dy + (long)row * E;
-        float s1 = 0.f, s2 = 0.f;
-        float4 gv[LN_MAXU], xh[LN_MAXU];
+    const bool drop = dx_drop != nullptr && drop_p > 0.f;
+    const int ngrp = (rows + gs - 1) / gs;
+    for (int grp = blockIdx.x * 4 + wave; grp < ngrp; grp += gridDim.x * 4) {
+        const int row0 = grp * gs;
+        float4 d[4][LN_MAXU], v[4][LN_MAXU], g[LN_MAXU];
+        float mean[4], rstd[4];
 #pragma unroll
-        for (int u = 0; u < LN_MAXU; ++u) {
-            const int c = lane * 4 + u * 256;
-            if (c < E) {
-                const float4 d = *reinterpret_cast<const float4*>(gr + c);
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-                xh[u] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-                gv[u] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-                s1 += gv[u].x + gv[u].y + gv[u].z + gv[u].w;
-                s2 += gv[u].x * xh[u].x + gv[u].y * xh[u].y + gv[u].z * xh[u].z + gv[u].w * xh[u].w;
-                dg[u].x += d.x * xh[u].x; dg[u].y += d.y * xh[u].y; dg[u].z += d.z * xh[u].z; dg[u].w += d.w * xh[u].w;
-                db[u].x += d.x; db[u].y += d.y; db[u].z += d.z; db[u].w += d.w;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= gs) break;
+            const int row = row0 + i < rows ? row0 + i : rows - 1;           // clamped: the tail rows are masked below
+            mean[i] = stats[2 * row];
+            rstd[i] = stats[2 * row + 1];
+#pragma unroll
+            for (int u = 0; u < LN_MAXU; ++u) {
+                const int c = lane * 4 + u * 256;
+                if (c < E) {
+                    d[i][u] = *reinterpret_cast<const float4*>(dy + (long)row * E + c);
+                    v[i][u] = *reinterpret_cast<const float4*>(x + (long)row * E + c);
+                }
             }
         }
-        s1 = wave_sum(s1) * invE;
-        s2 = wave_sum(s2) * invE;
 #pragma unroll
-        for (int u = 0; u < LN_MAXU; ++u) {
-            const int c = lane * 4 + u * 256;
-            if (c < E) {
-                float4 o;
-                o.x = rstd * (gv[u].x - s1 - xh[u].x * s2); o.y = rstd * (gv[u].y - s1 - xh[u].y * s2);
-                o.z = rstd * (gv[u].z - s1 - xh[u].z * s2); o.w = rstd * (gv[u].w - s1 - xh[u].w * s2);
-                if (add_to_dx) {
-                    const float4 a = *reinterpret_cast<const float4*>(add_to_dx + (long)row * E + c);
-                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        for (int u = 0; u < LN_MAXU; ++u)
+            if (lane * 4 + u * 256 < E) g[u] = *reinterpret_cast<const float4*>(gamma + lane * 4 + u * 256);
+        uint4 kb[LN_MAXU][4];
+        if (drop) {
+#pragma unroll
+            for (int u = 0; u < LN_MAXU; ++u)
+                if (lane * 4 + u * 256 < E) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kb[u][e] = dropout_bits4(rng, drop_site, (unsigned)row0 >> 2, (unsigned)(lane * 4 + u * 256 + e));
                 }
-                *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
-                store_planes4(po_dx, (long)row * E + c, o);
-                if (dx_drop) {
-                    if (drop_p > 0.f) {
-                        o.x = dropout_keep(rng, drop_site, row, c + 0, drop_thr) ? o.x * ik : 0.f;
-                        o.y = dropout_keep(rng, drop_site, row, c + 1, drop_thr) ? o.y * ik : 0.f;
-                        o.z = dropout_keep(rng, drop_site, row, c + 2, drop_thr) ? o.z * ik : 0.f;
-                        o.w = dropout_keep(rng, drop_site, row, c + 3, drop_thr) ? o.w * ik : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= gs) break;
+            const int row = row0 + i;
+            const int wsel = row & 3;                                         // which Philox word is this row's
+            const bool live = row < rows;                                     // wave-uniform
+            float s1 = 0.f, s2 = 0.f;
+            float4 gv[LN_MAXU], xh[LN_MAXU];
+#pragma unroll
+            for (int u = 0; u < LN_MAXU; ++u) {
+                if (lane * 4 + u * 256 < E) {
+                    const float4 dd = d[i][u], vv = v[i][u];
+                    xh[u] = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
+                    gv[u] = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
+                    s1 += gv[u].x + gv[u].y + gv[u].z + gv[u].w;
+                    s2 += gv[u].x * xh[u].x + gv[u].y * xh[u].y + gv[u].z * xh[u].z + gv[u].w * xh[u].w;
+                    if (live) {
+                        dg[u].x += dd.x * xh[u].x; dg[u].y += dd.y * xh[u].y; dg[u].z += dd.z * xh[u].z; dg[u].w += dd.w * xh[u].w;
+                        db[u].x += dd.x; db[u].y += dd.y; db[u].z += dd.z; db[u].w += dd.w;
                     }
-                    *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
-                    store_planes4(po_drop, (long)row * E + c, o);
+                }
+            }
+            s1 = wave_sum(s1) * invE;
+            s2 = wave_sum(s2) * invE;
+            if (!live) continue;
+#pragma unroll
+            for (int u = 0; u < LN_MAXU; ++u) {
+                const int c = lane * 4 + u * 256;
+                if (c < E) {
+                    float4 o;
+                    o.x = rstd[i] * (gv[u].x - s1 - xh[u].x * s2); o.y = rstd[i] * (gv[u].y - s1 - xh[u].y * s2);
+                    o.z = rstd[i] * (gv[u].z - s1 - xh[u].z * s2); o.w = rstd[i] * (gv[u].w - s1 - xh[u].w * s2);
+                    if (add_to_dx) {
+                        const float4 a = *reinterpret_cast<const float4*>(add_to_dx + (long)row * E + c);
+                        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                    }
+                    *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
+                    store_planes4(po_dx, (long)row * E + c, o);
+                    if (dx_drop) {
+                        if (drop) {
+                            o.x = pick_word(kb[u][0], wsel) >= drop_thr ? o.x * ik : 0.f;
+                            o.y = pick_word(kb[u][1], wsel) >= drop_thr ? o.y * ik : 0.f;
+                            o.z = pick_word(kb[u][2], wsel) >= drop_thr ? o.z * ik : 0.f;
+                            o.w = pick_word(kb[u][3], wsel) >= drop_thr ? o.w * ik : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
+                        store_planes4(po_drop, (long)row * E + c, o);
+                    }
                 }
             }
         }
@@ -415,8 +455,10 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, int row
     return 0;
 }
 
+static int ln_bwd_group(int rows) { return rows >= 1024 ? 4 : 1; }   // rows per wave
+
 int ln_bwd_blocks(int rows) {
-    int n = ceil_div(rows, 4);
+    int n = ceil_div(rows, 4 * ln_bwd_group(rows));   // a block is 4 waves
     return n > SLNLP_LN_MAX_PARTIALS ? SLNLP_LN_MAX_PARTIALS : n;
 }
 
@@ -433,7 +475,7 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
     const int nblk = nblk_force ? nblk_force : ln_bwd_blocks(rows);
     if (nblk_out) *nblk_out = nblk;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, x, gamma, stats, rows, E, add_to_dx, dx,
-                       dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop);
+                       dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop, ln_bwd_group(rows));
     SLNLP_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
