@@ -1,0 +1,150 @@
+// What bounds one K-step of the plane GEMM's operand ring on MI355X?  A workgroup of 8 waves streams STEPS stages
+// of PIECES KiB-per-wave pieces through an S-deep LDS ring with the GEMM's synchronisation (counted vmcnt + one
+// barrier per step) but no MFMA work: per-step time as a function of ring depth, stage size, workgroups per CU and
+// where the data lives (a footprint that fits the L2s / MALL / only HBM).  Also the same ring through VGPRs
+// (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/dma_ring.hip -o tools/micro/dma_ring
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <initializer_list>
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef __attribute__((address_space(1))) const void* glb_vp;
+
+// every workgroup walks its own contiguous run of the buffer (wrapping inside `foot` bytes)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// CONSUME: 0 = touch one word per lane, 1 = the GEMM's fragment reads (8 x ds_read_b128 per wave and 32 KiB stage),
+//          2 = reads + the 12 MFMAs they feed (split-bf16, 3 passes, 2x2 quadrant)
+// ORDER: 0 = refill the ring, then consume; 1 = consume, then refill; 2 = one DMA piece after every MFMA group
+template <int S, int PIECES, bool DMA, int CONSUME = 0, int ORDER = 0>
+__global__ __launch_bounds__(512) void ring_kernel(const char* __restrict__ buf, size_t foot, int steps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = PIECES * 8 * 1024;       // bytes per stage (8 waves x PIECES KiB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = ((size_t)blockIdx.x * steps * STAGE) % foot;
+    float acc = 0.f;
+    f32x4 macc[2][2] = {};
+    float4 regs[S][PIECES];
+    auto issue = [&](int t, int stage, int slot) {
+        size_t off = base + (size_t)t * STAGE;
+        if (off + STAGE > foot) off %= (foot - STAGE + 1), off &= ~(size_t)1023;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            const char* src = buf + off + (size_t)(p * 8 + wave) * 1024 + lane * 16;
+            char* dst = smem + stage * STAGE + (p * 8 + wave) * 1024;
+            if (DMA) __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)dst, 16, 0, 0);
+            else regs[slot][p] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    for (int t = 0; t < S - 1; ++t) issue(t, t, t);
+#pragma unroll 1
+    for (int t0 = 0; t0 < steps; t0 += S) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {            // unrolled by the ring depth so that stage / slot indices are static
+            const int t = t0 + u;
+            if (DMA) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PIECES) : "memory");
+            } else {                              // the register path: the oldest slot has landed -> write it to LDS
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PIECES) : "memory");
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p)
+                    *reinterpret_cast<float4*>(smem + u * STAGE + (p * 8 + wave) * 1024 + lane * 16) = regs[u][p];
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // the stage consumed in the previous step is free once every wave has passed this barrier: it may be
+            // refilled before, after or in between this step's fragment reads / MFMAs
+            const int tn = t + S - 1, sn = (u + S - 1) % S;
+            auto issue_piece = [&](int p) {
+                const int tt = tn < steps ? tn : 0;
+                size_t off = base + (size_t)tt * STAGE;
+                if (off + STAGE > foot) off %= (foot - STAGE + 1), off &= ~(size_t)1023;
+                const char* src = buf + off + (size_t)(p * 8 + wave) * 1024 + lane * 16;
+                char* dst = smem + sn * STAGE + (p * 8 + wave) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)dst, 16, 0, 0);
+            };
+            if (ORDER == 0) issue(tn < steps ? tn : 0, sn, sn);
+            if (CONSUME == 0) {
+                acc += *reinterpret_cast<const float*>(smem + u * STAGE + ((threadIdx.x * 16) % STAGE));
+            } else {
+                bf16x8 f[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)      // conflict-free: a wave reads 1 KiB contiguous
+                    f[i] = *reinterpret_cast<const bf16x8*>(smem + u * STAGE + ((i * 4096 + wave * 1024 + lane * 16) % STAGE));
+                if (CONSUME == 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(f[i]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            macc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[4 + i], f[2 + j], macc[i][j], 0, 0, 0);
+                            macc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i], f[6 + j], macc[i][j], 0, 0, 0);
+                            macc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i], f[2 + j], macc[i][j], 0, 0, 0);
+                            if (ORDER == 2 && i * 2 + j < PIECES) issue_piece(i * 2 + j);
+                        }
+                }
+            }
+            if (ORDER == 1) issue(tn < steps ? tn : 0, sn, sn);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CONSUME == 2) acc += macc[0][0][0] + macc[0][1][1] + macc[1][0][2] + macc[1][1][3];
+    if (acc == 1.2345f) sink[0] = acc;
+}
+
+template <int S, int PIECES, bool DMA, int CONSUME = 0, int ORDER = 0>
+static void run(const char* buf, size_t foot, int grid, float* sink, const char* where) {
+    const int nsteps = 48;                       // a multiple of every ring depth used below
+    const size_t lds = (size_t)S * PIECES * 8 * 1024;
+    hipFuncSetAttribute((const void*)ring_kernel<S, PIECES, DMA, CONSUME, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((ring_kernel<S, PIECES, DMA, CONSUME, ORDER>), dim3(grid), dim3(512), lds, 0, buf, foot, nsteps, sink);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double us = best * 1e3, bytes = (double)grid * nsteps * PIECES * 8192.0;
+    printf("%-4s %s consume %d order %d ring %d x %2d KiB  grid %4d : %7.2f us  %6.3f us/step  %7.1f GB/s  (%5.1f GB/s per workgroup)\n", where,
+           DMA ? "dma" : "reg", CONSUME, ORDER, S, PIECES * 8, grid, us, us / nsteps, bytes / us * 1e-3, bytes / us * 1e-3 / grid);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+int main(int argc, char**) {
+    const size_t cap = (size_t)1 << 30;
+    char* buf; float* sink;
+    if (hipMalloc(&buf, cap) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(buf, 1, cap);
+    struct { const char* name; size_t foot; } places[] = {{"L2", (size_t)2 << 20}, {"MALL", (size_t)96 << 20}, {"HBM", cap}};
+    const int nplaces = argc > 1 ? 3 : 2;
+    const bool full = argc > 1;
+    for (int ip = 0; ip < nplaces; ++ip) {
+        auto& pl = places[ip];
+        for (int grid : {64, 256, 512}) {
+            run<2, 4, true, 0>(buf, pl.foot, grid, sink, pl.name);
+            run<2, 4, true, 2, 0>(buf, pl.foot, grid, sink, pl.name);
+            run<2, 4, true, 2, 2>(buf, pl.foot, grid, sink, pl.name);
+            run<3, 4, true, 2, 0>(buf, pl.foot, grid, sink, pl.name);
+            run<3, 4, true, 2, 1>(buf, pl.foot, grid, sink, pl.name);
+            run<3, 4, true, 2, 2>(buf, pl.foot, grid, sink, pl.name);
+            run<4, 4, true, 2, 1>(buf, pl.foot, grid, sink, pl.name);
+            run<4, 4, true, 2, 2>(buf, pl.foot, grid, sink, pl.name);
+            if (!full) continue;
+            run<4, 4, true>(buf, pl.foot, grid, sink, pl.name);
+            run<4, 2, true>(buf, pl.foot, grid, sink, pl.name);
+            run<6, 2, true>(buf, pl.foot, grid, sink, pl.name);
+            run<2, 4, false>(buf, pl.foot, grid, sink, pl.name);
+            run<3, 4, false>(buf, pl.foot, grid, sink, pl.name);
+        }
+    }
+    hipError_t e = hipDeviceSynchronize();
+    printf("status: %s\n", hipGetErrorString(e));
+    return e != hipSuccess;
+}
