@@ -75,7 +75,7 @@ def build_sd(c, seed):
     return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
 
 
-def dominant_kernel_roofline(c, precision, dev):
+def dominant_kernel_roofline(c, precision, dev, workload):
     """The step's dominant kernel on its own: one grouped plane-GEMM launch = data gradient + weight gradient of
     one [B*S, E] dY against a [E, F] weight (FFN / out-proj pair of the encoder backward; 18 of them per cfg2 step
     plus 6 larger in_proj ones = ~45 % of the step's GPU time).  Timed live with HIP events on the launch stream."""
@@ -105,10 +105,14 @@ def dominant_kernel_roofline(c, precision, dev):
     us = e0.elapsed_time(e1) / n * 1e3
     flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the 3 split-bf16 MFMA passes are not counted)
     tf = flops / (us * 1e-6) / 1e12
-    return {"kernel": f"gemm_planes_kernel<{precision}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}",
+    blocks = tw * split + td
+    return {"kernel": f"gemm_planes_kernel<{precision}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {blocks} workgroups",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "us_per_launch_hip_events": round(us, 2),
-            "flops_per_launch": flops, "note": "back-to-back launches on one stream; includes launch gaps"}
+            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}> x{blocks}"),
+            "us_per_launch_hip_events": round(us, 2), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * (M * E + M * F + E * F) + 4.0 * (M * F + E * F) + 4.0 * M * F,
+            "note": "back-to-back launches on one stream (includes launch gaps); flops = 2 GEMMs x 2mnk, the 3 split-bf16 "
+                    "MFMA passes are not counted; bytes = operand planes (hi+lo) read once + fp32 results + result planes"}
 
 
 def concurrent_fits(c, precision, dev, k=4, steps=40):
@@ -167,6 +171,16 @@ def grid_folds_per_hour(dev, fits_per_gpu=4):
     return {"value": round(gs.n_tasks_ / dt * 3600.0, 0), "unit": "folds/hr", "fits": gs.n_tasks_, "seconds": round(dt, 2),
             "fits_per_gpu": fits_per_gpu,
             "sample": "6 candidates (lr x embedding_size) x cv 2, 10 epochs, 2000 samples; E128/E512 N2 H4 F256"}
+
+
+def pmc_kernel_traffic(workload, shape):
+    """HBM bytes of one launch of `shape` ("kernel xWORKGROUPS") from the same committed PMC passes, or None."""
+    f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}_step_traffic.json")
+    try:
+        e = json.load(open(f))["per_launch"][shape]
+        return float(e["fetch_bytes"] + e["write_bytes"])
+    except Exception:
+        return None
 
 
 def pmc_traffic(workload):
@@ -327,20 +341,21 @@ def main():
                                    f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
                        "launch": launch_used, "per_gpu": "independent fit (grid shard)" + (f"; REHEARSAL: {world} ranks share {ndev} GPU(s)" if shared else "")},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload),
-                         "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
-                         "ms_per_launch_hip_events": round(ms_event, 4)},
+            "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload),
+                              "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
+                              "ms_per_launch_hip_events": round(ms_event, 4)},
             "parity": parity, "final_loss": round(loss_end, 5),
         }
         if "rnn" not in c:
             with torch.cuda.stream(stream):
-                dk = dominant_kernel_roofline(c, args.precision, dev)
+                dk = dominant_kernel_roofline(c, args.precision, dev, args.workload)
             if dk:
-                out["roofline_dominant_kernel"] = dk
+                out["roofline"] = dk
             if world == 1 and not args.no_cpu_baseline:
                 out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
                 out["grid"] = grid_folds_per_hour(dev)
+        out.setdefault("roofline", dict(out["roofline_step"]))   # RNN workloads: no single dominant GEMM, the step is the unit
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))
             out["gpu_over_cpu"] = round(out["value"] / world / out["cpu_baseline"]["value"], 1)
