@@ -28,6 +28,7 @@ from pydoc import locate
 import numpy as np
 import torch
 
+from . import metrics
 from .data import TokenDataset
 
 
@@ -177,6 +178,8 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         if va is not None:
             Xva, Lva, yva = self._device_data(va)
         wrappers = [ScoringWrapper(s, labels) for s in (self.scoring or [])]
+        # the fast metrics index the probability columns by class id: valid when the labels are exactly the columns
+        fast_ok = labels is not None and list(labels) == list(range(len(self.classes_)))
         es, clip, sched = self.early_stopping, self.gradient_clipping, self.lr_scheduler
         max_norm = float(clip["gradient_clip_value"]) if clip and clip.get("gradient_clip_value") else 0.0
         momentum = float(self._opt_kwargs.get("momentum", 0.0))
@@ -200,10 +203,20 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                     row["valid_loss"] = va_loss
                     row["valid_loss_best"] = bool(va_loss < best_valid)
                     best_valid = min(best_valid, va_loss)
-                for wr in wrappers:                              # EpochScoring on cached predictions
-                    row[f"train_{wr.score}"] = float(wr(_CachedPredictor(np.exp(tr_logp), self.classes_), None, tr.y))
-                    if va is not None:
-                        row[f"valid_{wr.score}"] = float(wr(_CachedPredictor(np.exp(va_logp), self.classes_), None, va.y))
+                # EpochScoring on the epoch's cached predictions: the reference's five metrics from one device-side
+                # reduction (slnlp/metrics.py, same numbers as the sklearn scorers); anything else through sklearn
+                splits = [("train", tr_logp, ytr, tr)] + ([("valid", va_logp, yva, va)] if va is not None else [])
+                names = [wr.score for wr in wrappers]
+                fast = {sp: metrics.epoch_scores(names, lp, yd, part.y) if fast_ok and names else {} for sp, lp, yd, part in splits}
+                proba = {}
+                for wr in wrappers:
+                    for sp, lp, yd, part in splits:
+                        if wr.score in fast[sp]:
+                            row[f"{sp}_{wr.score}"] = fast[sp][wr.score]
+                            continue
+                        if sp not in proba:
+                            proba[sp] = np.exp(lp.cpu().numpy())
+                        row[f"{sp}_{wr.score}"] = float(wr(_CachedPredictor(proba[sp], self.classes_), None, part.y))
                 row["dur"] = time.time() - t0
                 self.history.append(row)
                 if self.verbose:
@@ -247,7 +260,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                 g["lr"] = self.lr_
 
     def _run_epoch(self, X, L, y, bs, train, momentum, max_norm):
-        """One pass in dataset order.  Returns (sample-weighted mean loss, log-probs [N,V] numpy)."""
+        """One pass in dataset order.  Returns (sample-weighted mean loss, log-probs [N,V] on the device)."""
         n = X.shape[0]
         losses, sizes, outs = [], [], []
         for i in range(0, n, bs):
@@ -277,7 +290,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             outs.append(logp.detach().clone())
         w = torch.tensor(sizes, dtype=torch.float32, device=X.device)
         mean = float((torch.stack(losses).float() * w).sum() / w.sum())      # one sync per epoch
-        return mean, torch.cat(outs).cpu().numpy()
+        return mean, torch.cat(outs)
 
     # --------------------------------------------------------------- predict
     def predict_proba(self, X):

@@ -110,3 +110,27 @@ def test_split_is_torch_random_split(tmp_path):
     test, train = ds.split(0.15, seed=1)
     perm = torch.randperm(40, generator=torch.Generator().manual_seed(1)).numpy()           # asl_dataset.py:240-244
     assert len(test) == 6 and np.array_equal(test.ids, ds.ids[perm[:6]]) and np.array_equal(train.y, ds.y[perm[6:]])
+
+
+def test_fast_epoch_metrics_equal_the_sklearn_scorers():
+    """slnlp/metrics.py forms the reference's five EpochScoring metrics (config-transformer.yaml:9) from a per-sample
+    reduction; the numbers must be the ones the sklearn scorers (helper.py:529-554 wrapper) return."""
+    import warnings
+    import torch
+    from slnlp import metrics
+    from slnlp.net import ScoringWrapper, _CachedPredictor
+    for seed, (N, V) in enumerate([(3000, 202), (37, 16), (500, 202)]):
+        rng = np.random.RandomState(seed)
+        y = rng.randint(2, V, N)
+        logits = (rng.randn(N, V) * 3).astype(np.float32)
+        logits[np.arange(N)[::3], y[::3]] += 6.0                        # a third of the samples classified correctly
+        logp = torch.log_softmax(torch.from_numpy(logits), -1)
+        if seed == 1:                                                   # p == 1 and p == 0: both clip bounds of log_loss
+            logp[0, :] = -1e3
+            logp[0, 3] = 0.0
+        fast = metrics.epoch_scores(list(metrics.FAST), logp, torch.from_numpy(y))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for name in metrics.FAST:
+                ref = float(ScoringWrapper(name, list(range(V)))(_CachedPredictor(np.exp(logp.numpy()), np.arange(V)), None, y))
+                assert fast[name] == ref, (name, fast[name], ref)
