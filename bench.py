@@ -194,8 +194,20 @@ def pmc_traffic(workload):
         return None
 
 
+def cpu_parity(c, sd, Xe, ye, Le, logp_gpu):
+    """CPU leg, part 1 (the checker): the oracle's eval-mode log-probs for one held-out batch against the HIP path's --
+    the "top-1 vs ref" half of BASELINE.json's metric.  With cpu_baseline() below, the only place bench.py touches oracle/."""
+    from oracle import rnn_ref, transformer_ref as tr
+    if "rnn" in c:
+        lo = rnn_ref.forward(sd, Xe, ye, Le, rnn_type=c["rnn"], num_layers=c["N"])
+    else:
+        lo = tr.forward(sd, Xe, ye, num_heads=c["H"], num_layers=c["N"])
+    return {"argmax_agree": float((logp_gpu.argmax(-1) == lo.argmax(-1)).float().mean()),
+            "logp_rel_err": float((logp_gpu - lo).abs().max() / lo.abs().max())}
+
+
 def cpu_baseline(c, sd, X, y, Ln, budget_s=20.0):
-    """The oracle (CPU port of the reference step) timed on this host's cores on a bounded sample."""
+    """CPU leg, part 2: the oracle (CPU port of the reference step) timed on this host's cores on a bounded sample."""
     from oracle import rnn_ref, train_ref, transformer_ref as tr
     # the GPU box gives this process a CPU share (16 cores per GPU), not the whole host
     cores = min(len(os.sched_getaffinity(0)), 16)
@@ -316,21 +328,17 @@ def main():
         ms_event = ev_ms / args.steps           # HIP events on the launch stream, rank 0
         achieved = step_flops / (ms_event * 1e-3) / 1e12
         # parity on a held-out batch (eval mode) against the CPU oracle
-        from oracle import rnn_ref, transformer_ref as tr
         cfg0, sd0 = build_sd(c, seed=1)
         Xe, ye, Le = torch.from_numpy(Xn[:B]), torch.from_numpy(yn[:B]), torch.from_numpy(Ln[:B])
         if "rnn" in c:
             e2 = re_.RnnEngine(cfg0, device=dev)
             e2.load_state(sd0)
             lp = e2.forward(Xe.to(dev), ye.to(dev), Le.to(dev)).cpu()
-            lo = rnn_ref.forward(sd0, Xe, ye, Le, rnn_type=c["rnn"], num_layers=c["N"])
         else:
             e2 = te.TransformerEngine(cfg0, device=dev)
             e2.load_state(sd0)
             lp = e2.forward(Xe.to(dev), ye.to(dev)).cpu()
-            lo = tr.forward(sd0, Xe, ye, num_heads=c["H"], num_layers=c["N"])
-        parity = {"argmax_agree": float((lp.argmax(-1) == lo.argmax(-1)).float().mean()),
-                  "logp_rel_err": float((lp - lo).abs().max() / lo.abs().max())}
+        parity = cpu_parity(c, sd0, Xe, ye, Le, lp)
         out = {
             "metric": f"train seq/s (batch={B},len={S})", "value": round(seqs / wall, 1), "unit": "seq/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
