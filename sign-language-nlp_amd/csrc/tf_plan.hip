@@ -355,6 +355,8 @@ struct slnlp_tf_plan {
         return 0;
     }
 
+    int dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const;
+
     // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
     int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
                float p, int site, const float* resid, hipStream_t st, int drop_head_dim = 0) const {
@@ -592,6 +594,23 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
 
 }  // extern "C"
 
+// Decoder layer l up to its cross-attention query: self-attention over ONE key (softmax == 1 -> out_proj(v_proj(t));
+// the q/k rows of in_proj are dead; in train mode the weight-1 "attention" is still dropped per (row, head) -- fused into
+// the V projection), residual + norm1, then q = in_proj_q(t1) (transformer.py:82-87).
+int slnlp_tf_plan::dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const {
+    const slnlp_tf_plan* pl = this;
+    const int E = cfg.E, dh = E / cfg.H;
+    const unsigned long long* rng = buf.rng;
+    (void)rng;
+    const DecP& q = L.dec[l];
+    const DecA& a = w.dec[l];
+    SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, st, dh));
+    SLNLP_TRY(pl->linear(a.v, B, E, pl->P(q.sout_w), E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, st));
+    SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
+    SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st));
+    return 0;
+}
+
 int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
                                 bool defer_join) {
     slnlp_tf_plan* pl = this;
@@ -601,6 +620,12 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     const unsigned long long* rng = pl->buf.rng;
     pl->last_B = B; pl->last_p = p; pl->last_X = X; pl->last_y = y;
 
+    // The target side up to the first cross-attention (embedding, layer 0's single-key self-attention block and its
+    // query projection: five B-row launches) depends on nothing the encoder computes: it runs on side[1] next to the
+    // encoder and is joined right before layer 0's cross-attention.
+    SLNLP_TRY(fork(st, 1));
+    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, side[1]));
+    SLNLP_TRY(dec_self_block(0, w.t0, B, p, side[1]));
     const bool up = use_planes;
     if (up) {   // weights as bf16 planes, once per forward (they changed in the optimizer step / load_state_dict)
         SLNLP_TRY(prepare_planes(B, st));
@@ -608,7 +633,6 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     }
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st,
                         up ? w.x0p.out() : PlaneOut{}, w.emb_keep));
-    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st));
 
     const float* x = w.x0;
     const PP* xp = &w.x0p;
@@ -658,13 +682,8 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
-        // self-attention over ONE key: softmax == 1 -> out_proj(v_proj(t)); q/k rows of in_proj are dead
-        // (train mode: the weight-1 "attention" is still dropped per (row, head) -- fused into the V projection)
-        SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, st, dh));
-        SLNLP_TRY(pl->linear(a.v, B, E, pl->P(q.sout_w), E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, st));
-        SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
-        // cross-attention: q from tgt, k|v from memory, no masks (transformer.py:82-87)
-        SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st));
+        if (l == 0) SLNLP_TRY(join(st, 1));                     // layer 0's block ran on side[1] (above)
+        else SLNLP_TRY(dec_self_block(l, t, B, p, st));
         if (hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
             set_error("tf_forward: wait for K/V projection failed");
             return SLNLP_ERR_LAUNCH;
@@ -763,22 +782,27 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         }
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b)),
                                  pl->dgrad_args(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2), st));
-        // norm1 / self-attention (single key)
+        // norm1 / self-attention (single key).  For layer 0 nothing downstream on the main stream needs these (they end
+        // in weight gradients and the target-embedding gradient): they go to side[1] while the encoder backward starts.
+        hipStream_t sb = st;
+        if (l == 0) {
+            SLNLP_TRY(pl->fork(st, 1));
+            sb = s1;
+        }
         SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
-                                pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, st));
+                                pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, sb));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
         {
             slnlp_gemm_args dg = pl->dgrad_args(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr);
             if (p > 0.f) { dg.drop_p = p; dg.drop_site = pl->dec_site(l, 0); dg.rng = rng; dg.drop_head_dim = dh; }   // same mask as forward
-            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b)), dg, st));
+            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, B, E, a.v, E, pl->G(q.sout_w), pl->G(q.sout_b)), dg, sb));
         }
         // softmax over one element has zero gradient: the q/k rows of in_proj (weight and bias) get exactly 0.
         // Nothing ever writes them, and the gradient arena is zeroed at plan creation, so they stay zero.
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gv, E, B, E, t_in, E, pl->G(q.sin_w) + 2L * E * E, pl->G(q.sin_b) + 2 * E),
-                                 pl->dgrad_args(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1), st));
+                                 pl->dgrad_args(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1), sb));
         dt = a.gt0;
     }
-    SLNLP_TRY(pl->fork(st, 1));
     SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s1));
 
     // encoder: needs the complete d memory
