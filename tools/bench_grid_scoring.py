@@ -10,7 +10,7 @@ warnings.filterwarnings("ignore")
 SCORING = ["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"]
 ds = synthetic_dataset(2000, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8)
 for scoring in (None, SCORING):
-    for k in (1, 4):
+    for k in (1, 2, 3, 4, 6):
         factory = lambda: NeuralNetClassifier(
             module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
             module__embedding_size=128, module__num_heads=4, module__num_layers=2, module__hidden_size=256, module__dropout=0.1,
