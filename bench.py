@@ -109,7 +109,7 @@ def dominant_kernel_roofline(c, precision, dev, workload):
     return {"kernel": f"gemm_planes_kernel<{precision}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {blocks} workgroups",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}> x{blocks}"),
-            "us_per_launch_hip_events": round(us, 2), "flops_per_launch": flops,
+            "us_per_launch_hip_events": round(us, 2), "us_per_launch_rocprof": rocprof_kernel_times(workload), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * (M * E + M * F + E * F) + 4.0 * (M * F + E * F) + 4.0 * M * F,
             "note": "back-to-back launches on one stream (includes launch gaps); flops = 2 GEMMs x 2mnk, the 3 split-bf16 "
                     "MFMA passes are not counted; bytes = operand planes (hi+lo) read once + fp32 results + result planes"}
@@ -173,6 +173,16 @@ def grid_folds_per_hour(dev, fits_per_gpu=4):
             "fits_per_gpu": fits_per_gpu,
             "sample": "6 candidates (lr x embedding_size) x cv 2, 10 epochs, 2000 samples, 80/20 train/valid split inside each "
                       "fit, the reference's 5 epoch metrics on both; E128/E512 N2 H4 F256"}
+
+
+def rocprof_kernel_times(workload):
+    """The committed rocprofv3 --kernel-trace view of the same kernel (tools/roofline_kernel_stats.py): its back-to-back
+    launches (what the HIP events above time) and its launches inside train steps, or None."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", f"r01_bench_{workload}_roofline_kernel.json")))
+        return {"back_to_back_avg_us": e["back_to_back"]["avg_us"], "in_step_avg_us": e["in_step"]["avg_us"], "min_us": e["min_us"]}
+    except Exception:
+        return None
 
 
 def pmc_kernel_traffic(workload, shape):
