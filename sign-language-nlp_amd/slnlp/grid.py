@@ -1,32 +1,42 @@
 """Cross-validated grid search sharded over the GPUs of one node.
 
 The reference farms the (candidate x fold) fits of ``GridSearchCV`` out to dask
-workers, one per GPU, pickling the whole dataset with every task
-(/root/reference/main.py:62-95, helper.py:108-180, 490-526; 324 candidates x 5
-folds for config-transformer.yaml).  Here: one process per GPU
-(``torch.distributed``, RCCL on GPUs / gloo in CPU tests);
+workers, one per GPU, pickling the whole dataset with every task; dask hands a
+worker its next task when it falls idle (/root/reference/main.py:62-95,
+helper.py:108-180, 490-526; 324 candidates x 5 folds for config-transformer.yaml).
+Here: one process per GPU (``torch.distributed``, RCCL on GPUs / gloo in CPU tests);
 
 * rank 0 broadcasts the integer dataset ONCE (``X[N,S]``, ``lengths[N]``, ``y[N]``),
-* every rank derives the identical task list (``ParameterGrid`` x ``StratifiedKFold(cv)``,
-  no shuffle) and takes the tasks ``i % world == rank`` of the list sorted by
-  estimated cost (longest first), so no scheduler and no per-task traffic,
-* one ``all_gather`` of the per-task score rows at the end; every rank computes
-  ``mean_test_score`` / ``rank_test_score`` / ``best_index_`` identically and
-  rank 0 refits the best candidate on the whole training set (``refit=True``).
+* every rank derives the identical work list (``ParameterGrid`` x ``StratifiedKFold(cv)``, no shuffle), sorted
+  by estimated cost, longest first,
+* **dynamic distribution**: every worker (``fits_per_gpu`` host threads per rank) pulls the index of its next
+  work unit from ONE shared counter -- ``store.add`` on the process group's rendezvous store across ranks, a
+  locked integer inside one process -- so a rank whose fits stop early (``EarlyStopping``) simply takes more
+  units; fit times need not be predictable.  ``schedule="static"`` keeps the round-robin deal ``i % world``,
+* one ``all_gather`` of the per-task score rows at the end; every rank computes ``mean_test_score`` /
+  ``rank_test_score`` / ``best_index_`` identically and rank 0 refits the best candidate on the whole training
+  set (``refit=True``).  The refit needs every score, so it cannot start before the last fit ends; it is one
+  fit out of 1 621.
 
-There is no per-step collective: fits are independent.
+There is no per-step collective: fits are independent.  Every task is seeded by its
+index, so ``cv_results_`` does not depend on the world size, on ``fits_per_gpu`` or on which rank ran what.
 
-``fits_per_gpu=k`` runs k of the rank's fits at a time, one host thread and one HIP stream each: a single
-batch-50 fit leaves most of the GPU idle during its decoder (tgt length 1) phases, and k = 4 fits were
-measured at 1.5x the aggregate seq/s of one (tools/bench_concurrent.py).  Every task is seeded by its index,
-so results do not depend on the world size or on k.
+A **work unit** is a list of tasks.  With ``lockstep=k`` tasks that share every shape-defining parameter (and the
+fold sizes) are packed k to a unit and handed to ``fit_and_score_group`` in one call, which advances them through ONE
+launch sequence (slnlp.lockstep); otherwise a unit is one task.
+
+A task that raises does not strand the other ranks in the collective: its row carries NaN and an error flag, the
+gather completes, and then EVERY rank raises.
 """
 import itertools
+import threading
 import time
 
 import numpy as np
 
 from .data import TokenDataset
+
+_FIT_CALLS = itertools.count()       # distinguishes the store keys of successive fit() calls in one process group
 
 
 def parameter_grid(param_grid):
@@ -35,21 +45,50 @@ def parameter_grid(param_grid):
     return [dict(zip(keys, vals)) for vals in itertools.product(*[param_grid[k] for k in keys])]
 
 
-def estimate_cost(params):
-    """Relative cost of one fit for LPT ordering: layers x (E^2 + E*F)."""
-    E = params.get("module__embedding_size", 128)
-    F = params.get("module__hidden_size", 256)
-    N = params.get("module__num_layers", 2)
-    return float(N) * (E * E + E * F)
+def estimate_cost(params, seq_len=48, n_samples=1, defaults=None):
+    """Relative cost of one fit, for the longest-first order only: samples x epochs x per-sequence FLOPs
+    ~ N x (S x (E^2 + E x F) + S^2 x E) (attention's S^2 term matters once S > E)."""
+    d = dict(defaults or {})
+    d.update(params)
+    E = d.get("module__embedding_size", 128)
+    F = d.get("module__hidden_size", 256)
+    N = d.get("module__num_layers", 2)
+    epochs = d.get("max_epochs", 1)
+    return float(n_samples) * float(epochs) * float(N) * (seq_len * (E * E + E * F) + seq_len * seq_len * E)
 
 
-def build_tasks(param_grid, y, cv):
+def build_tasks(param_grid, y, cv, seq_len=48, defaults=None):
     from sklearn.model_selection import StratifiedKFold
     cands = parameter_grid(param_grid)
     folds = list(StratifiedKFold(n_splits=cv).split(np.zeros(len(y)), y))
     tasks = [(ci, fi) for ci in range(len(cands)) for fi in range(len(folds))]
-    order = sorted(range(len(tasks)), key=lambda t: (-estimate_cost(cands[tasks[t][0]]), t))
+    cost = lambda t: estimate_cost(cands[tasks[t][0]], seq_len, len(folds[tasks[t][1]][0]), defaults)
+    order = sorted(range(len(tasks)), key=lambda t: (-cost(t), t))
     return cands, folds, tasks, order
+
+
+SHAPE_KEYS_EXCLUDED = ("lr", "optimizer__momentum", "module__dropout")
+
+
+def build_units(cands, folds, tasks, order, lockstep=1):
+    """Pack the cost-ordered task list into work units of up to ``lockstep`` tasks that can advance through one
+    launch sequence: same candidate shapes (every parameter except lr / momentum / dropout) and the same train-fold
+    size (=> the same number and sizes of batches).  ``lockstep <= 1``: one task per unit."""
+    if lockstep <= 1:
+        return [[t] for t in order]
+    units, open_units = [], {}
+    for t in order:
+        ci, fi = tasks[t]
+        key = (tuple(sorted((k, repr(v)) for k, v in cands[ci].items() if k not in SHAPE_KEYS_EXCLUDED)),
+               len(folds[fi][0]), len(folds[fi][1]))
+        u = open_units.get(key)
+        if u is None:
+            u = open_units[key] = []
+            units.append(u)                      # a unit keeps the position of its first (most expensive) task
+        u.append(t)
+        if len(u) == lockstep:
+            del open_units[key]
+    return units
 
 
 def _dist():
@@ -59,13 +98,25 @@ def _dist():
     return None, 0, 1
 
 
-def broadcast_dataset(ds, device="cpu", src=0):
+def comm_device(device="cpu"):
+    """Where collective payloads must live: the GPU for RCCL ("nccl"), host memory for gloo."""
+    dist, _, _ = _dist()
+    if dist is not None and dist.get_backend() == "nccl":
+        import torch
+        dev = torch.device(device)
+        return dev if dev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    return "cpu"
+
+
+def broadcast_dataset(ds, device="cpu", src=0, force=False):
     """Rank ``src`` holds the dataset; everyone else receives it (ONE broadcast of a packed int64 buffer
-    over RCCL/xGMI on GPUs: ~4 MB at N=10k, latency-bound)."""
+    over RCCL/xGMI on GPUs: ~4 MB at N=10k, latency-bound).  ``force``: run the collectives even in a
+    one-rank group (exercises the RCCL path on a single GPU)."""
     import torch
     dist, rank, world = _dist()
-    if world == 1:
+    if dist is None or (world == 1 and not force):
         return ds
+    device = comm_device(device)
     meta = torch.zeros(4, dtype=torch.int64, device=device)
     if rank == src:
         meta[:] = torch.tensor([len(ds), ds.ids.shape[1], len(ds.vocab_X) if ds.vocab_X else 0,
@@ -76,12 +127,37 @@ def broadcast_dataset(ds, device="cpu", src=0):
     if rank == src:
         buf[:] = torch.from_numpy(np.concatenate([ds.ids.ravel(), ds.lengths, ds.y])).to(device)
     dist.broadcast(buf, src)
-    if rank == src:
+    if rank == src and not force:
         return ds
     from model.util import Vocab
     b = buf.cpu().numpy()
-    return TokenDataset(b[:n * s].reshape(n, s), b[n * s:n * s + n], b[n * s + n:], Vocab(vx) if vx else None,
-                        Vocab(vy) if vy else None)
+    keep = ds if rank == src else None
+    return TokenDataset(b[:n * s].reshape(n, s), b[n * s:n * s + n], b[n * s + n:],
+                        keep.vocab_X if keep else (Vocab(vx) if vx else None),
+                        keep.vocab_y if keep else (Vocab(vy) if vy else None))
+
+
+class WorkCounter:
+    """next() -> 0, 1, 2, ... handed out exactly once across every worker thread of every rank."""
+
+    def __init__(self, key, static=False):
+        dist, self.rank, self.world = _dist()
+        self._lock, self._n, self._store, self._key = threading.Lock(), 0, None, key
+        self.static = static
+        if self.world > 1 and not static:
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                self._store = _get_default_store()
+            except Exception:                      # no rendezvous store reachable: fall back to the static deal
+                self.static = True
+
+    def next(self):
+        if self._store is not None:
+            return int(self._store.add(self._key, 1)) - 1
+        with self._lock:
+            i = self._n
+            self._n += 1
+        return i * self.world + self.rank if self.world > 1 else i        # static deal: i-th unit of this rank
 
 
 def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_log_loss", seed=None, concurrent=False):
@@ -111,55 +187,111 @@ def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_l
 
 class ShardedGridSearchCV:
     def __init__(self, estimator_factory, param_grid, cv=5, scoring="neg_log_loss", refit=True, fit_and_score=None,
-                 device="cpu", verbose=0, fits_per_gpu=1, seed=1):
+                 device="cpu", verbose=0, fits_per_gpu=1, seed=1, schedule="dynamic", lockstep=1,
+                 fit_and_score_group=None, force_collectives=False):
         self.estimator_factory, self.param_grid, self.cv = estimator_factory, param_grid, cv
         self.scoring, self.refit, self.verbose, self.device = scoring, refit, verbose, device
         self.fit_and_score = fit_and_score or default_fit_and_score
         self.fits_per_gpu, self.seed = int(fits_per_gpu), seed
+        assert schedule in ("dynamic", "static")
+        self.schedule, self.lockstep, self.fit_and_score_group = schedule, int(lockstep), fit_and_score_group
+        self.force_collectives = force_collectives
+
+    def _defaults(self):
+        try:
+            return self.estimator_factory().get_params()
+        except Exception:
+            return {}
 
     def fit(self, dataset):
+        import inspect
         import torch
         dist, rank, world = _dist()
-        ds = broadcast_dataset(dataset, self.device)
-        cands, folds, tasks, order = build_tasks(self.param_grid, ds.y, self.cv)
-        mine = [order[i] for i in range(rank, len(order), world)]
-        rows = torch.full((len(tasks), 2), float("nan"), dtype=torch.float64)
+        ds = broadcast_dataset(dataset, self.device, force=self.force_collectives)
+        cands, folds, tasks, order = build_tasks(self.param_grid, ds.y, self.cv, ds.ids.shape[1], self._defaults())
+        group_fn = self.fit_and_score_group
+        if self.lockstep > 1 and group_fn is None:
+            from .lockstep import fit_and_score_group as group_fn
+        units = build_units(cands, folds, tasks, order, self.lockstep if group_fn else 1)
+        call = next(_FIT_CALLS)
+        counter = WorkCounter(f"slnlp/grid/{call}/next", static=self.schedule == "static")
+        rows = torch.full((len(tasks), 3), float("nan"), dtype=torch.float64)      # score, seconds, error flag
+        rows[:, 2] = 0.0
+        mine, errors = [], []
         t_start = time.time()
-        import inspect
         sig = inspect.signature(self.fit_and_score).parameters
         takes_seed, takes_conc = "seed" in sig, "concurrent" in sig
         is_cuda = str(self.device).startswith("cuda")
+        lock = threading.Lock()
 
-        def run_task(t):
+        def run_unit(unit):
             if is_cuda and torch.device(self.device).index is not None:
                 torch.cuda.set_device(torch.device(self.device))     # the current device is per host thread
-            ci, fi = tasks[t]
-            tr, te = folds[fi]
             t0 = time.time()
-            kw = {"seed": self.seed + t} if (takes_seed and self.seed is not None) else {}
-            if takes_conc and self.fits_per_gpu > 1:
-                kw["concurrent"] = True
-            score = self.fit_and_score(self.estimator_factory, cands[ci], ds[tr], ds[te], self.scoring, **kw)
-            rows[t, 0], rows[t, 1] = score, time.time() - t0         # each task owns its row
+            seeds = [self.seed + t if self.seed is not None else None for t in unit]
+            try:
+                if len(unit) > 1 or (group_fn is not None and self.lockstep > 1):
+                    scores = group_fn(self.estimator_factory, [cands[tasks[t][0]] for t in unit],
+                                      [ds[folds[tasks[t][1]][0]] for t in unit], [ds[folds[tasks[t][1]][1]] for t in unit],
+                                      self.scoring, seeds=seeds)
+                else:
+                    ci, fi = tasks[unit[0]]
+                    kw = {"seed": seeds[0]} if (takes_seed and seeds[0] is not None) else {}
+                    if takes_conc and self.fits_per_gpu > 1:
+                        kw["concurrent"] = True
+                    scores = [self.fit_and_score(self.estimator_factory, cands[ci], ds[folds[fi][0]], ds[folds[fi][1]],
+                                                 self.scoring, **kw)]
+                dt = (time.time() - t0) / len(unit)
+                for t, s in zip(unit, scores):
+                    rows[t, 0], rows[t, 1] = float(s), dt         # each task owns its row
+            except Exception as e:                                  # keep the collective alive; raise after it
+                import traceback
+                for t in unit:
+                    rows[t, 0], rows[t, 1], rows[t, 2] = float("nan"), time.time() - t0, 1.0
+                with lock:
+                    errors.append((unit, e, traceback.format_exc()))
             if self.verbose:
-                print(f"[rank {rank}] task {t} cand {ci} fold {fi}: score {float(rows[t, 0]):.4f} ({float(rows[t, 1]):.2f}s)",
-                      flush=True)
+                for t in unit:
+                    print(f"[rank {rank}] task {t} cand {tasks[t][0]} fold {tasks[t][1]}: score {float(rows[t, 0]):.4f} "
+                          f"({float(rows[t, 1]):.2f}s)", flush=True)
+
+        def worker():
+            while True:
+                i = counter.next()
+                if i >= len(units):
+                    return
+                with lock:
+                    mine.extend(units[i])
+                run_unit(units[i])
 
         if self.fits_per_gpu > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(self.fits_per_gpu) as pool:
-                list(pool.map(run_task, mine))                       # longest-first order; re-raises a task's exception
+            threads = [threading.Thread(target=worker) for _ in range(self.fits_per_gpu)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
         else:
-            for t in mine:
-                run_task(t)
+            worker()
         self.local_seconds_ = time.time() - t_start
-        if world > 1:                                     # each task has exactly one owner: combine by all_gather
+        if dist is not None and (world > 1 or self.force_collectives):   # each task has exactly one owner: combine by all_gather
             mine_mask = torch.zeros(len(tasks), dtype=torch.bool)
             mine_mask[mine] = True
-            send = torch.where(mine_mask[:, None], rows, torch.zeros_like(rows)).to(self.device)
+            send = torch.where(mine_mask[:, None], rows, torch.zeros_like(rows))
+            send = torch.cat([send, torch.tensor([[self.local_seconds_, float(len(mine)), 0.0]], dtype=torch.float64)])
+            send = send.to(comm_device(self.device))
             gathered = [torch.empty_like(send) for _ in range(world)]
             dist.all_gather(gathered, send)
-            rows = torch.stack([g.cpu() for g in gathered]).sum(0)
+            gathered = [g.cpu() for g in gathered]
+            rows = torch.stack([g[:-1] for g in gathered]).sum(0)
+            self.rank_seconds_ = [float(g[-1, 0]) for g in gathered]
+            self.rank_tasks_ = [int(g[-1, 1]) for g in gathered]
+        else:
+            self.rank_seconds_, self.rank_tasks_ = [self.local_seconds_], [len(mine)]
+        if float(rows[:, 2].sum()) > 0:
+            failed = [int(t) for t in torch.nonzero(rows[:, 2]).flatten()]
+            detail = f"\n--- first failure on this rank ---\n{errors[0][2]}" if errors else ""
+            raise RuntimeError(f"ShardedGridSearchCV: {len(failed)} task(s) failed (task ids {failed[:8]}...)" + detail) \
+                from (errors[0][1] if errors else None)
         scores = rows[:, 0].numpy().reshape(len(cands), len(folds))
         self.cv_results_ = {
             "params": cands,
@@ -172,9 +304,11 @@ class ShardedGridSearchCV:
         self.best_index_ = int(np.argmax(mean))            # first maximum, like sklearn's rank 1
         self.best_score_ = float(mean[self.best_index_])
         self.best_params_ = cands[self.best_index_]
-        self.n_tasks_, self.tasks_of_rank_ = len(tasks), mine
+        self.n_tasks_, self.tasks_of_rank_, self.n_units_ = len(tasks), sorted(mine), len(units)
         if self.refit and rank == 0:
             self.best_estimator_ = self.estimator_factory().set_params(**self.best_params_)
             if hasattr(self.best_estimator_, "fit"):
+                t0 = time.time()
                 self.best_estimator_.fit(ds)
+                self.refit_time_ = time.time() - t0
         return self

@@ -34,15 +34,57 @@ def oracle_fit_and_score(factory, params, train, test, scoring):
         return -float(train_ref.cross_entropy_on_logprobs(fwd(trn.sd, Xt, yt, None), yt, 1))
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, schedule="dynamic"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3) if rank == 0 else None
-    gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=oracle_fit_and_score, refit=False)
+    gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=oracle_fit_and_score, refit=False, schedule=schedule)
     gs.fit(ds)
     out[rank] = (gs.cv_results_["mean_test_score"].tolist(), gs.best_index_, gs.best_params_, sorted(gs.tasks_of_rank_))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def skewed_fit_and_score(factory, params, train, test, scoring):
+    """Deliberately unpredictable fit times (what EarlyStopping does to the real grid): the estimated cost says
+    nothing about them.  Score = a pure function of the task, so results are checkable."""
+    import time
+    slow = params["lr"] == 0.1 and params["module__num_layers"] == 2
+    time.sleep(0.30 if slow else 0.02)
+    return -float(params["lr"]) * params["module__embedding_size"] - 0.001 * len(test)
+
+
+def _run_skewed(rank, world, port, out, schedule):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3) if rank == 0 else None
+    gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=skewed_fit_and_score, refit=False, schedule=schedule)
+    gs.fit(ds)
+    out[rank] = (gs.cv_results_["mean_test_score"].tolist(), gs.rank_seconds_, gs.rank_tasks_, sorted(gs.tasks_of_rank_))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def failing_fit_and_score(factory, params, train, test, scoring):
+    if params["lr"] == 0.01 and params["module__embedding_size"] == 32 and params["module__num_layers"] == 2:
+        raise ValueError("boom")
+    return -1.0
+
+
+def _run_failing(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3) if rank == 0 else None
+    gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=failing_fit_and_score, refit=False)
+    try:
+        gs.fit(ds)
+        out[rank] = "no error"
+    except RuntimeError as e:
+        out[rank] = str(e)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,14 +114,57 @@ def test_sharded_grid_world2_equals_world1():
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_run, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert len(out) == world
-    for r in range(world):
-        mean, best, params, mine = out[r]
-        assert np.allclose(mean, single.cv_results_["mean_test_score"], rtol=0, atol=1e-12)   # same on every rank
-        assert best == single.best_index_ and params == single.best_params_
+    for schedule in ("dynamic", "static"):
+        out.clear()
+        mp.spawn(_run, args=(world, _free_port(), out, schedule), nprocs=world, join=True)
+        assert len(out) == world
+        for r in range(world):
+            mean, best, params, mine = out[r]
+            assert np.allclose(mean, single.cv_results_["mean_test_score"], rtol=0, atol=1e-12)   # same on every rank
+            assert best == single.best_index_ and params == single.best_params_
+        assert sorted(out[0][3] + out[1][3]) == list(range(single.n_tasks_))
+        assert set(out[0][3]).isdisjoint(out[1][3])
+
+
+def test_dynamic_schedule_balances_skewed_fit_times():
+    """Work counter on the process group's store: with fit times the cost estimate cannot see, both ranks finish
+    within 15 % of the mean (the static deal leaves one rank with most of the slow fits), and the results are still
+    those of one rank."""
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    single = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=skewed_fit_and_score, refit=False).fit(ds)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_skewed, args=(2, _free_port(), out, "dynamic"), nprocs=2, join=True)
+    mean, secs, ntasks, mine0 = out[0]
+    assert np.allclose(mean, single.cv_results_["mean_test_score"], rtol=0, atol=1e-12)
+    assert out[0][1] == out[1][1] and sum(ntasks) == single.n_tasks_       # every rank knows every rank's time
+    assert max(secs) / (sum(secs) / len(secs)) <= 1.15, secs
     assert sorted(out[0][3] + out[1][3]) == list(range(single.n_tasks_))
-    assert set(out[0][3]).isdisjoint(out[1][3])
+
+
+def test_failing_task_raises_on_every_rank_instead_of_hanging():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_failing, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        assert "task(s) failed" in out[r], out[r]
+    with pytest.raises(RuntimeError, match="boom|failed"):
+        ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+        grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=failing_fit_and_score, refit=False).fit(ds)
+
+
+def test_build_units_packs_shape_compatible_tasks():
+    ds = synthetic_dataset(50, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    g = {"lr": [0.1, 0.01], "module__dropout": [0.1, 0.3], "module__embedding_size": [16, 32]}
+    cands, folds, tasks, order = grid.build_tasks(g, ds.y, 5)
+    assert [[t] for t in order] == grid.build_units(cands, folds, tasks, order, 1)
+    units = grid.build_units(cands, folds, tasks, order, 4)
+    assert sorted(t for u in units for t in u) == list(range(len(tasks)))
+    for u in units:
+        assert 1 <= len(u) <= 4
+        assert len({cands[tasks[t][0]]["module__embedding_size"] for t in u}) == 1      # one shape per unit
+        assert len({len(folds[tasks[t][1]][0]) for t in u}) == 1                         # one batch schedule per unit
+    assert len(units) < len(tasks) / 2
 
 
 def test_fits_per_gpu_threads_same_results_and_seed_passed():
