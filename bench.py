@@ -9,9 +9,17 @@ clip_grad_norm_(0.5) + SGD-momentum) of BASELINE.json configs[1]
 len=48, |src|=3000, |tgt|=202, dropout 0.1) on one batch of synthetic ASL-Phono
 token ids that is already resident in HBM (hipGraph replay or plain stream launches,
 whichever a short probe during warmup finds faster -- slnlp/launch.py).
-N>1: one process per GPU, each running its own independent fit (the reference's
-only parallelism is the embarrassingly parallel (candidate x fold) grid,
-SURVEY.md section 8e) -> weak scaling, no data-path collective.
+N>1: one process per GPU over RCCL (the driver launches the ranks with
+torch.distributed.run; run by hand without WORLD_SIZE, ``--gpus N`` spawns the N
+rank processes itself before anything touches the GPU).  Two legs per N:
+
+* ``value``: every rank runs its own independent fit (the reference's only
+  parallelism is the embarrassingly parallel (candidate x fold) grid, SURVEY.md
+  section 8e) -> weak scaling, no data-path collective;
+* ``grid``: the other half of BASELINE.json's metric -- folds/hr of ONE bounded
+  cross-validated grid search (the same sample at every N -> strong scaling)
+  run by ShardedGridSearchCV over the N ranks: dataset broadcast over RCCL,
+  dynamic work counter, one all_gather of the scores.
 
 Prints ONE JSON line (rank 0).
 """
@@ -148,31 +156,63 @@ def concurrent_fits(c, precision, dev, k=4, steps=40):
             "ms_per_round": round(dt / steps * 1e3, 3), "note": f"{k} independent fits, {steps} steps each, one stream per fit"}
 
 
-def grid_folds_per_hour(dev, fits_per_gpu=4):
+GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__embedding_size": [512, 128],
+               "module__num_layers": [4, 2]}                 # 24 of config-transformer.yaml's 324 candidates (F 256, H 4)
+GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 8, 2000
+
+
+def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
+    from slnlp.net import NeuralNetClassifier
+    return lambda: NeuralNetClassifier(
+        module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
+        module__embedding_size=128, module__num_heads=4, module__num_layers=2, module__hidden_size=256, module__dropout=0.1,
+        criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=max_epochs, batch_size=50,
+        device=str(dev), gradient_clipping={"gradient_clip_value": 0.5},
+        scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
+
+
+def grid_folds_per_hour(dev, world, rank, fits_per_gpu=4, lockstep=1):
     """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
-    on a bounded sample -- 6 candidates x cv 2 = 12 fits of 10 epochs over 2000 synthetic samples
-    (batch 50, len 48, |src| 3000, 200 labels), run by ShardedGridSearchCV the way a rank runs its shard."""
+    on a bounded sample of config-transformer.yaml's grid -- 24 candidates x cv 5 = 120 fits of 8 epochs over 2000
+    synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
+    ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling)."""
     import warnings
     from slnlp.data import synthetic_dataset
     from slnlp.grid import ShardedGridSearchCV
-    from slnlp.net import NeuralNetClassifier
     warnings.filterwarnings("ignore", message="enable_nested_tensor")        # torch modules built only to draw the initial weights
-    warnings.filterwarnings("ignore", message="The least populated class")    # 1000 samples over 200 labels
-    ds = synthetic_dataset(2000, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8)
-    factory = lambda: NeuralNetClassifier(
-        module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
-        module__embedding_size=128, module__num_heads=4, module__num_layers=2, module__hidden_size=256, module__dropout=0.1,
-        criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=10, batch_size=50,
-        device=str(dev), gradient_clipping={"gradient_clip_value": 0.5},
-        scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
-    grid = {"lr": [0.1, 0.01, 0.001], "module__embedding_size": [128, 512]}
+    warnings.filterwarnings("ignore", message="The least populated class")    # 2000 samples over 200 labels
+    ds = synthetic_dataset(GRID_SAMPLES, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8)
+    # untimed warm-up on every rank (code objects, allocator pools, plan creation paths): one tiny fit per shape
+    warm = ShardedGridSearchCV(grid_factory(ds.truncated(200), dev, 1), {"module__embedding_size": [512, 128], "module__num_layers": [4, 2]},
+                               cv=2, refit=False, device=str(dev), fits_per_gpu=1, schedule="static", lockstep=lockstep)
+    warm_t0 = time.perf_counter()
+    _fit_local(warm, ds.truncated(200))       # every rank warms up on the whole warm-up grid, not on a shard of it
+    warm_s = time.perf_counter() - warm_t0
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     t0 = time.perf_counter()
-    gs = ShardedGridSearchCV(factory, grid, cv=2, refit=False, device=str(dev), fits_per_gpu=fits_per_gpu).fit(ds)
+    gs = ShardedGridSearchCV(grid_factory(ds, dev), GRID_SAMPLE, cv=GRID_CV, refit=False, device=str(dev),
+                             fits_per_gpu=fits_per_gpu, lockstep=lockstep).fit(ds if rank == 0 else None)
     dt = time.perf_counter() - t0
     return {"value": round(gs.n_tasks_ / dt * 3600.0, 0), "unit": "folds/hr", "fits": gs.n_tasks_, "seconds": round(dt, 2),
-            "fits_per_gpu": fits_per_gpu,
-            "sample": "6 candidates (lr x embedding_size) x cv 2, 10 epochs, 2000 samples, 80/20 train/valid split inside each "
-                      "fit, the reference's 5 epoch metrics on both; E128/E512 N2 H4 F256"}
+            "fits_per_gpu": fits_per_gpu, "lockstep": lockstep, "ranks": world, "schedule": gs.schedule,
+            "rank_seconds": [round(v, 2) for v in gs.rank_seconds_], "rank_fits": gs.rank_tasks_, "warmup_seconds": round(warm_s, 2),
+            "best_index": gs.best_index_, "best_score": round(gs.best_score_, 5),
+            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x embedding_size x num_layers of config-transformer.yaml; "
+                      f"F 256, H 4) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
+                      "the reference's 5 epoch metrics on both; includes the dataset broadcast and the score all_gather"}
+
+
+def _fit_local(gs, ds):
+    """Run a grid search on this rank alone even inside a process group (warm-up)."""
+    from slnlp import grid as G
+    saved = G._dist
+    G._dist = lambda: (None, 0, 1)
+    try:
+        return gs.fit(ds)
+    finally:
+        G._dist = saved
 
 
 def rocprof_kernel_times(workload):
@@ -216,32 +256,67 @@ def cpu_parity(c, sd, Xe, ye, Le, logp_gpu):
             "logp_rel_err": float((logp_gpu - lo).abs().max() / lo.abs().max())}
 
 
-def cpu_baseline(c, sd, X, y, Ln, budget_s=20.0):
-    """CPU leg, part 2: the oracle (CPU port of the reference step) timed on this host's cores on a bounded sample."""
+def cpu_baseline(c, sd, X, y, Ln, budget_s=14.0):
+    """CPU leg, part 2: the oracle (CPU port of the reference step) timed on this host's cores on a bounded sample.
+    Headline variant = BASELINE.md section 3's: all the cores this process may use, dropout ON (fresh Bernoulli
+    masks per step, the reference's nn.Dropout cost; 25 % of its CPU step).  Also reported:
+    dropout off, and one thread."""
     from oracle import rnn_ref, train_ref, transformer_ref as tr
     # the GPU box gives this process a CPU share (16 cores per GPU), not the whole host
     cores = min(len(os.sched_getaffinity(0)), 16)
-    torch.set_num_threads(cores)
-    masks = None  # dropout-free arithmetic: the reference's bernoulli cost is not charged to the CPU side
-    if "rnn" in c:
-        fwd = lambda p, X, y, L: rnn_ref.forward(p, X, y, L, rnn_type=c["rnn"], num_layers=c["N"])
-        frozen = ("model.decoder.pre_output_layer.weight",)
-    else:
-        fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=c["H"], num_layers=c["N"], p_drop=0.0, masks=masks)
-        frozen = ()
-    trn = train_ref.Trainer(sd, fwd, pad_tgt=1, lr=LR, momentum=MOMENTUM, max_norm=MAX_NORM, frozen=frozen)
     B = c["B"]
-    trn.step(X[:B], y[:B], Ln[:B])  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        i = (n % (X.shape[0] // B)) * B
-        trn.step(X[i:i + B], y[i:i + B], Ln[i:i + B])
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 50:
-            break
-    return {"value": round(n * B / dt, 2), "unit": "seq/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps of batch {B} ({dt:.1f} s), torch fp32, {cores} threads, dropout off"}
+
+    def timed(threads, draw, budget):
+        torch.set_num_threads(threads)
+        if "rnn" in c:
+            fwd = lambda p, X, y, L: rnn_ref.forward(p, X, y, L, rnn_type=c["rnn"], num_layers=c["N"],
+                                                     p_drop=c["dropout"] if draw else 0.0, masks="draw" if draw else None)
+            frozen = ("model.decoder.pre_output_layer.weight",)
+        else:
+            fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=c["H"], num_layers=c["N"],
+                                                p_drop=c["dropout"] if draw else 0.0, masks="draw" if draw else None)
+            frozen = ()
+        trn = train_ref.Trainer(sd, fwd, pad_tgt=1, lr=LR, momentum=MOMENTUM, max_norm=MAX_NORM, frozen=frozen)
+        trn.step(X[:B], y[:B], Ln[:B])  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            i = (n % (X.shape[0] // B)) * B
+            trn.step(X[i:i + B], y[i:i + B], Ln[i:i + B])
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or n >= 50:
+                break
+        return n * B / dt, n, dt
+
+    v, n, dt = timed(cores, True, budget_s)
+    v_nodrop, n2, dt2 = timed(cores, False, budget_s * 0.5)
+    v_one, n3, dt3 = timed(1, True, budget_s * 0.5)
+    torch.set_num_threads(cores)
+    return {"value": round(v, 2), "unit": "seq/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of batch {B} ({dt:.1f} s), torch fp32, {cores} threads, dropout {c['dropout']} (masks drawn per step)",
+            "dropout_off": {"value": round(v_nodrop, 2), "sample": f"{n2} steps ({dt2:.1f} s), {cores} threads"},
+            "one_thread": {"value": round(v_one, 2), "cores": 1, "sample": f"{n3} steps ({dt3:.1f} s), dropout {c['dropout']}"}}
+
+
+def spawn_ranks(n):
+    """``--gpus N`` run by hand (no WORLD_SIZE): start the N rank processes -- fresh children, before this parent has
+    touched the GPU -- hand them the rendezvous through the environment torch.distributed.run would set, relay rank 0's
+    JSON line (the children inherit stdout) and exit with the worst return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
 
 
 def main():
@@ -252,26 +327,37 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", type=int, default=3, choices=[1, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid", action="store_true", help="skip the folds/hr leg")
+    ap.add_argument("--fits-per-gpu", type=int, default=4, help="concurrent fits per GPU in the grid leg")
+    ap.add_argument("--lockstep", type=int, default=1, help="fits advanced through one launch sequence in the grid leg")
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")
     ap.add_argument("--eager", action="store_true", help="same as --launch eager")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))      # the parent has not touched the GPU (device_count() does not initialise it)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only compute path")
     ndev = torch.cuda.device_count()
     shared = world > ndev                      # rehearsal on a box with fewer GPUs than ranks: ranks share GPUs, gloo barrier
     dev_index = local_rank % ndev
+    backend = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if shared:
-            dist.init_process_group("gloo")    # RCCL refuses two ranks on one device
+            dist.init_process_group("gloo", timeout=datetime.timedelta(hours=2))    # RCCL refuses two ranks on one device
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(hours=2))
+        backend = dist.get_backend()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -321,16 +407,26 @@ def main():
         wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     loss_end = eng.loss
+    rank_walls = [wall]
     if world > 1:
-        t = torch.tensor([wall], device="cpu" if shared else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t)
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if shared else dev)
+        t[rank] = wall
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_walls = [float(v) for v in t.cpu()]
+        wall = max(rank_walls)
+
+    # ---- leg 2: the sharded grid search, every rank takes part (collectives inside)
+    chosen = eng._launch.mode((B, float(MOMENTUM), float(MAX_NORM))) if launch == "auto" else None
+    grid = None
+    if "rnn" not in c and not args.no_grid:
+        del eng
+        torch.cuda.empty_cache()
+        grid = grid_folds_per_hour(dev, world, rank, fits_per_gpu=args.fits_per_gpu, lockstep=args.lockstep)
 
     out = None
     if rank == 0:
         seqs = world * B * args.steps
         if launch == "auto":
-            chosen = eng._launch.mode((B, float(MOMENTUM), float(MAX_NORM)))
             launch_used = f"{'hipGraph replay' if chosen == 'graph' else 'eager stream launches'} (auto: timed both in warmup)"
         else:
             launch_used = "hipGraph replay" if launch else "eager stream launches"
@@ -361,12 +457,16 @@ def main():
                                    f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
                        "launch": launch_used, "per_gpu": "independent fit (grid shard)" + (f"; REHEARSAL: {world} ranks share {ndev} GPU(s)" if shared else "")},
+            "ranks": {"world": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                      "devices_visible": ndev, "rank_wall_s": [round(v, 4) for v in rank_walls]},
             "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload),
                               "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
                               "ms_per_launch_hip_events": round(ms_event, 4)},
             "parity": parity, "final_loss": round(loss_end, 5),
         }
+        if grid is not None:
+            out["grid"] = grid
         if "rnn" not in c:
             with torch.cuda.stream(stream):
                 dk = dominant_kernel_roofline(c, args.precision, dev, args.workload)
@@ -374,7 +474,6 @@ def main():
                 out["roofline"] = dk
             if world == 1 and not args.no_cpu_baseline:
                 out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
-                out["grid"] = grid_folds_per_hour(dev)
         out.setdefault("roofline", dict(out["roofline_step"]))   # RNN workloads: no single dominant GEMM, the step is the unit
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))

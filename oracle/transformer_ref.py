@@ -41,9 +41,13 @@ def padding_mask(ids_len_first, pad_idx):
 
 def dropout(x, p, masks, name):
     """Dropout with host-supplied keep masks (``masks[name]``: 0/1 tensor of
-    x's shape).  ``masks is None`` or p == 0 -> identity (eval / parity mode)."""
+    x's shape).  ``masks is None`` or p == 0 -> identity (eval / parity mode).
+    ``masks == "draw"``: fresh Bernoulli keep masks from torch's generator, what ``nn.Dropout`` does in the
+    reference's train mode (used to time the CPU step like-for-like, not for parity)."""
     if masks is None or p == 0.0:
         return x
+    if isinstance(masks, str):
+        return x * torch.bernoulli(torch.full_like(x, 1.0 - p)) / (1.0 - p)
     return x * masks[name].to(x.dtype) / (1.0 - p)
 
 

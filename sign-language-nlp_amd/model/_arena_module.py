@@ -37,6 +37,9 @@ class _HipFn(torch.autograd.Function):
         eng = ctx.eng
         eng.seed_dlogp(dlogp)
         eng.backward()
+        # the fused clip+SGD kernel advances the dropout step counter; on this path (stock torch.optim / skorch loop)
+        # nothing else would, and every step would redraw the SAME masks
+        eng.rng[1:2].add_(1)
         gv = eng.views(eng.grads)
         dead = ctx.module._dead_params
         grads = tuple(None if name in dead else gv[name].clone() for name in ctx.module._param_names)
@@ -53,7 +56,20 @@ class ArenaModule(nn.Module):
         self._entries = entries
         self._param_names = [n for n, _, _ in entries]
         self._engines = {}
+        self._opt_state = None      # (grads, momentum, rng, lr) on the device: ONE set per module, shared by every plan
         self._build(torch.zeros(total, dtype=torch.float32), init_values)
+
+    def _shared_state(self):
+        """Gradient / momentum arenas, dropout rng {seed, step} and lr live on the module, not on a plan: training with
+        more than one sequence length (per-batch padding) must not split the momentum or restart the mask stream."""
+        dev = self._arena.device
+        st = self._opt_state
+        if st is None or st["grads"].device != dev:
+            n = self._arena.numel()
+            st = self._opt_state = {
+                "grads": torch.zeros(n, dtype=torch.float32, device=dev), "momentum": torch.zeros(n, dtype=torch.float32, device=dev),
+                "rng": torch.tensor([self.seed, 0], dtype=torch.int64, device=dev), "lr": torch.zeros(1, dtype=torch.float32, device=dev)}
+        return st
 
     def _state_order(self, views):
         raise NotImplementedError
@@ -110,10 +126,7 @@ class ArenaModule(nn.Module):
         eng = self._engines.get(S)
         if eng is None or eng.cfg.B < B:
             old = eng
-            eng = self._make_engine(max(B, old.cfg.B if old is not None else 0), S, old)
-            if old is not None:
-                eng.rng.copy_(old.rng)
-                eng.lr.copy_(old.lr)
+            eng = self._make_engine(max(B, old.cfg.B if old is not None else 0), S, self._shared_state())
             self._engines[S] = eng
         return eng
 
@@ -128,8 +141,28 @@ class ArenaModule(nn.Module):
         eng = self._engine_for(inputs[0].shape[0], inputs[0].shape[1])
         return eng.forward(*inputs, train=self.training).clone()
 
-    # engines hold ctypes handles: rebuild lazily after copy / pickle (sklearn.clone, checkpoints)
+    # engines hold ctypes handles: rebuild lazily after copy / pickle (sklearn.clone, checkpoints).  copy.deepcopy
+    # and pickle restore every tensor separately, so the parameters would stop aliasing ``_arena`` (the memory the HIP
+    # plans compute from): ``__setstate__`` re-creates them as views of the restored arena.
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_engines"] = {}
+        d["_opt_state"] = None
+        d["_param_grads"] = {n: p.grad for n, p in self.named_parameters() if p.grad is not None}
         return d
+
+    def __setstate__(self, state):
+        grads = state.pop("_param_grads", {})
+        super().__setstate__(state)
+        self._engines, self._opt_state = {}, None
+        self._build(self._arena.detach())
+        for n, p in self.named_parameters():
+            if n in grads:
+                p.grad = grads[n]
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        return new

@@ -90,11 +90,11 @@ class EncoderDecoderAttnBase(ArenaModule):
     def _state_order(self, views):
         return [(n, views[n], True) for n in self._param_names]
 
-    def _make_engine(self, B, S, old):
+    def _make_engine(self, B, S, shared):
         from slnlp import rnn_engine as re_
         cfg = re_.make_config(B=B, S=S, **self._cfg_args)
         eng = re_.RnnEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
-                            grads=old.grads if old else None, momentum=old.momentum if old else None)
+                            grads=shared["grads"], momentum=shared["momentum"], rng=shared["rng"], lr=shared["lr"])
         if getattr(self, "persistent_kernels", False):        # opt-in (never when several fits share the GPU)
             eng.set_persistent(True)
         return eng

@@ -89,11 +89,11 @@ class Transformer(ArenaModule):
     def _move_buffers(self, device):
         self._pe = self._pe.to(device)
 
-    def _make_engine(self, B, S, old):
+    def _make_engine(self, B, S, shared):
         from slnlp import tf_engine as te
         cfg = te.make_config(B=B, S=S, **self._cfg_args)
         return te.TransformerEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
-                                    grads=old.grads if old else None, momentum=old.momentum if old else None,
+                                    grads=shared["grads"], momentum=shared["momentum"], rng=shared["rng"], lr=shared["lr"],
                                     pe=self._pe.view(-1, self.embedding_size))
 
     def forward(self, X, y, lengths=None, **kwargs):

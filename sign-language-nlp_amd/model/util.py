@@ -52,6 +52,14 @@ def resolve_lengths(data, vocab, dim=-1):
     return data.size(dim) - data.eq(pad_idx).sum(dim=dim)
 
 
+class _Stoi(dict):
+    """token -> index; unknown tokens answer 0 (``<unk>``) like torchtext-0.6's defaultdict.  Module-level so that a
+    ``Vocab`` (and any module / estimator holding one) pickles."""
+
+    def __missing__(self, key):
+        return 0
+
+
 class Vocab:
     """Minimal stand-in for the torchtext-0.6 ``Vocab`` the reference passes as
     ``src_vocab`` / ``tgt_vocab``: the model only needs ``.stoi[str]`` and
@@ -64,11 +72,6 @@ class Vocab:
         else:
             toks = [t for t in tokens_or_size if t not in (UNK_WORD, PAD_WORD)]
         self.itos = [UNK_WORD, PAD_WORD] + toks
-
-        class _Stoi(dict):
-            def __missing__(self, key):
-                return 0
-
         self.stoi = _Stoi({t: i for i, t in enumerate(self.itos)})
 
     def __len__(self):

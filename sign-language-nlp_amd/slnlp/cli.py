@@ -57,22 +57,30 @@ def load_config(path=None, overrides=None):
 
 
 def format_dir(workdir, **kwargs):
-    """helper.py:307-313: ``workdir`` may reference any argument and ``{datetime:%Y-...}``."""
-    if workdir is None:
+    """``workdir`` is a ``str.format`` template over the run's arguments plus ``{datetime:%Y-...}`` (the reference's
+    config files use ``{model}`` and ``{datetime:...}``, config-transformer.yaml:4; helper.py:307-313).  No workdir ->
+    the empty string."""
+    if not workdir:
         return ""
-    return os.path.normpath(workdir.format(datetime=datetime.datetime.now(), **kwargs))
+    fields = dict(kwargs, datetime=datetime.datetime.now())
+    return os.path.normpath(workdir.format(**fields))
 
 
 def prefix_args(prefix, ensure_list=False, output=None, **kwargs):
-    """helper.py:325-341: {a: {b: v}} -> {"prefix__a__b": v} (values wrapped in lists for a parameter grid)."""
-    output = {} if output is None else output
-    for k, v in kwargs.items():
-        name = k if prefix is None else f"{prefix}__{k}"
-        if isinstance(v, dict):
-            prefix_args(prefix=name, output=output, ensure_list=ensure_list, **v)
+    """Flatten nested argument dicts into skorch's double-underscore names: ``prefix_args("module", a={"b": v})`` ->
+    ``{"module__a__b": v}`` (helper.py:325-341).  ``ensure_list`` wraps scalars in one-element lists, the form a
+    parameter grid needs.  Iterative (explicit stack of (name, value) pairs), leaves in depth-first key order."""
+    flat = {} if output is None else output
+    stack = [(k if prefix is None else f"{prefix}__{k}", v) for k, v in reversed(list(kwargs.items()))]
+    while stack:
+        name, value = stack.pop()
+        if isinstance(value, dict):
+            stack.extend((f"{name}__{k}", v) for k, v in reversed(list(value.items())))
+        elif ensure_list and not isinstance(value, list):
+            flat[name] = [value]
         else:
-            output[name] = [v] if ensure_list and not isinstance(v, list) else v
-    return output
+            flat[name] = value
+    return flat
 
 
 def build_param_grid(grid_args):
@@ -173,7 +181,9 @@ def run(args):
     if world > 1:
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            # the only collectives are the dataset broadcast and the score all_gather, hours apart on a full grid:
+            # the default 10-minute watchdog would abort ranks that wait for a slower one
+            dist.init_process_group("nccl", device_id=torch.device(device), timeout=datetime.timedelta(hours=48))
     workdir = args.get("workdir") or "."
     if rank == 0:
         os.makedirs(workdir, exist_ok=True)
@@ -212,11 +222,28 @@ def run(args):
         est = gs.best_estimator_
         test_output = {f"test_{m}": float(ScoringWrapper(m, test_data.labels())(est, test_data, test_data.y)) for m in metrics}
         save_json(test_output, os.path.join(workdir, "test_output.json"))
-        est.save_params(workdir)
+        # workdir/{params,optimizer,criterion}.pt + history.json are the refit's best-valid-loss checkpoint (skorch
+        # Checkpoint(monitor="valid_loss_best", dirname=workdir), helper.py:211-213) and stay untouched; the weights
+        # after the last epoch (not kept by the reference) go to a directory of their own
+        est.save_params(os.path.join(workdir, "final"))
     if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+        _wait_for_rank0(rank, world)
     return gs, test_output
+
+
+def _wait_for_rank0(rank, world):
+    """Ranks > 0 are done after the score all_gather; rank 0 still refits and tests.  Wait on the rendezvous store (a
+    host-side key, no collective: nothing for a watchdog to time out) so the process group is torn down together."""
+    import torch.distributed as dist
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        if rank == 0:
+            store.set("slnlp/cli/done", "1")
+        else:
+            store.wait(["slnlp/cli/done"], datetime.timedelta(hours=48))
+    except Exception:
+        dist.barrier()
 
 
 def main(argv=None):

@@ -12,11 +12,22 @@ asl_dataset.py:48-55 / transformer.py:65) and exposes ``vocab_X`` / ``vocab_y``.
 import numpy as np
 
 
+class LabelArray(np.ndarray):
+    """``dataset.y`` as the int64 array everything here indexes -- and callable, so the reference's spelling
+    ``train_data.y().to_array()`` (main.py:77, asl_dataset.py:200-208) reads the same labels."""
+
+    def __call__(self):
+        return self
+
+    def to_array(self):
+        return np.asarray(self)
+
+
 class TokenDataset:
     def __init__(self, X, lengths, y, vocab_X=None, vocab_y=None):
         self.ids = np.ascontiguousarray(X, dtype=np.int64)
         self.lengths = np.ascontiguousarray(lengths, dtype=np.int64)
-        self.y = np.ascontiguousarray(y, dtype=np.int64)
+        self.y = np.ascontiguousarray(y, dtype=np.int64).view(LabelArray)
         assert self.ids.ndim == 2 and len(self.ids) == len(self.lengths) == len(self.y)
         self.vocab_X, self.vocab_y = vocab_X, vocab_y
         self.batch_first = True
@@ -40,7 +51,7 @@ class TokenDataset:
         return self
 
     def to_array(self):
-        return self.y
+        return np.asarray(self.y)
 
     def labels(self):
         """Every index of the target vocabulary, specials included (asl_dataset.py:210-213 returns

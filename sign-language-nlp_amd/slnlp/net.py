@@ -41,32 +41,28 @@ def _resolve(obj):
 
 
 class ScoringWrapper:
-    """helper.py:529-554: sklearn scorer by name; ``labels`` for log-loss, ``zero_division=0`` otherwise."""
+    """Named sklearn scorer with the extra keyword the reference gives each metric (helper.py:529-554): log-loss is told
+    the full label set (a fold may miss classes), the precision / recall / F1 family gets ``zero_division=0``, accuracy
+    takes nothing.  Exposes ``score`` (the name) and ``greater_is_better`` -- what the reference's EpochScoring and
+    GridSearchCV wiring read (helper.py:255-268, 183-194)."""
+
+    _EXTRA = {"neg_log_loss": lambda labels: {"labels": labels}, "accuracy": lambda labels: {}}
 
     def __init__(self, score_func, labels=None):
         from sklearn.metrics import get_scorer
-        self._score_func = score_func
-        self.scorer = get_scorer(score_func)
-        if score_func == 'neg_log_loss':
-            self.scorer._kwargs["labels"] = labels
-        elif score_func == 'accuracy':
-            pass
-        else:
-            self.scorer._kwargs["zero_division"] = 0
+        self.score = score_func
+        base = get_scorer(score_func)
+        extra = self._EXTRA.get(score_func, lambda labels: {"zero_division": 0})(labels)
+        self.greater_is_better = base._sign > 0
+        # a scorer object of the same kind with the merged keywords (get_scorer hands out a fresh copy per call)
+        base._kwargs = {**base._kwargs, **extra}
+        self.scorer = base
 
     def __call__(self, estimator, X, y_true, sample_weight=None):
         return self.scorer(estimator, X, y_true, sample_weight)
 
     def __repr__(self):
-        return f"{type(self).__name__}('{self._score_func}')"
-
-    @property
-    def greater_is_better(self):
-        return self.scorer._sign == 1
-
-    @property
-    def score(self):
-        return self._score_func
+        return "%s('%s')" % (type(self).__name__, self.score)
 
 
 from sklearn.base import BaseEstimator, ClassifierMixin  # noqa: E402  (sklearn >= 1.6 scorers require classifier tags)
@@ -104,6 +100,53 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             self._params[k] = v
         self.initialized_ = False
         self.history = []
+        self._apply_callbacks(callbacks)
+
+    # skorch callback objects (helper.py:197-273 builds Checkpoint, EarlyStopping, GradientNormClipping, LRScheduler and
+    # EpochScoring instances) are translated, by class name and public attributes, into the settings this loop
+    # implements natively; a callback it cannot honour is an error, never silently dropped.
+    _COSMETIC_CALLBACKS = ("PrintLog", "ProgressBar", "EpochTimer", "PassthroughScoring")
+
+    def _apply_callbacks(self, callbacks):
+        if callbacks in (None, "disable", []):
+            return
+        scoring = list(self._params.get("scoring") or [])
+        for cb in callbacks:
+            obj = cb[1] if isinstance(cb, tuple) else cb
+            kind = type(obj).__name__
+            get = lambda k, d=None: getattr(obj, k, d)
+            if kind == "EarlyStopping":
+                if get("monitor", "valid_loss") != "valid_loss" or not get("lower_is_better", True):
+                    raise ValueError("EarlyStopping: only monitor='valid_loss', lower_is_better=True is implemented")
+                self._params["early_stopping"] = {"patience": get("patience", 5), "threshold": get("threshold", 1e-4),
+                                                  "threshold_mode": get("threshold_mode", "rel")}
+            elif kind == "GradientNormClipping":
+                self._params["gradient_clipping"] = {"gradient_clip_value": get("gradient_clip_value")}
+            elif kind == "LRScheduler":
+                pol = get("policy", "ReduceLROnPlateau")
+                pol = pol if isinstance(pol, str) else getattr(pol, "__name__", str(pol))
+                if pol != "ReduceLROnPlateau" or get("monitor", "valid_loss") != "valid_loss":
+                    raise ValueError("LRScheduler: only ReduceLROnPlateau on valid_loss is implemented")
+                self._params["lr_scheduler"] = {"policy": pol, **dict(get("kwargs", {}) or {})}
+            elif kind == "Checkpoint":
+                if get("monitor", "valid_loss_best") != "valid_loss_best":
+                    raise ValueError("Checkpoint: only monitor='valid_loss_best' is implemented")
+                self._params["checkpoint_dir"] = get("dirname")
+            elif kind == "EpochScoring":
+                sc = get("scoring")
+                name = sc if isinstance(sc, str) else getattr(sc, "score", None)
+                if get("name") == "lr":
+                    continue                                  # every history row carries lr already
+                if not isinstance(name, str):
+                    raise ValueError("EpochScoring: scoring must be a metric name or a ScoringWrapper")
+                if name not in scoring:
+                    scoring.append(name)                      # both splits are scored for every metric
+            elif kind in self._COSMETIC_CALLBACKS:
+                continue
+            else:
+                raise TypeError(f"NeuralNetClassifier: callback {kind!r} has no equivalent in the fused fit loop")
+        if scoring:
+            self._params["scoring"] = scoring
 
     # ------------------------------------------------------------ sklearn API
     def get_params(self, deep=True):
@@ -112,6 +155,8 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
     def set_params(self, **params):
         for k, v in params.items():
             self._params[k] = v
+        if params.get("callbacks") is not None:
+            self._apply_callbacks(params["callbacks"])
         return self
 
     def __getattr__(self, name):
@@ -195,11 +240,13 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             for epoch in range(len(self.history) + 1, len(self.history) + int(self.max_epochs) + 1):
                 t0 = time.time()
                 self.module_.train()
-                tr_loss, tr_logp = self._run_epoch(Xtr, Ltr, ytr, bs, True, momentum, max_norm)
-                row = {"epoch": epoch, "train_loss": tr_loss, "lr": self.lr_}
+                tr_loss, tr_logp, tr_batches = self._run_epoch(Xtr, Ltr, ytr, bs, True, momentum, max_norm)
+                row = {"epoch": epoch, "train_loss": tr_loss, "lr": self.lr_,
+                       "batches": [{"train_loss": l, "train_batch_size": n} for l, n in tr_batches]}   # skorch history layout
                 if va is not None:
                     self.module_.eval()
-                    va_loss, va_logp = self._run_epoch(Xva, Lva, yva, bs, False, momentum, max_norm)
+                    va_loss, va_logp, va_batches = self._run_epoch(Xva, Lva, yva, bs, False, momentum, max_norm)
+                    row["batches"] += [{"valid_loss": l, "valid_batch_size": n} for l, n in va_batches]
                     row["valid_loss"] = va_loss
                     row["valid_loss_best"] = bool(va_loss < best_valid)
                     best_valid = min(best_valid, va_loss)
@@ -220,7 +267,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                 row["dur"] = time.time() - t0
                 self.history.append(row)
                 if self.verbose:
-                    print("  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in row.items()))
+                    print("  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in row.items() if k != "batches"))
                 if self.checkpoint_dir and row.get("valid_loss_best"):
                     self.save_params(self.checkpoint_dir)
                 monitor = row.get("valid_loss", tr_loss)
@@ -260,7 +307,8 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                 g["lr"] = self.lr_
 
     def _run_epoch(self, X, L, y, bs, train, momentum, max_norm):
-        """One pass in dataset order.  Returns (sample-weighted mean loss, log-probs [N,V] on the device)."""
+        """One pass in dataset order.  Returns (sample-weighted mean loss, log-probs [N,V] on the device,
+        [(batch loss, batch size)])."""
         n = X.shape[0]
         losses, sizes, outs = [], [], []
         for i in range(0, n, bs):
@@ -288,9 +336,10 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                         losses.append(self.criterion_(logp, yb))
             sizes.append(xb.shape[0])
             outs.append(logp.detach().clone())
-        w = torch.tensor(sizes, dtype=torch.float32, device=X.device)
-        mean = float((torch.stack(losses).float() * w).sum() / w.sum())      # one sync per epoch
-        return mean, torch.cat(outs)
+        per_batch = torch.stack(losses).float().cpu()                       # one sync per epoch
+        w = torch.tensor(sizes, dtype=torch.float32)
+        mean = float((per_batch * w).sum() / w.sum())
+        return mean, torch.cat(outs), list(zip(per_batch.tolist(), sizes))
 
     # --------------------------------------------------------------- predict
     def predict_proba(self, X):
@@ -317,21 +366,62 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         return float((self.predict(ds) == (ds.y if y is None else np.asarray(y))).mean())
 
     # ------------------------------------------------------------ checkpoint
+    def _sgd_state_dict(self):
+        """The fused update's momentum arena as a ``torch.optim.SGD.state_dict()``: one ``momentum_buffer`` per parameter,
+        in ``module.parameters()`` order, plus the param group with the current lr -- what skorch's Checkpoint writes as
+        optimizer.pt (helper.py:211-213) and what ``torch.optim.SGD.load_state_dict`` reads back."""
+        params = dict(self.module_.named_parameters())
+        opt = torch.optim.SGD([p for n, p in params.items()], lr=self.lr_, **self._opt_kwargs)
+        st = self.module_._shared_state()
+        mom = st["momentum"]
+        for name, shape, off in self.module_._entries:
+            if name in self.module_._dead_params:
+                continue                                   # never receives a gradient: torch keeps no state for it
+            n = 1
+            for d in shape:
+                n *= d
+            opt.state[params[name]]["momentum_buffer"] = mom[off:off + n].view(*shape).detach().cpu().clone()
+        return opt.state_dict()
+
+    def _load_sgd_state_dict(self, sd):
+        names = [n for n, _ in self.module_.named_parameters()]
+        ent = {n: (shape, off) for n, shape, off in self.module_._entries}
+        st = self.module_._shared_state()
+        for idx, state in sd.get("state", {}).items():
+            shape, off = ent[names[int(idx)]]
+            buf = state.get("momentum_buffer")
+            if buf is not None:
+                st["momentum"][off:off + buf.numel()].copy_(buf.reshape(-1).to(st["momentum"].device, torch.float32))
+        groups = sd.get("param_groups") or [{}]
+        if "lr" in groups[0]:
+            self._set_lr(groups[0]["lr"])
+
     def save_params(self, dirname):
-        """skorch ``Checkpoint`` artefacts: params.pt (state_dict), optimizer.pt, criterion.pt, history.json."""
+        """skorch ``Checkpoint`` artefacts: params.pt (state_dict), optimizer.pt (a torch.optim state_dict in either
+        mode), criterion.pt, history.json."""
         os.makedirs(dirname, exist_ok=True)
         torch.save({k: v.detach().cpu() for k, v in self.module_.state_dict().items()}, os.path.join(dirname, "params.pt"))
-        if self._fused:
-            bufs = {f"S{S}": e.momentum.detach().cpu() for S, e in self.module_._engines.items()}
-            torch.save({"momentum_arena": bufs, "lr": self.lr_}, os.path.join(dirname, "optimizer.pt"))
-        else:
-            torch.save(self.optimizer_.state_dict(), os.path.join(dirname, "optimizer.pt"))
+        torch.save(self._sgd_state_dict() if self._fused else self.optimizer_.state_dict(), os.path.join(dirname, "optimizer.pt"))
         torch.save(self.criterion_.state_dict(), os.path.join(dirname, "criterion.pt"))
         with open(os.path.join(dirname, "history.json"), "w") as f:
             json.dump(self.history, f, indent=1)
 
     def load_params(self, dirname):
+        """Restore what ``save_params`` / skorch's Checkpoint wrote: weights, optimizer state (momentum buffers + lr) and,
+        when present, the history -- training resumes where the checkpoint was taken."""
         if not self.initialized_:
             self.initialize()
         self.module_.load_state_dict(torch.load(os.path.join(dirname, "params.pt")))
+        opt_file = os.path.join(dirname, "optimizer.pt")
+        if os.path.exists(opt_file):
+            sd = torch.load(opt_file)
+            if self._fused:
+                self._load_sgd_state_dict(sd)
+            else:
+                self.optimizer_.load_state_dict(sd)
+                self.lr_ = float(self.optimizer_.param_groups[0]["lr"])
+        hist = os.path.join(dirname, "history.json")
+        if os.path.exists(hist):
+            with open(hist) as f:
+                self.history = json.load(f)
         return self

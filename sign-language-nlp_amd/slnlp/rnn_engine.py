@@ -32,7 +32,7 @@ def layout(cfg):
 
 
 class RnnEngine:
-    def __init__(self, cfg, device="cuda", seed=0, params=None, grads=None, momentum=None):
+    def __init__(self, cfg, device="cuda", seed=0, params=None, grads=None, momentum=None, rng=None, lr=None):
         _lib.require_gpu()
         self.cfg, self.device = cfg, torch.device(device)
         self.entries, self.arena_floats = layout(cfg)
@@ -42,8 +42,10 @@ class RnnEngine:
         for t in (self.params, self.grads, self.momentum):
             assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.arena_floats and t.is_contiguous()
         self.workspace = torch.empty(int(load().slnlp_rnn_workspace_bytes(C.byref(cfg))), dtype=torch.uint8, device=dev)
-        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
-        self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        # rng = {seed, dropout step counter}; lr: read from device memory by the update kernel.  A module with several
+        # plans (one per sequence length) hands every plan the same two tensors
+        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev) if rng is None else rng
+        self.lr = torch.zeros(1, dtype=torch.float32, device=dev) if lr is None else lr
         self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)
         self.logp = torch.empty(cfg.B, cfg.Vt, dtype=torch.float32, device=dev)
         bufs = TfBuffers(ptr(self.params), ptr(self.grads), ptr(self.momentum), None, ptr(self.workspace),

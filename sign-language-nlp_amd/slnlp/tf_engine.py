@@ -51,7 +51,7 @@ def layout(cfg):
 class TransformerEngine:
     """One plan = one (config, max batch) on one GPU / one stream."""
 
-    def __init__(self, cfg, device="cuda", seed=0, max_len=5000, params=None, grads=None, momentum=None, pe=None):
+    def __init__(self, cfg, device="cuda", seed=0, max_len=5000, params=None, grads=None, momentum=None, pe=None, rng=None, lr=None):
         """``params`` / ``grads`` / ``momentum`` / ``pe``: adopt arenas owned by the caller (the
         drop-in ``model.Transformer`` keeps its nn.Parameters as views of ``params``)."""
         _lib.require_gpu()
@@ -66,8 +66,10 @@ class TransformerEngine:
         self.pe = positional_table(max_len, cfg.E).to(dev) if pe is None else pe   # [max_len, E]
         ws = int(load().slnlp_tf_workspace_bytes(C.byref(cfg)))
         self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
-        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
-        self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        # rng = {seed, dropout step counter}; lr: read from device memory by the update kernel.  A module with several
+        # plans (one per sequence length) hands every plan the same two tensors
+        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev) if rng is None else rng
+        self.lr = torch.zeros(1, dtype=torch.float32, device=dev) if lr is None else lr
         self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)
         self.logp = torch.empty(cfg.B, cfg.Vt, dtype=torch.float32, device=dev)
         bufs = TfBuffers(ptr(self.params), ptr(self.grads), ptr(self.momentum), ptr(self.pe), ptr(self.workspace),

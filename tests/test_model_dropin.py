@@ -155,3 +155,32 @@ def test_rnn_autograd_training_matches_golden(rnn_type):
         assert abs(float(norm) - g["grad_norms"][s]) < 2e-3 * g["grad_norms"][s], s
     assert dict(m.named_parameters())["model.decoder.pre_output_layer.weight"].grad is None   # dead weight, as in the reference
     gold.check_summary(g, "wfinal", {k: v.detach().cpu() for k, v in m.named_parameters()}, 1e-3)
+
+
+@pytest.mark.gpu
+def test_autograd_path_redraws_dropout_masks_and_shares_state_across_lengths():
+    """Stock-optimizer loop (no fused update): every training step must draw new dropout masks (the fused SGD kernel is what
+    advances the step counter otherwise), and plans for different sequence lengths share ONE rng / momentum / gradient
+    set owned by the module."""
+    g, c, sd, X, L, y = gold.tf_case("tiny")
+    m = make(c, dropout=0.5).to("cuda")
+    m.load_state_dict({**m.state_dict(), **sd})
+    m.train()
+    Xd, yd = X.cuda(), y.cuda()
+    outs = []
+    for _ in range(3):
+        lp = m(X=Xd, y=yd)
+        lp.sum().backward()                       # no optimizer step: the weights stay put, only the masks can differ
+        outs.append(lp.detach().cpu())
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    e_full = m.engine(Xd.shape[0], Xd.shape[1])
+    assert int(e_full.rng[1]) == 3
+    lp = m(X=Xd[:, :7].contiguous(), y=yd)        # a second sequence length -> a second plan
+    lp.sum().backward()
+    e_short = m.engine(Xd.shape[0], 7)
+    assert e_short is not e_full and int(e_full.rng[1]) == 4
+    for k in ("rng", "lr", "grads", "momentum"):
+        assert getattr(e_short, k).data_ptr() == getattr(e_full, k).data_ptr(), k
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(X=Xd, y=yd), m(X=Xd, y=yd))      # eval: no dropout

@@ -205,3 +205,66 @@ def test_sharded_grid_concurrent_rnn_fits_equal_sequential():
         gs = ShardedGridSearchCV(factory, pg, cv=2, refit=False, device="cuda", fits_per_gpu=k).fit(ds)
         out.append(gs.cv_results_["mean_test_score"])
     assert np.array_equal(out[0], out[1]) and np.isfinite(out[0]).all()
+
+
+def test_checkpoint_is_a_torch_sgd_state_dict_and_resumes(tmp_path):
+    """optimizer.pt of the fused path loads into a stock torch.optim.SGD over the module's parameters (momentum buffers
+    per parameter, lr in the param group) and ``load_params`` restores weights + momentum + lr: a resumed fit continues
+    the trajectory of an uninterrupted one.  history.json carries skorch's per-batch rows."""
+    import json
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(100, seq_len=10, src_vocab=50, n_labels=5, seed=8, min_len=3)
+    torch.manual_seed(3)
+    full = make_net(ds, max_epochs=4).fit(ds)
+    torch.manual_seed(3)
+    first = make_net(ds, max_epochs=2).fit(ds)
+    first.save_params(str(tmp_path))
+    sd = torch.load(tmp_path / "optimizer.pt")
+    names = [n for n, _ in first.module_.named_parameters()]
+    ref_opt = torch.optim.SGD(first.module_.parameters(), lr=123.0, momentum=0.9)
+    ref_opt.load_state_dict(sd)                                       # the stock optimizer accepts it
+    assert ref_opt.param_groups[0]["lr"] == pytest.approx(0.05) and ref_opt.param_groups[0]["momentum"] == 0.9
+    mom = first.module_._shared_state()["momentum"]
+    ent = {n: (shape, off) for n, shape, off in first.module_._entries}
+    for i, n in enumerate(names):
+        buf = sd["state"][i]["momentum_buffer"]
+        shape, off = ent[n]
+        assert tuple(buf.shape) == tuple(shape) and torch.equal(buf, mom[off:off + buf.numel()].view(*shape).cpu())
+    assert float(sd["state"][names.index("linear.weight")]["momentum_buffer"].abs().sum()) > 0
+    hist = json.load(open(tmp_path / "history.json"))
+    assert len(hist) == 2 and {"train_loss", "train_batch_size"} <= set(hist[0]["batches"][0])
+    assert {"valid_loss", "valid_batch_size"} <= set(hist[0]["batches"][-1])
+    assert sum(b["train_batch_size"] for b in hist[0]["batches"] if "train_batch_size" in b) == 80
+    # resume in a fresh estimator: epochs 3-4 reproduce the uninterrupted run
+    torch.manual_seed(99)                                              # different initial weights: must be overwritten
+    resumed = make_net(ds, max_epochs=2, warm_start=True).initialize()
+    resumed.load_params(str(tmp_path))
+    # the dropout step counter is not part of a skorch checkpoint; dropout is 0 here so the trajectory is deterministic
+    resumed.partial_fit(ds)
+    assert [h["epoch"] for h in resumed.history] == [1, 2, 3, 4]
+    for a, b in zip(resumed.history[2:], full.history[2:]):
+        assert a["train_loss"] == pytest.approx(b["train_loss"], rel=1e-5), (a["train_loss"], b["train_loss"])
+        assert a["valid_loss"] == pytest.approx(b["valid_loss"], rel=1e-5)
+
+
+def test_rccl_collectives_of_the_grid_on_one_gpu(tmp_path):
+    """The nccl (= RCCL) branch of broadcast_dataset / all_gather executed on hardware: a one-rank RCCL group with
+    ``force_collectives`` sends the packed dataset and the score rows through RCCL and must give the results of the
+    collective-free run."""
+    import torch.distributed as dist
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV, broadcast_dataset
+    ds = synthetic_dataset(60, seq_len=10, src_vocab=50, n_labels=3, seed=9, min_len=3)
+    grid = {"lr": [0.1, 0.01], "module__num_layers": [1, 2]}
+    plain = ShardedGridSearchCV(lambda: make_net(ds, max_epochs=1), grid, cv=2, refit=False, device="cuda:0").fit(ds)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got = broadcast_dataset(ds, "cuda:0", force=True)
+        assert np.array_equal(got.ids, ds.ids) and np.array_equal(got.y, ds.y) and np.array_equal(got.lengths, ds.lengths)
+        gs = ShardedGridSearchCV(lambda: make_net(ds, max_epochs=1), grid, cv=2, refit=False, device="cuda:0",
+                                 force_collectives=True).fit(ds)
+        assert dist.get_backend() == "nccl" and gs.rank_tasks_ == [8]
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(gs.cv_results_["mean_test_score"], plain.cv_results_["mean_test_score"])
+    assert gs.best_index_ == plain.best_index_
