@@ -89,11 +89,15 @@ def collate_data(data):
     return {"X": X, "lengths": X_lengths, "y": y}, y
 
 
-def synthetic_dataset(n, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8):
+def synthetic_dataset(n, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8, with_vocab=True):
     """Synthetic ASL-Phono-shaped dataset: ``n_labels`` glosses (+ <unk>, <pad>) and learnable
-    structure -- each label draws its tokens from a label-specific slice of the vocabulary."""
+    structure -- each label draws its tokens from a label-specific slice of the vocabulary.
+    ``with_vocab=False``: arrays only (tools/gen_golden.py runs with the reference's ``model`` package imported)."""
     from . import synth
-    from model.util import Vocab
+    if with_vocab:
+        from model.util import Vocab
+    else:
+        Vocab = lambda size: None
     rs = np.random.RandomState(seed)
     tgt_vocab = n_labels + 2
     X, lengths, _ = synth.make_batch(n, seq_len, src_vocab, tgt_vocab, seed=seed, min_len=min_len)

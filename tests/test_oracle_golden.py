@@ -60,20 +60,21 @@ def _tf_trainer(c, sd):
     return train_ref.Trainer(sd, fwd, pad_tgt=1, lr=0.01, momentum=0.9, max_norm=0.5)
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "e1024"])     # cfg5's step (4.5 TFLOP on the CPU) is pinned on the GPU side only
 def test_transformer_train(name):
     g, c, sd, X, L, y = gold.tf_case(name)
     trn = _tf_trainer(c, sd)
     _, _, grads = trn.loss_and_grads(X, y, L)
-    gold.check_summary(g, "grad0", grads, TOL_TRAIN)
+    tol = TOL_TRAIN if c["E"] < 1024 else 5e-4       # E 1024 / head_dim 256: fp32 summation order alone gives 2.1e-4 on the norm
+    gold.check_summary(g, "grad0", grads, tol)
     for s in range(len(g["losses"])):
         loss, total, _ = trn.step(X, y, L)
         assert abs(float(loss) - g["losses"][s]) / g["losses"][s] < TOL_TRAIN, s
-        assert abs(float(total) - g["grad_norms"][s]) / g["grad_norms"][s] < TOL_TRAIN, s
-    gold.check_summary(g, "wfinal", trn.sd, TOL_TRAIN)
+        assert abs(float(total) - g["grad_norms"][s]) / g["grad_norms"][s] < tol, s
+    gold.check_summary(g, "wfinal", trn.sd, tol)
 
 
-RNN = [("lstm", "tiny"), ("lstm", "mid"), ("lstm", "cfg3"), ("gru", "tiny"), ("gru", "mid")]
+RNN = [("lstm", "tiny"), ("lstm", "mid"), ("lstm", "cfg3"), ("gru", "tiny"), ("gru", "mid"), ("gru", "cfg3")]
 
 
 @pytest.mark.parametrize("rnn_type,name", RNN)
@@ -95,7 +96,7 @@ def test_rnn_forward(rnn_type, name):
         assert gold.rel_err(taps["alphas"].numpy(), g["tap_alphas"]) < TOL_FWD
 
 
-@pytest.mark.parametrize("rnn_type,name", [r for r in RNN if r[1] != "cfg3"])
+@pytest.mark.parametrize("rnn_type,name", RNN)
 def test_rnn_train(rnn_type, name):
     g, c, sd, X, L, y = gold.rnn_case(rnn_type, name)
     fwd = lambda p, X, y, L: rnn_ref.forward(p, X, y, L, rnn_type=rnn_type, num_layers=c["N"])
@@ -111,3 +112,66 @@ def test_rnn_train(rnn_type, name):
         assert abs(float(loss) - g["losses"][s]) / g["losses"][s] < TOL_TRAIN, s
         assert abs(float(total) - g["grad_norms"][s]) / g["grad_norms"][s] < TOL_TRAIN, s
     gold.check_summary(g, "wfinal", trn.sd, TOL_TRAIN)
+
+
+# G8 tolerances per epoch.  A fit is a chaotic map (tools/gen_golden.py, FIT_CASE): the oracle under another torch thread
+# count already moves the epoch-e valid loss by ~1e-8 x 10^e at lr 0.01, so the bar widens with the epoch there; the lr
+# 0.001 run holds the tight bar over all five epochs.
+G8_TOL = {0.001: [5e-5] * 5, 0.01: [5e-5, 1e-4, 1e-3, 1e-3, 5e-3]}
+
+
+@pytest.mark.parametrize("lr", [0.001, 0.01])
+def test_fit_trajectory_g8(lr):
+    """G8: the restated skorch loop around the ORACLE forward reproduces the loop around the reference module
+    (tests/golden/fit_cfg1.npz: cfg1 shape, 5 epochs, 1000 synthetic samples, 200 labels): epoch losses and the
+    reference's five metrics on both splits."""
+    from sklearn.model_selection import StratifiedKFold
+    from sklearn.metrics import accuracy_score, f1_score, log_loss, precision_score, recall_score
+    from slnlp import synth
+    from slnlp.data import synthetic_dataset
+    g = gold.load("fit_cfg1")
+    Vs, nl, E, H, N, F, S, n, bs, epochs = [int(v) for v in g["cfg"]]
+    mom, clip = [float(v) for v in g["mom_clip"]]
+    hist = g[f"history_lr{lr}"]
+    ds = synthetic_dataset(n, seq_len=S, src_vocab=Vs, n_labels=nl, seed=1, min_len=8)
+    Vt = nl + 2
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(tr.param_shapes(E, H, N, F, Vs, Vt), seed=1).items()}
+    fwd = lambda p, X, y, L: tr.forward(p, X, y, num_heads=H, num_layers=N)
+    trn = train_ref.Trainer(sd, fwd, pad_tgt=1, lr=lr, momentum=mom, max_norm=clip)
+    tr_idx, va_idx = next(iter(StratifiedKFold(n_splits=5).split(np.arange(n), ds.y)))
+    assert (len(tr_idx), len(va_idx)) == (int(g["n_train"]), int(g["n_valid"]))
+    cols = list(g["columns"])
+    labels = list(range(Vt))
+
+    def metrics(logp, y):
+        proba = torch.softmax(logp, -1).double().numpy()
+        pred = proba.argmax(1)
+        kw = dict(average="weighted", zero_division=0)
+        return [-log_loss(y, proba, labels=labels), accuracy_score(y, pred), precision_score(y, pred, **kw),
+                recall_score(y, pred, **kw), f1_score(y, pred, **kw)]
+    torch.set_num_threads(8)
+    for ep in range(epochs):
+        row = {}
+        for split, idx in (("train", tr_idx), ("valid", va_idx)):
+            X, y = torch.from_numpy(ds.ids[idx]), torch.from_numpy(np.asarray(ds.y)[idx])
+            tot, outs = 0.0, []
+            for i in range(0, len(idx), bs):
+                if split == "train":
+                    loss, _, logp = trn.step(X[i:i + bs], y[i:i + bs], None)
+                else:
+                    with torch.no_grad():
+                        logp = fwd(trn.sd, X[i:i + bs], y[i:i + bs], None)
+                        loss = train_ref.cross_entropy_on_logprobs(logp, y[i:i + bs], 1)
+                tot += float(loss) * len(y[i:i + bs])
+                outs.append(logp)
+            row[split + "_loss"] = tot / len(idx)
+            for k, v in zip(g["metrics"], metrics(torch.cat(outs), np.asarray(ds.y)[idx])):
+                row[f"{split}_{k}"] = v
+        for j, k in enumerate(cols):
+            ref = hist[ep, j]
+            if "loss" in k:                      # train_loss, valid_loss, *_neg_log_loss: continuous in the log-probs
+                assert abs(row[k] - ref) <= G8_TOL[lr][ep] * abs(ref), (ep, k, row[k], ref)
+            else:                                # arg-max metrics move in steps: allow near-tie samples to flip
+                n_split = len(tr_idx) if k.startswith("train") else len(va_idx)
+                assert abs(row[k] - ref) <= (2.5 if ep < 3 else 6.5) / n_split, (ep, k, row[k], ref)
+    gold.check_summary(g, f"wfinal_lr{lr}", trn.sd, 5e-4 if lr == 0.001 else 5e-3)

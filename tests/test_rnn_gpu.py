@@ -20,7 +20,7 @@ def make_engine(c, sd, dropout=0.0, precision=3, seed=0):
     return eng
 
 
-CASES = [("lstm", "tiny"), ("lstm", "mid"), ("lstm", "cfg3"), ("gru", "tiny"), ("gru", "mid")]
+CASES = [("lstm", "tiny"), ("lstm", "mid"), ("lstm", "cfg3"), ("gru", "tiny"), ("gru", "mid"), ("gru", "cfg3")]
 
 
 def test_layout_is_reference_state_dict():
@@ -61,9 +61,11 @@ def test_forward_vs_golden(rnn_type, name):
         assert gold.rel_err(fin[:, :8].numpy(), g["tap_enc_final"]) < TOL
 
 
-@pytest.mark.parametrize("rnn_type,name", [c for c in CASES if c[1] != "cfg3"])
+@pytest.mark.parametrize("rnn_type,name", CASES)
 def test_train_steps_vs_golden(rnn_type, name):
+    """Reference trajectories: 5 steps tiny, 2 steps mid and at the configs[2] shape (E512 Hd512 N4), LSTM and GRU."""
     g, c, sd, X, L, y = gold.rnn_case(rnn_type, name)
+    assert len(g["losses"]) == (5 if name == "tiny" else 2)
     eng = make_engine(c, sd)
     eng.set_lr(0.01)
     Xc, yc, Lc = X.cuda(), y.cuda(), L.cuda()

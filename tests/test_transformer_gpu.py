@@ -18,6 +18,7 @@ TOL = 1e-3          # north_star: logits / loss within 1e-3 rel
 # GEMMs on the CPU with an exact-product 6-term bf16 split already differs from torch fp32 by 3e-3
 # (cfg1) .. 4e-3 (cfg2) of the tensor max, the shipped 3-term split by 5e-3 .. 4e-2.
 TOL_GRAD = 2e-2     # per-tensor gradient error relative to the tensor max (2-layer configs)
+TOL_NORM = 2e-3     # pre-clip total gradient norm (measured <= 4e-4): a sum over 27 M elements averages the gate flips out
 
 
 def make_engine(c, sd, dropout=0.0, precision=3, B=None, seed=0):
@@ -122,22 +123,26 @@ def test_gradients_vs_oracle(name):
     assert float(gv["src_embedding.weight"][1].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "e1024", "cfg5"])
 def test_train_steps_vs_golden(name):
+    """Reference training trajectories (tools/gen_golden.py::train_steps): 5 steps for tiny / cfg1 / cfg2 (the headline
+    config), one step at the E1024 and configs[4] shapes -- per-tensor gradients of step 0, loss and pre-clip gradient
+    norm of every step, every weight tensor after the last step."""
     g, c, sd, X, L, y = gold.tf_case(name)
+    assert len(g["losses"]) == (5 if name in ("tiny", "cfg1", "cfg2") else 1)
     eng = make_engine(c, sd)
     eng.set_lr(0.01)
     Xc, yc = X.cuda(), y.cuda()
     eng.forward(Xc, yc, train=True)
     eng.backward()
     gold.check_summary(g, "grad0", {k: v.cpu() for k, v in eng.views(eng.grads).items()},
-                       TOL_GRAD if name != "cfg2" else 5e-2)
+                       TOL_GRAD if c["N"] <= 2 else 5e-2)
     for s in range(len(g["losses"])):
         eng.train_step(Xc, yc, momentum=0.9, max_norm=0.5)
         torch.cuda.synchronize()
         print(f"[{name}] step {s}: loss {eng.loss:.6f} (ref {g['losses'][s]:.6f}) norm {eng.grad_norm:.5f} (ref {g['grad_norms'][s]:.5f})")
         assert abs(eng.loss - g["losses"][s]) < TOL * g["losses"][s]
-        assert abs(eng.grad_norm - g["grad_norms"][s]) < TOL_GRAD * g["grad_norms"][s]
+        assert abs(eng.grad_norm - g["grad_norms"][s]) < TOL_NORM * g["grad_norms"][s]
     gold.check_summary(g, "wfinal", {k: v.cpu() for k, v in eng.views().items()}, TOL)
 
 

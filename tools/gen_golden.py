@@ -29,15 +29,15 @@ TF_CASES = {
     # name: Vs, Vt, E, H, N, F, B, S, min_len, train_steps
     "tiny": dict(Vs=64, Vt=16, E=32, H=4, N=2, F=64, B=4, S=12, min_len=3, steps=5),
     "cfg1": dict(Vs=3000, Vt=202, E=128, H=4, N=2, F=256, B=50, S=48, min_len=8, steps=5),
-    "cfg2": dict(Vs=3000, Vt=202, E=512, H=8, N=6, F=512, B=50, S=48, min_len=8, steps=1),
-    "e1024": dict(Vs=3000, Vt=202, E=1024, H=4, N=2, F=128, B=50, S=48, min_len=8, steps=0),
+    "cfg2": dict(Vs=3000, Vt=202, E=512, H=8, N=6, F=512, B=50, S=48, min_len=8, steps=5),
+    "e1024": dict(Vs=3000, Vt=202, E=1024, H=4, N=2, F=128, B=50, S=48, min_len=8, steps=1),
     # BASELINE.json configs[4] shape (d_model 1024, 6 layers, batch 256, len 64; F = grid max 512, fp32 reference weights)
-    "cfg5": dict(Vs=3000, Vt=202, E=1024, H=8, N=6, F=512, B=256, S=64, min_len=8, steps=0),
+    "cfg5": dict(Vs=3000, Vt=202, E=1024, H=8, N=6, F=512, B=256, S=64, min_len=8, steps=1),
 }
 RNN_CASES = {
     "tiny": dict(Vs=64, Vt=16, E=24, Hd=32, N=2, B=4, S=12, min_len=3, steps=5),
     "mid": dict(Vs=3000, Vt=202, E=128, Hd=256, N=2, B=50, S=48, min_len=8, steps=2),
-    "cfg3": dict(Vs=3000, Vt=202, E=512, Hd=512, N=4, B=50, S=48, min_len=8, steps=0),
+    "cfg3": dict(Vs=3000, Vt=202, E=512, Hd=512, N=4, B=50, S=48, min_len=8, steps=2),
 }
 LR, MOM, CLIP, PAD = 0.01, 0.9, 0.5, 1
 HEAD = 16  # leading elements of each tensor kept as a slice
@@ -201,6 +201,106 @@ def gen_masks_pe(model):
     np.savez_compressed(os.path.join(OUT, "masks_pe.npz"), **out)
 
 
+# Two learning rates of the grid (config-transformer.yaml:46).  A fit is a chaotic map: measured with the CPU oracle, another
+# torch thread count (= another fp32 summation order) moves the epoch-e valid loss by ~1e-8 x 10^e at lr 0.01 (1.4e-4 at
+# epoch 4) and by ~2e-8 x 5^e at lr 0.001 (1.2e-6 at epoch 4); at cfg1's own lr 0.1 one epoch already gives 8e-4.  The
+# lr 0.001 run is the tight pin, the lr 0.01 run checks a trajectory that actually learns (valid accuracy 0.5 % -> 21 %).
+FIT_CASE = dict(Vs=3000, n_labels=200, E=128, H=4, N=2, F=256, S=48, n=1000, batch=50, epochs=5, lrs=(0.001, 0.01))
+FIT_METRICS = ["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"]   # config-transformer.yaml:9
+
+
+def gen_fit(model):
+    out = {}
+    for lr in FIT_CASE["lrs"]:
+        gen_fit_one(model, lr, out)
+    np.savez_compressed(os.path.join(OUT, "fit_cfg1.npz"), **out)
+
+
+def gen_fit_one(model, lr, out):
+    """G8: the skorch fit loop the reference configures (helper.py:41-105, 197-273), restated with
+    stock torch pieces around the REFERENCE module -- cfg1 shape, 5 epochs, synthetic 200-label data, dropout 0:
+    CVSplit(5) = first fold of StratifiedKFold(5) as the valid split, batches of 50 in dataset order, CrossEntropyLoss(
+    ignore_index=<pad>), clip_grad_norm_(0.5), SGD(momentum .9); per epoch the batch-size-weighted mean train / valid
+    loss and the reference's five metrics on both splits (sklearn scorers on softmax(log-probs), as skorch's
+    predict_nonlinearity='auto' does)."""
+    from sklearn.metrics import get_scorer
+    from sklearn.model_selection import StratifiedKFold
+    from slnlp.data import synthetic_dataset
+    c = FIT_CASE
+    ds = synthetic_dataset(c["n"], seq_len=c["S"], src_vocab=c["Vs"], n_labels=c["n_labels"], seed=1, min_len=8, with_vocab=False)
+    Vt = c["n_labels"] + 2
+    torch.manual_seed(0)
+    m = model.Transformer(embedding_size=c["E"], num_heads=c["H"], num_layers=c["N"], hidden_size=c["F"], dropout=0.0,
+                          src_vocab=Vocab(c["Vs"]), tgt_vocab=Vocab(Vt), device=torch.device("cpu"), batch_first=True)
+    m = m.to(torch.device("cpu"))
+    load_recipe(m)
+    import warnings
+    warnings.filterwarnings("ignore")
+    tr_idx, va_idx = next(iter(StratifiedKFold(n_splits=5).split(np.arange(len(ds)), ds.y)))
+    opt = torch.optim.SGD(m.parameters(), lr=lr, momentum=MOM, nesterov=False)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=PAD)
+    labels = list(range(Vt))
+
+    class Cached:                                     # predictions of the epoch, as skorch's scoring cache serves them
+        def __init__(self, proba):
+            self.proba, self.classes_ = proba, np.arange(Vt)
+        _estimator_type = "classifier"
+
+        def predict_proba(self, X):
+            return self.proba
+
+        def predict(self, X):
+            return self.proba.argmax(1)
+
+        def __sklearn_tags__(self):
+            from sklearn.utils import Tags, ClassifierTags, TargetTags, InputTags
+            return Tags(estimator_type="classifier", target_tags=TargetTags(required=True), classifier_tags=ClassifierTags(),
+                        input_tags=InputTags())
+
+    def scores(logp, y):
+        proba = torch.softmax(logp, -1).double().numpy()
+        out = []
+        for name in FIT_METRICS:
+            sc = get_scorer(name)
+            sc._kwargs = {**sc._kwargs, **({"labels": labels} if name == "neg_log_loss" else {} if name == "accuracy" else {"zero_division": 0})}
+            out.append(float(sc(Cached(proba), None, y)))
+        return out
+
+    def epoch(idx, train):
+        X, L, y = t(ds.ids[idx]), t(ds.lengths[idx]), t(np.asarray(ds.y)[idx])
+        tot, outs = 0.0, []
+        for i in range(0, len(idx), c["batch"]):
+            xb, lb, yb = X[i:i + c["batch"]], L[i:i + c["batch"]], y[i:i + c["batch"]]
+            if train:
+                m.train()
+                opt.zero_grad()
+                logp = m(X=xb, y=yb, lengths=lb)
+                loss = crit(logp, yb)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), CLIP)
+                opt.step()
+            else:
+                m.eval()
+                with torch.no_grad():
+                    logp = m(X=xb, y=yb, lengths=lb)
+                    loss = crit(logp, yb)
+            tot += float(loss) * len(yb)
+            outs.append(logp.detach())
+        return tot / len(idx), scores(torch.cat(outs), np.asarray(ds.y)[idx])
+
+    rows = []
+    for ep in range(c["epochs"]):
+        tl, ts = epoch(tr_idx, True)
+        vl, vs = epoch(va_idx, False)
+        rows.append([tl, vl] + ts + vs)
+        print("fit lr", lr, "epoch", ep, "train", tl, "valid", vl, "valid acc", vs[1])
+    out.update({"cfg": np.array([c[k] for k in ("Vs", "n_labels", "E", "H", "N", "F", "S", "n", "batch", "epochs")]),
+                "lrs": np.array(c["lrs"]), "mom_clip": np.array([MOM, CLIP]), "metrics": np.array(FIT_METRICS),
+                "columns": np.array(["train_loss", "valid_loss"] + ["train_" + k for k in FIT_METRICS] + ["valid_" + k for k in FIT_METRICS]),
+                f"history_lr{lr}": np.array(rows, np.float64), "n_train": np.array(len(tr_idx)), "n_valid": np.array(len(va_idx))})
+    summarize({k: p.detach().clone() for k, p in m.named_parameters()}, f"wfinal_lr{lr}", out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     model = import_reference_model()
@@ -208,13 +308,13 @@ def main():
     only = set(sys.argv[1:])                     # e.g. `gen_golden.py tf_cfg5`: regenerate just those fixtures
     if not only:
         gen_masks_pe(model)
+    if not only or "fit_cfg1" in only:
+        gen_fit(model)
     for name, c in TF_CASES.items():
         if not only or f"tf_{name}" in only:
             gen_transformer(model, name, c)
     for rnn_type in ("lstm", "gru"):
         for name, c in RNN_CASES.items():
-            if name == "cfg3" and rnn_type == "gru":
-                continue
             if not only or f"rnn_{rnn_type}_{name}" in only:
                 gen_rnn(model, rnn_type, name, c)
 
