@@ -352,6 +352,33 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* plan, int B, void* stream);
 int slnlp_tf_tap(slnlp_tf_plan* plan, const char* name, float* out, int64_t max_floats,
                  int64_t* n_out, void* stream);
 
+/* ---------------------------------------------------------------- lockstep --
+ * K Transformer fits of ONE shape (own weights, lr, dropout rate, seed and data) advancing through one launch
+ * sequence: every call site of the step is launched once for all K fits, so a 50-row decoder stage becomes a
+ * K x 50-row stage at the same latency.  Replaces the reference's one-fit-at-a-time dask tasks
+ * (/root/reference/main.py:70-78, helper.py:490-526) for the fits of a work unit; each fit's results are
+ * bit-identical to running it alone through slnlp_tf_train_step / slnlp_tf_forward.
+ * The plans must outlive the group and must not be stepped on their own while it exists.
+ * workspace: slnlp_tf_lockstep_workspace_bytes(cfg, K) bytes, 256-byte aligned, caller-owned (staging + tables). */
+typedef struct slnlp_tf_lockstep slnlp_tf_lockstep;
+int64_t slnlp_tf_lockstep_workspace_bytes(const slnlp_tf_config* cfg, int K);
+int slnlp_tf_lockstep_create(slnlp_tf_plan** plans, int K, void* workspace, int64_t workspace_bytes, void* stream,
+                             slnlp_tf_lockstep** out);
+void slnlp_tf_lockstep_destroy(slnlp_tf_lockstep* group);
+/* data slot (0..3, e.g. train / valid / test) of every fit: X[f] int64 [rows, S], y[f] int64 [rows] on the device,
+ * and where a pass over it leaves its results: logp[f] float [rows, Vt], loss[f] float [ceil(rows / batch)] */
+int slnlp_tf_lockstep_set_data(slnlp_tf_lockstep* group, int slot, const int64_t* const* X, const int64_t* const* y,
+                               int64_t rows, float* const* logp, float* const* loss, void* stream);
+/* rows [row0, row0 + B) of the slot, every fit: train != 0 -> forward + criterion + backward + clip + SGD-momentum,
+ * else eval-mode forward + criterion.  Log-probs go to logp[f][row0 ..], the batch loss to loss[f][step_index]. */
+int slnlp_tf_lockstep_step(slnlp_tf_lockstep* group, int slot, int64_t row0, int B, int step_index, int train,
+                           float momentum, float max_norm, void* stream);
+/* one pass over the slot in dataset order, batches of `batch` rows (the last may be shorter): no host sync inside */
+int slnlp_tf_lockstep_epoch(slnlp_tf_lockstep* group, int slot, int batch, int train, float momentum, float max_norm,
+                            void* stream);
+/* kernel launches per step of the cached program for (slot, B, train), or -1 if none has been recorded yet */
+int slnlp_tf_lockstep_num_launches(slnlp_tf_lockstep* group, int slot, int B, int train);
+
 
 /* ------------------------------------------------- enc-dec RNN (+attn) plan --
  * Whole-model drop-in for model.EncoderDecoder{LSTM,GRU}Attn

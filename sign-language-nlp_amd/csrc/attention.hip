@@ -10,6 +10,7 @@
 // Cross-attention (decoder, tgt length 1, no masks): one workgroup per (batch, head),
 // matrix-vector products out of LDS tiles.
 #include "common.hpp"
+#include "launch.hpp"
 
 namespace slnlp {
 
@@ -110,7 +111,7 @@ __device__ __forceinline__ void put_planes(unsigned short* __restrict__ T, int o
     T[ATILE + off] = l;
 }
 
-__global__ __launch_bounds__(256) void attn_self_fwd_mfma_kernel(
+__device__ __forceinline__ void attn_self_fwd_mfma_body(
     const float* __restrict__ qkv, const long* __restrict__ ids, long ld_ids, long pad_idx, int causal, int B,
     int S, int H, int dh, float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr,
     int drop_site, const unsigned long long* __restrict__ rng, PlaneOut po) {
@@ -222,10 +223,11 @@ __global__ __launch_bounds__(256) void attn_self_fwd_mfma_kernel(
         }
     }
 }
+SLNLP_ZKERNEL(attn_self_fwd_mfma_kernel, 256, attn_self_fwd_mfma_body)
 
 // Backward.  Tiles (hi+lo each): TQ | TK | TO (dO) | TV (V, later dropped P) | TS (dS; only when the head dim needs
 // more than one 64-wide chunk, else dS reuses TO): 73 728 B or 92 160 B of dynamic LDS.
-__global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
+__device__ __forceinline__ void attn_self_bwd_mfma_body(
     const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ dctx, int B, int S,
     int H, int dh, float* __restrict__ dqkv, float drop_p, unsigned drop_thr, int drop_site,
     const unsigned long long* __restrict__ rng, PlaneOut po) {
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(256) void attn_self_bwd_mfma_kernel(
         store(acc, 1);
     }
 }
+SLNLP_ZKERNEL(attn_self_bwd_mfma_kernel, 256, attn_self_bwd_mfma_body)
 
 // ------------------------------------------------------------------ cross ---
 constexpr int XDH = 256;  // max head dim
@@ -431,7 +434,7 @@ __device__ __forceinline__ float xcol_sum(const float* __restrict__ T, const flo
     return red[d] + red[64 + d] + red[128 + d] + red[192 + d];
 }
 
-__global__ __launch_bounds__(256) void attn_cross_fwd_kernel(
+__device__ __forceinline__ void attn_cross_fwd_body(
     const float* __restrict__ q, const float* __restrict__ kv, long ld_kv, int B, int S, int H, int dh,
     float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr, int drop_site,
     const unsigned long long* __restrict__ rng) {
@@ -481,8 +484,9 @@ __global__ __launch_bounds__(256) void attn_cross_fwd_kernel(
         if (tid < dc) ctx[(long)b * E + h * dh + d0 + tid] = o;
     }
 }
+SLNLP_ZKERNEL(attn_cross_fwd_kernel, 256, attn_cross_fwd_body)
 
-__global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
+__device__ __forceinline__ void attn_cross_bwd_body(
     const float* __restrict__ q, const float* __restrict__ kv, long ld_kv, const float* __restrict__ probs,
     const float* __restrict__ dctx, int B, int S, int H, int dh, float* __restrict__ dq, float* __restrict__ dkv,
     long ld_dkv, float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* __restrict__ rng,
@@ -556,6 +560,7 @@ __global__ __launch_bounds__(256) void attn_cross_bwd_kernel(
         }
     }
 }
+SLNLP_ZKERNEL(attn_cross_bwd_kernel, 256, attn_cross_bwd_body)
 
 constexpr size_t ATTN_BWD_MFMA_LDS = 10 * ATILE * sizeof(unsigned short);  // up to 92 160 B (head dim > 64)
 
@@ -587,9 +592,8 @@ int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t 
     SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
-    hipLaunchKernelGGL(attn_self_fwd_mfma_kernel, dim3(B * H), dim3(256), 0, st, qkv, (const long*)ids, (long)ld_ids,
-                       (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
-    SLNLP_CHECK_LAUNCH("attn_self_fwd");
+    SLNLP_TRY(zlaunch(attn_self_fwd_mfma_kernel, dim3(B * H), 256, 0, st, "attn_self_fwd",
+                      qkv, (const long*)ids, (long)ld_ids, (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng, po));
     return 0;
 }
 
@@ -599,10 +603,8 @@ int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B
     SLNLP_CHECK_ARG(qkv && probs && dctx && dqkv, "attn_self_bwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
     SLNLP_TRY(attn_init());
-    hipLaunchKernelGGL(attn_self_bwd_mfma_kernel, dim3(B * H), dim3(256),
-                       (dh <= MFMA_DH ? 8 : 10) * ATILE * sizeof(unsigned short), st, qkv, probs, dctx, B, S, H, dh, dqkv,
-                       drop_p, dropout_threshold(drop_p), drop_site, rng, po);
-    SLNLP_CHECK_LAUNCH("attn_self_bwd");
+    SLNLP_TRY(zlaunch(attn_self_bwd_mfma_kernel, dim3(B * H), 256, (dh <= MFMA_DH ? 8 : 10) * ATILE * sizeof(unsigned short), st, "attn_self_bwd",
+                      qkv, probs, dctx, B, S, H, dh, dqkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po));
     return 0;
 }
 
@@ -612,9 +614,8 @@ int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S,
     SLNLP_CHECK_ARG(q && kv && ctx && probs, "attn_cross_fwd: null pointer");
     SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh, "attn_cross_fwd: ld_kv=%ld", (long)ld_kv);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_fwd: bad dropout args");
-    hipLaunchKernelGGL(attn_cross_fwd_kernel, dim3(B * H), dim3(256), 0, st, q, kv, (long)ld_kv, B, S, H,
-                       dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng);
-    SLNLP_CHECK_LAUNCH("attn_cross_fwd");
+    SLNLP_TRY(zlaunch(attn_cross_fwd_kernel, dim3(B * H), 256, 0, st, "attn_cross_fwd",
+                      q, kv, (long)ld_kv, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng));
     return 0;
 }
 
@@ -625,9 +626,8 @@ int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* 
     SLNLP_CHECK_ARG(q && kv && probs && dctx && dq && dkv, "attn_cross_bwd: null pointer");
     SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh && ld_dkv >= 2L * H * dh && ld_dkv % 4 == 0, "attn_cross_bwd: bad ld");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_bwd: bad dropout args");
-    hipLaunchKernelGGL(attn_cross_bwd_kernel, dim3(B * H), dim3(256), 0, st, q, kv, (long)ld_kv, probs,
-                       dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po);
-    SLNLP_CHECK_LAUNCH("attn_cross_bwd");
+    SLNLP_TRY(zlaunch(attn_cross_bwd_kernel, dim3(B * H), 256, 0, st, "attn_cross_bwd",
+                      q, kv, (long)ld_kv, probs, dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po));
     return 0;
 }
 

@@ -172,7 +172,8 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
 int attn_init();
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st);
 int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
-            float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st);
+            float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st,
+            float* logp2 = nullptr, const int* logp2_row = nullptr, float* loss_hist = nullptr, const int* hist_idx = nullptr);
 int lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits, hipStream_t st);
 int rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, float fill,
                  int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);

@@ -2,12 +2,13 @@
 // add, LayerNorm, log-softmax / NLL criterion, grad-norm clip + SGD-momentum.
 // All fp32, 16-B vector accesses, one wave per row for the row-wise reductions.
 #include "common.hpp"
+#include "launch.hpp"
 
 namespace slnlp {
 
 // ===================================================================== embed
 // /root/reference/model/transformer.py:106-109 + component/positional_encoding.py:48-49
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__ ids, long ld_ids, int B, int S,
+__device__ __forceinline__ void embed_fwd_body(const long* __restrict__ ids, long ld_ids, int B, int S,
                                                         int E, int V, const float* __restrict__ table,
                                                         const float* __restrict__ pe, float* __restrict__ out,
                                                         float scale, float drop_p, unsigned drop_thr, int drop_site,
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
         store_planes4(po, (long)m * E + c, v);
     }
 }
+SLNLP_ZKERNEL(embed_fwd_kernel, 256, embed_fwd_body)
 
 // Embedding backward = segmented sum of dx rows by token id, deterministic (fixed order, no float
 // atomics), in two levels so that a hot id (the <pad> row takes ~40 % of all tokens) is never one
@@ -67,7 +69,7 @@ __device__ __forceinline__ float4 load_dx_row(const float* __restrict__ dx, int 
 
 constexpr int EMB_CHUNK = 64;
 
-__global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __restrict__ ids, long ld_ids, int B, int S,
+__device__ __forceinline__ void embed_bwd_chunk_body(const long* __restrict__ ids, long ld_ids, int B, int S,
                                                               int E, int V, const float* __restrict__ dx,
                                                               float* __restrict__ partial, int* __restrict__ pid,
                                                               float drop_p, unsigned drop_thr, int drop_site,
@@ -129,8 +131,9 @@ __global__ __launch_bounds__(256) void embed_bwd_chunk_kernel(const long* __rest
         }
     }
 }
+SLNLP_ZKERNEL(embed_bwd_chunk_kernel, 256, embed_bwd_chunk_body)
 
-__global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __restrict__ pid, int M, int E,
+__device__ __forceinline__ void embed_bwd_combine_body(const int* __restrict__ pid, int M, int E,
                                                                 const float* __restrict__ partial,
                                                                 float* __restrict__ dtable, float scale) {
     __shared__ int list[1024];             // slots holding a partial of this id, increasing (<= #chunks)
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256) void embed_bwd_combine_kernel(const int* __res
         }
     }
 }
+SLNLP_ZKERNEL(embed_bwd_combine_kernel, 256, embed_bwd_combine_body)
 
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
@@ -209,9 +213,8 @@ int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     const long total = (long)B * S * (E / 4);
     int grid = ceil_div(total, 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, st, (const long*)ids, (long)ld_ids, B, S, E, V,
-                       table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx, po, keep_mask);
-    SLNLP_CHECK_LAUNCH("embed_fwd");
+    SLNLP_TRY(zlaunch(embed_fwd_kernel, dim3(grid), 256, 0, st, "embed_fwd",
+                      (const long*)ids, (long)ld_ids, B, S, E, V, table, pe, out, scale, drop_p, dropout_threshold(drop_p), drop_site, rng, (long)nan_idx, po, keep_mask));
     return 0;
 }
 
@@ -226,30 +229,22 @@ int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_bwd: bad shape");
     SLNLP_CHECK_ARG((long)B * S <= 65536, "embed_bwd: more than 65536 tokens per batch");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_bwd: bad dropout args");
-    if (hipMemsetAsync(dtable, 0, (size_t)V * E * sizeof(float), st) != hipSuccess) {
-        set_error("embed_bwd: memset failed");
-        return SLNLP_ERR_LAUNCH;
-    }
+    SLNLP_TRY(fill_zero(dtable, (size_t)V * E * sizeof(float), st));    // rows of ids that do not occur (our kernel: recordable)
     const int M = B * S;
     float* partial = (float*)scratch;
     int* pid = (int*)(partial + (size_t)M * E);
-    hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3(M), dim3(256), 0, st, (const long*)ids,
-                       (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng, keep_mask);
-    SLNLP_CHECK_LAUNCH("embed_bwd_chunk");
-    hipLaunchKernelGGL(embed_bwd_combine_kernel, dim3(M), dim3(256), 0, st, pid, M, E, partial, dtable, scale);
-    SLNLP_CHECK_LAUNCH("embed_bwd_combine");
-    if (zero_row >= 0 && zero_row < V &&
-        hipMemsetAsync(dtable + zero_row * E, 0, (size_t)E * sizeof(float), st) != hipSuccess) {
-        set_error("embed_bwd: memset of the padding_idx row failed");
-        return SLNLP_ERR_LAUNCH;
-    }
+    SLNLP_TRY(zlaunch(embed_bwd_chunk_kernel, dim3(M), 256, 0, st, "embed_bwd_chunk",
+                      (const long*)ids, (long)ld_ids, B, S, E, V, dx, partial, pid, drop_p, dropout_threshold(drop_p), drop_site, rng, keep_mask));
+    SLNLP_TRY(zlaunch(embed_bwd_combine_kernel, dim3(M), 256, 0, st, "embed_bwd_combine",
+                      pid, M, E, partial, dtable, scale));
+    if (zero_row >= 0 && zero_row < V) SLNLP_TRY(fill_zero(dtable + zero_row * E, (size_t)E * sizeof(float), st));
     return 0;
 }
 
 // ================================================================= layernorm
 constexpr int LN_MAXU = 4;  // float4 per lane -> E <= 1024 in the backward (register-resident columns)
 
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void layernorm_fwd_body(const float* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int rows, int E,
                                                             float eps, float* __restrict__ y,
@@ -297,8 +292,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         stats[2 * row + 1] = rstd;
     }
 }
+SLNLP_ZKERNEL(layernorm_fwd_kernel, 256, layernorm_fwd_body)
 
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+__device__ __forceinline__ void layernorm_bwd_body(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
     float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
@@ -411,9 +407,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         partial[((long)blockIdx.x * 2 + 1) * E + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
     }
 }
+SLNLP_ZKERNEL(layernorm_bwd_kernel, 256, layernorm_bwd_body)
 
 // grid (entry, ceil(E/64)); block = 64 columns x 4 partial-groups, combined through LDS in fixed order.
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_reduce_entry* __restrict__ table) {
+__device__ __forceinline__ void ln_param_reduce_body(const slnlp_ln_reduce_entry* __restrict__ table) {
     __shared__ float red[2][4][64];
     const slnlp_ln_reduce_entry e = table[blockIdx.x];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.y * 64 + col;
@@ -444,14 +441,14 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const slnlp_ln_red
         e.dbeta[c] = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
     }
 }
+SLNLP_ZKERNEL(ln_param_reduce_kernel, 256, ln_param_reduce_body)
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                   float* stats, hipStream_t st, PlaneOut po) {
     SLNLP_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null pointer");
     SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "layernorm_fwd: need E %% 4 == 0 and E <= %d, got rows=%d E=%d", LN_MAXU * 256, rows, E);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, gamma, beta, rows, E, eps, y,
-                       stats, po);
-    SLNLP_CHECK_LAUNCH("layernorm_fwd");
+    SLNLP_TRY(zlaunch(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), 256, 0, st, "layernorm_fwd",
+                      x, gamma, beta, rows, E, eps, y, stats, po));
     return 0;
 }
 
@@ -474,16 +471,15 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
     // blocks for smaller batches too; blocks without rows write zero partials.
     const int nblk = nblk_force ? nblk_force : ln_bwd_blocks(rows);
     if (nblk_out) *nblk_out = nblk;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, x, gamma, stats, rows, E, add_to_dx, dx,
-                       dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop, ln_bwd_group(rows));
-    SLNLP_CHECK_LAUNCH("layernorm_bwd");
+    SLNLP_TRY(zlaunch(layernorm_bwd_kernel, dim3(nblk), 256, 0, st, "layernorm_bwd",
+                      dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop, ln_bwd_group(rows)));
     return 0;
 }
 
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st) {
     SLNLP_CHECK_ARG(table_dev && n > 0 && max_E > 0, "ln_param_reduce: bad args");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(n, ceil_div(max_E, 64)), dim3(256), 0, st, table_dev);
-    SLNLP_CHECK_LAUNCH("ln_param_reduce");
+    SLNLP_TRY(zlaunch(ln_param_reduce_kernel, dim3(n, ceil_div(max_E, 64)), 256, 0, st, "ln_param_reduce",
+                      table_dev));
     return 0;
 }
 
@@ -494,10 +490,14 @@ constexpr int LOSS_MAXB = 1024;
 
 // grid = B rows, one wave each.  n_valid (targets != ignore_index) is recomputed by every row (B <= 1024
 // compares) so d loss/d logits needs no second pass; the scalar loss is summed by lsm_loss_reduce_kernel.
-__global__ __launch_bounds__(64) void lsm_nll_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ y,
+__device__ __forceinline__ void lsm_nll_body(const float* __restrict__ logits, long ld, const long* __restrict__ y,
                                                      int B, int V, long ignore, float* __restrict__ logp,
-                                                     float* __restrict__ row_nll, float* __restrict__ dlogits, long ldd) {
+                                                     float* __restrict__ row_nll, float* __restrict__ dlogits, long ldd,
+                                                     float* __restrict__ logp2, const int* __restrict__ logp2_row) {
+    // logp2 (optional): a second copy of the log-probs for the caller, at row offset *logp2_row (a device scalar, so a
+    // recorded launch can walk an epoch's output buffer) -- replaces a device-to-device copy per step
     const int lane = threadIdx.x, b = blockIdx.x;
+    if (logp2) logp2 += (long)(logp2_row ? *logp2_row : 0) * V;
     int cnt = 0;
     for (int i = lane; i < B; i += 64) {
         const long t = y[i];
@@ -516,6 +516,7 @@ __global__ __launch_bounds__(64) void lsm_nll_kernel(const float* __restrict__ l
     for (int v = lane; v < V; v += 64) {
         const float lp = xr[v] - lse;
         logp[(long)b * V + v] = lp;
+        if (logp2) logp2[(long)b * V + v] = lp;
         m2 = fmaxf(m2, lp);
     }
     m2 = wave_max(m2);
@@ -537,8 +538,10 @@ __global__ __launch_bounds__(64) void lsm_nll_kernel(const float* __restrict__ l
         dlogits[(long)b * ldd + v] = dlp - expf(lp) * sum;
     }
 }
+SLNLP_ZKERNEL(lsm_nll_kernel, 64, lsm_nll_body)
 
-__global__ __launch_bounds__(64) void lsm_loss_reduce_kernel(const float* __restrict__ row_nll, int B, float* __restrict__ loss) {
+__device__ __forceinline__ void lsm_loss_reduce_body(const float* __restrict__ row_nll, int B, float* __restrict__ loss,
+                                                     float* __restrict__ loss_hist, const int* __restrict__ hist_idx) {
     float tot = 0.f, n = 0.f;
     for (int b = threadIdx.x; b < B; b += 64) {
         const float v = row_nll[b];
@@ -546,10 +549,14 @@ __global__ __launch_bounds__(64) void lsm_loss_reduce_kernel(const float* __rest
     }
     tot = wave_sum(tot);
     n = wave_sum(n);
-    if (threadIdx.x == 0) loss[0] = tot / n;   // 0/0 = NaN when every target is ignored, as torch
+    if (threadIdx.x == 0) {
+        loss[0] = tot / n;   // 0/0 = NaN when every target is ignored, as torch
+        if (loss_hist) loss_hist[hist_idx ? *hist_idx : 0] = tot / n;    // per-batch losses of an epoch, no host round trip
+    }
 }
+SLNLP_ZKERNEL(lsm_loss_reduce_kernel, 64, lsm_loss_reduce_body)
 
-__global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ dlogp, int B,
+__device__ __forceinline__ void lsm_bwd_body(const float* __restrict__ logp, const float* __restrict__ dlogp, int B,
                                                       int V, float* __restrict__ dlogits, long ldd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
@@ -560,25 +567,26 @@ __global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ 
     for (int v = lane; v < V; v += 64)
         dlogits[(long)b * ldd + v] = dlogp[(long)b * V + v] - expf(logp[(long)b * V + v]) * sum;
 }
+SLNLP_ZKERNEL(lsm_bwd_kernel, 256, lsm_bwd_body)
 
 int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
-            float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st) {
+            float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st,
+            float* logp2, const int* logp2_row, float* loss_hist, const int* hist_idx) {
     SLNLP_CHECK_ARG(logits && y && logp && loss && row_scratch, "lsm_nll: null pointer");
     SLNLP_CHECK_ARG(B > 0 && B <= LOSS_MAXB && V > 0 && ld_logits >= V, "lsm_nll: bad shape B=%d V=%d", B, V);
     SLNLP_CHECK_ARG(!dlogits || ld_dlogits >= V, "lsm_nll: ld_dlogits too small");
-    hipLaunchKernelGGL(lsm_nll_kernel, dim3(B), dim3(64), 0, st, logits, (long)ld_logits, (const long*)y, B, V,
-                       (long)ignore_index, logp, row_scratch, dlogits, (long)ld_dlogits);
-    SLNLP_CHECK_LAUNCH("lsm_nll");
-    hipLaunchKernelGGL(lsm_loss_reduce_kernel, dim3(1), dim3(64), 0, loss_st ? loss_st : st, row_scratch, B, loss);
-    SLNLP_CHECK_LAUNCH("lsm_loss_reduce");
+    SLNLP_TRY(zlaunch(lsm_nll_kernel, dim3(B), 64, 0, st, "lsm_nll",
+                      logits, (long)ld_logits, (const long*)y, B, V, (long)ignore_index, logp, row_scratch, dlogits, (long)ld_dlogits,
+                      logp2, logp2_row));
+    SLNLP_TRY(zlaunch(lsm_loss_reduce_kernel, dim3(1), 64, 0, loss_st ? loss_st : st, "lsm_loss_reduce",
+                      row_scratch, B, loss, loss_hist, hist_idx));
     return 0;
 }
 
 int lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits, int64_t ld_dlogits, hipStream_t st) {
     SLNLP_CHECK_ARG(logp && dlogp && dlogits && B > 0 && V > 0 && ld_dlogits >= V, "lsm_bwd: bad args");
-    hipLaunchKernelGGL(lsm_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, logp, dlogp, B, V, dlogits,
-                       (long)ld_dlogits);
-    SLNLP_CHECK_LAUNCH("lsm_bwd");
+    SLNLP_TRY(zlaunch(lsm_bwd_kernel, dim3(ceil_div(B, 4)), 256, 0, st, "lsm_bwd",
+                      logp, dlogp, B, V, dlogits, (long)ld_dlogits));
     return 0;
 }
 
@@ -586,7 +594,7 @@ int lsm_bwd(const float* logp, const float* dlogp, int B, int V, float* dlogits,
 // clip_grad_norm_(max_norm) + torch.optim.SGD(momentum) over one flat arena.
 constexpr int OPT_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, float* __restrict__ partials) {
+__device__ __forceinline__ void sumsq_body(const float* __restrict__ g, long n4, float* __restrict__ partials) {
     __shared__ float red[4];
     float s = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)OPT_BLOCKS * 256) {
@@ -598,8 +606,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+SLNLP_ZKERNEL(sumsq_kernel, 256, sumsq_body)
 
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+__device__ __forceinline__ void sgd_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   long n4, const float* __restrict__ lr_dev, float momentum,
                                                   float max_norm, const float* __restrict__ partials,
                                                   float* __restrict__ norm_out, unsigned long long* __restrict__ rng) {
@@ -629,6 +638,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
         if (rng) rng[1] += 1ull;
     }
 }
+SLNLP_ZKERNEL(sgd_kernel, 256, sgd_body)
 
 int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                   float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
@@ -637,13 +647,12 @@ int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_
     SLNLP_CHECK_ARG(n > 0 && n % 4 == 0, "clip_sgd_step: n=%ld must be a positive multiple of 4", (long)n);
     SLNLP_CHECK_ARG(((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0 && ((uintptr_t)momentum_buf & 15) == 0,
                     "clip_sgd_step: arenas must be 16-byte aligned");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, (long)(n / 4), partials);
-    SLNLP_CHECK_LAUNCH("sumsq");
+    SLNLP_TRY(zlaunch(sumsq_kernel, dim3(OPT_BLOCKS), 256, 0, st, "sumsq",
+                      grads, (long)(n / 4), partials));
     int grid = ceil_div(n / 4, 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, st, params, grads, momentum_buf, (long)(n / 4), lr_dev,
-                       momentum, max_norm, partials, norm_out, rng);
-    SLNLP_CHECK_LAUNCH("sgd");
+    SLNLP_TRY(zlaunch(sgd_kernel, dim3(grid), 256, 0, st, "sgd",
+                      params, grads, momentum_buf, (long)(n / 4), lr_dev, momentum, max_norm, partials, norm_out, rng));
     return 0;
 }
 

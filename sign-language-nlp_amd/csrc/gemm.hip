@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "gemm_jobs.hpp"
 
 namespace slnlp {
 
@@ -43,12 +44,6 @@ constexpr int KLD = BKT;      // [row][k] image: 64 bf16 = 128-B rows, 16-B slot
 // a padded stride cannot do that (the g=1 slots are the g=0 slots shifted by one).
 __device__ __forceinline__ int kmaj_off(int row, int k) { return row * KLD + ((((k >> 3) ^ (row & 7)) << 3) | (k & 7)); }
 
-struct GemmParams {
-    slnlp_gemm_args a;
-    unsigned drop_thr;
-    float drop_scale;
-    int a_vec, b_vec;  // 16-B vector loads legal for this operand
-};
 
 __device__ __forceinline__ unsigned short f2bf(float x) {
     __bf16 b = (__bf16)x;
@@ -348,24 +343,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
 // Several independent fp32-operand GEMMs in ONE launch (e.g. the data- and weight-gradient of one dY in the
 // decoder, whose B-row GEMMs are pure launch latency): workgroups [block_begin, block_begin + gx*gy) run job j.
-constexpr int GEMM_GROUP_MAX = 8;
-struct GemmGroupParams {
-    GemmParams job[GEMM_GROUP_MAX];
-    int variant[GEMM_GROUP_MAX];      // (a_kmajor, b_kmajor, narrow) -> 0..5
-    int gx[GEMM_GROUP_MAX], gy[GEMM_GROUP_MAX], block_begin[GEMM_GROUP_MAX];
-    int njobs;
-};
-
+// `tab` != nullptr: a merged (lockstep) launch -- the jobs of K fits in a device-resident table, blockmap[block] = job
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupParams P) {
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupParams P, const GemmJob* __restrict__ tab,
+                                                         const int* __restrict__ blockmap) {
     __shared__ __attribute__((aligned(16))) unsigned short smem[tile_lds_elems<NSPLIT, false, false, 64>()];   // the largest variant
-    int j = 0;
-    for (int t = 1; t < P.njobs; ++t)
-        if ((int)blockIdx.x >= P.block_begin[t]) j = t;
-    const GemmParams& p = P.job[j];
-    const int lid = blockIdx.x - P.block_begin[j], gx = P.gx[j], gy = P.gy[j];
+    GemmParams p;
+    int variant, gx, gy, lid;
+    if (tab) {
+        const GemmJob& J = tab[blockmap[blockIdx.x]];
+        p = J.p; variant = J.variant; gx = J.gx; gy = J.gy; lid = blockIdx.x - J.block_begin;
+    } else {
+        int j = 0;
+        for (int t = 1; t < P.njobs; ++t)
+            if ((int)blockIdx.x >= P.block_begin[t]) j = t;
+        p = P.job[j]; variant = P.variant[j]; gx = P.gx[j]; gy = P.gy[j]; lid = blockIdx.x - P.block_begin[j];
+    }
+    launder(p.a);
     const int bx = lid % gx, by = lid / gx;
-    switch (P.variant[j]) {
+    switch (variant) {
         case 0: gemm_tile<NSPLIT, true, true, 64, true>(p, bx, by, gx, gy, smem); break;
         case 1: gemm_tile<NSPLIT, true, true, 16, true>(p, bx, by, gx, gy, smem); break;
         case 2: gemm_tile<NSPLIT, true, false, 64, true>(p, bx, by, gx, gy, smem); break;
@@ -425,6 +421,7 @@ static int fill_params(const slnlp_gemm_args& a, GemmParams& p) {
 
 int gemm(const slnlp_gemm_args& a, hipStream_t s) {
     if (a.A_hi || a.B_hi) return gemm_planes(a, s);   // pre-split operands: LDS-DMA kernel (gemm_planes.hip)
+    if (recording()) return gemm_group(&a, 1, s);     // lockstep: every GEMM is a job of a grouped launch (same tile code)
     GemmParams p;
     SLNLP_TRY(fill_params(a, p));
     const bool ak = a.a_kmajor != 0, bk = a.b_kmajor != 0;
@@ -462,14 +459,22 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
         P.block_begin[i] = blocks;
         blocks += P.gx[i] * P.gy[i];
     }
+    if (recording()) {
+        SLNLP_CHECK_ARG(fusable, "gemm_group: an operand that cannot take 16-byte loads cannot join a lockstep launch");
+        return record_op(gemm_group_kernel_ptr(jobs[0].precision), dim3(blocks), dim3(256), 0, REC_GEMM_GROUP, &P, sizeof(P), "gemm_group");
+    }
     if (!fusable || njobs == 1) {
         for (int i = 0; i < njobs; ++i) SLNLP_TRY(gemm(jobs[i], s));
         return SLNLP_OK;
     }
-    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_group_kernel<3>, dim3(blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(blocks), dim3(256), 0, s, P);
+    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_group_kernel<3>, dim3(blocks), dim3(256), 0, s, P, (const GemmJob*)nullptr, (const int*)nullptr);
+    else hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(blocks), dim3(256), 0, s, P, (const GemmJob*)nullptr, (const int*)nullptr);
     SLNLP_CHECK_LAUNCH("gemm_group");
     return SLNLP_OK;
+}
+
+const void* gemm_group_kernel_ptr(int precision) {
+    return precision == 3 ? (const void*)gemm_group_kernel<3> : (const void*)gemm_group_kernel<1>;
 }
 
 // ------------------------------------------------------------- fused recurrent step ---

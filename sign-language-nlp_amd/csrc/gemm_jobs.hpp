@@ -1,0 +1,64 @@
+// gemm_jobs.hpp -- job descriptors of the grouped GEMM kernels (gemm.hip, gemm_planes.hip), shared with the lockstep
+// driver (lockstep.hip), which concatenates the job lists of K fits into one device-resident table per launch.
+#pragma once
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace slnlp {
+
+// ---- fp32-operand GEMM (gemm.hip)
+struct GemmParams {
+    slnlp_gemm_args a;
+    unsigned drop_thr;
+    float drop_scale;
+    int a_vec, b_vec;  // 16-B vector loads legal for this operand
+};
+constexpr int GEMM_GROUP_MAX = 8;
+struct GemmGroupParams {
+    GemmParams job[GEMM_GROUP_MAX];
+    int variant[GEMM_GROUP_MAX];      // (a_kmajor, b_kmajor, narrow) -> 0..5
+    int gx[GEMM_GROUP_MAX], gy[GEMM_GROUP_MAX], block_begin[GEMM_GROUP_MAX];
+    int njobs;
+};
+// one entry of a merged (lockstep) launch's job table; blocks [block_begin, block_begin + gx * gy) run it
+struct GemmJob {
+    GemmParams p;
+    int variant, gx, gy, block_begin;
+};
+
+// ---- pre-split plane GEMM (gemm_planes.hip)
+// One GEMM of a grouped launch.  A launch runs up to MAX_JOBS independent GEMMs (e.g. the data-gradient and
+// the weight-gradient of one dY): blocks [block_begin, block_begin + tiles_x * tiles_y * nks) belong to the job.
+// nks > 1 splits the K loop over nks blocks per output tile; partial tiles go to scratch in the accumulator
+// layout and the LAST block to arrive (per-tile counter) adds them in split order -- deterministic, no float atomics.
+struct PlaneJob {
+    slnlp_gemm_args a;
+    unsigned drop_thr;
+    float drop_scale;
+    int variant;        // 0: A,B k-major   1: A k-major, B m-major   2: A,B m-major
+    int tiles_x, tiles_y, nks, block_begin;
+    float* part;        // [tile][nks][PTHREADS * 8]
+    float* part_rs;     // [tile_y][nks][PT]     (row sums of A)
+    int* counters;      // [tiles], zero outside a launch
+};
+constexpr int MAX_JOBS = 4;
+struct PlaneGroupParams {
+    PlaneJob job[MAX_JOBS];
+    int njobs;
+};
+
+// every pointer of a job read from a device table is generic to the compiler: make them global again (launch.hpp)
+__device__ __forceinline__ void launder(slnlp_gemm_args& a) {
+    a.A = as_global(a.A); a.B = as_global(a.B); a.C = as_global(a.C);
+    a.bias = as_global(a.bias); a.gate = as_global(a.gate); a.rng = as_global(a.rng);
+    a.resid = as_global(a.resid); a.rowsum_a = as_global(a.rowsum_a);
+    a.A_hi = as_global(a.A_hi); a.A_lo = as_global(a.A_lo); a.B_hi = as_global(a.B_hi); a.B_lo = as_global(a.B_lo);
+    a.C_hi = as_global(a.C_hi); a.C_lo = as_global(a.C_lo);
+}
+
+// kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)
+const void* gemm_group_kernel_ptr(int precision);
+const void* gemm_planes_kernel_ptr(int precision);
+size_t gemm_planes_lds_bytes();
+
+}  // namespace slnlp

@@ -16,6 +16,7 @@
 //      m-major image [k][64 rows] : 16-B slot ^= 2*(k>>1 & 1 | k>>3 & 1 << 1) -> ds_read_b64_tr_b16
 //  * padding makes every tile interior: no bounds logic anywhere in the loop.
 #include "common.hpp"
+#include "gemm_jobs.hpp"
 
 namespace slnlp {
 
@@ -30,26 +31,6 @@ constexpr int PT = 64;                 // tile edge (M, N and K)
 constexpr int IMG = PT * PT;           // bf16 elements per plane image (8 KiB)
 constexpr int PTHREADS = 512;
 constexpr int NSTAGE = 2;              // LDS ring depth (NSTAGE-1 tiles in flight)
-
-// One GEMM of a grouped launch.  A launch runs up to MAX_JOBS independent GEMMs (e.g. the data-gradient and
-// the weight-gradient of one dY): blocks [block_begin, block_begin + tiles_x * tiles_y * nks) belong to the job.
-// nks > 1 splits the K loop over nks blocks per output tile; partial tiles go to scratch in the accumulator
-// layout and the LAST block to arrive (per-tile counter) adds them in split order -- deterministic, no float atomics.
-struct PlaneJob {
-    slnlp_gemm_args a;
-    unsigned drop_thr;
-    float drop_scale;
-    int variant;        // 0: A,B k-major   1: A k-major, B m-major   2: A,B m-major
-    int tiles_x, tiles_y, nks, block_begin;
-    float* part;        // [tile][nks][PTHREADS * 8]
-    float* part_rs;     // [tile_y][nks][PT]     (row sums of A)
-    int* counters;      // [tiles], zero outside a launch
-};
-constexpr int MAX_JOBS = 4;
-struct PlaneGroupParams {
-    PlaneJob job[MAX_JOBS];
-    int njobs;
-};
 
 __device__ __forceinline__ int mswz(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
 
@@ -263,14 +244,24 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
     }
 }
 
+// `tab` != nullptr: a merged (lockstep) launch -- the jobs of K fits in a device-resident table, blockmap[block] = job
 template <int NSPLIT>
-__global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P) {
+__global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
+                                                               const int* __restrict__ blockmap) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // NSTAGE stages (+ scratch after the loop)
-    int j = 0;
-    for (int t = 1; t < P.njobs; ++t)
-        if ((int)blockIdx.x >= P.job[t].block_begin) j = t;                 // block-uniform
-    const PlaneJob& job = P.job[j];
+    PlaneJob job;
+    if (tab) {
+        job = tab[blockmap[blockIdx.x]];
+    } else {
+        int j = 0;
+        for (int t = 1; t < P.njobs; ++t)
+            if ((int)blockIdx.x >= P.job[t].block_begin) j = t;             // block-uniform
+        job = P.job[j];
+    }
+    launder(job.a);
+    job.part = as_global(job.part); job.part_rs = as_global(job.part_rs); job.counters = as_global(job.counters);
     const int lid = blockIdx.x - job.block_begin;
+    if (lid >= job.tiles_x * job.tiles_y * job.nks) return;                 // padding block of a merged launch (jobs start on multiples of 8)
     if (job.variant == 0) plane_tile<NSPLIT, true, true>(job, lid, smem);
     else if (job.variant == 1) plane_tile<NSPLIT, true, false>(job, lid, smem);
     else plane_tile<NSPLIT, false, false>(job, lid, smem);
@@ -363,18 +354,25 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
         blocks += tiles * nks;
     }
     SLNLP_TRY(gemm_planes_init());
-    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_planes_kernel<3>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P);
-    else hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P);
+    if (recording())
+        return record_op(gemm_planes_kernel_ptr(jobs[0].precision), dim3(blocks), dim3(PTHREADS), PLANE_LDS, REC_PLANE_GROUP, &P, sizeof(P), "gemm_planes");
+    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_planes_kernel<3>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P, (const PlaneJob*)nullptr, (const int*)nullptr);
+    else hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P, (const PlaneJob*)nullptr, (const int*)nullptr);
     SLNLP_CHECK_LAUNCH("gemm_planes");
     return 0;
 }
+
+const void* gemm_planes_kernel_ptr(int precision) {
+    return precision == 3 ? (const void*)gemm_planes_kernel<3> : (const void*)gemm_planes_kernel<1>;
+}
+size_t gemm_planes_lds_bytes() { return PLANE_LDS; }
 
 int gemm_planes(const slnlp_gemm_args& a, hipStream_t s) { return gemm_planes_group(&a, nullptr, 1, nullptr, 0, s); }
 
 // fp32 [R, C] (row stride ld) -> bf16 hi / lo planes with row stride ldp (valid region only; the padding of the
 // planes stays zero from their one-time memset).  Used for the weights once per step and by tests.
-__global__ void split_planes_kernel(const float* __restrict__ x, long ld, int R, int C, unsigned short* __restrict__ hi,
-                                    unsigned short* __restrict__ lo, long ldp) {
+__device__ __forceinline__ void split_planes_body(const float* __restrict__ x, long ld, int R, int C, unsigned short* __restrict__ hi,
+                                                  unsigned short* __restrict__ lo, long ldp) {
     const long n4 = (long)R * (C >> 2);
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int r = (int)(i / (C >> 2)), c = (int)(i % (C >> 2)) << 2;
@@ -398,14 +396,14 @@ __global__ void split_planes_kernel(const float* __restrict__ x, long ld, int R,
     }
 }
 
+SLNLP_ZKERNEL(split_planes_kernel, 256, split_planes_body)
+
 int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, unsigned short* lo, int64_t ldp, hipStream_t st) {
     SLNLP_CHECK_ARG(x && hi && R > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ldp % 4 == 0 && ldp >= C,
                     "split_planes: bad args (C, ld, ldp must be multiples of 4)");
     int grid = ceil_div((long)R * (C / 4), 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, st, x, (long)ld, R, C, hi, lo, (long)ldp);
-    SLNLP_CHECK_LAUNCH("split_planes");
-    return 0;
+    return zlaunch(split_planes_kernel, dim3(grid), 256, 0, st, "split_planes", x, (long)ld, R, C, hi, lo, (long)ldp);
 }
 
 }  // namespace slnlp

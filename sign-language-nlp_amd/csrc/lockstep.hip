@@ -1,0 +1,328 @@
+// lockstep.hip -- K Transformer fits of one shape advancing through ONE launch sequence.
+//
+// What it replaces: the reference runs its (candidate x fold) fits as independent dask tasks, one after another per
+// worker (/root/reference/main.py:70-78, helper.py:490-526).  A batch-50 fit cannot fill 256 CUs (its decoder stages
+// are 50-row kernels), so here the K fits of a work unit (same shapes, own weights / lr / dropout / seed / data) step
+// together: every call site of the step is launched ONCE for all K fits (launch.hpp).
+//
+//  record   for each fit, run the ordinary plan code (forward + criterion + backward + clip + SGD, or an eval
+//           forward) with a Recorder installed: nothing is launched, the call sites come back as a list of
+//           {kernel, grid, argument pack};
+//  merge    call site i of every fit must be the same kernel with the same geometry (same shapes => same code
+//           path); the K packs become one device table and grid.z = K; grouped-GEMM call sites concatenate their job
+//           lists into one device job table + a block -> job map (jobs start on multiples of 8 blocks so the
+//           XCD-aware tile order inside a job still sees blocks b and b + 8 on one XCD);
+//  replay   one hipLaunchKernel per merged call site.  Programs are cached per (data slot, batch size, train).
+//
+// Per-fit arithmetic is untouched -- block (x, y, z) does for fit z exactly what block (x, y) does in that fit's own
+// launch -- so every fit's weights, losses and log-probs are bit-identical to a solo run of the same fit.
+//
+// Data: each fit has its own device-resident dataset per slot (train / valid / test: X int64 [rows, S], y int64
+// [rows]); one gather launch copies batch [row0, row0 + B) of every fit into the staging buffers the recorded
+// programs read, and publishes {row0, batch index} as device scalars: lsm_nll writes the batch's log-probs at row
+// row0 of the fit's epoch-long output buffer and the loss into the fit's per-batch loss history, so a whole epoch
+// needs no host synchronisation and no per-step device-to-device copies.
+#include <map>
+#include <tuple>
+
+#include "gemm_jobs.hpp"
+#include "tf_plan.hpp"
+
+namespace slnlp {
+
+constexpr int LS_MAX_FITS = 64;
+constexpr int LS_SLOTS = 4;
+
+struct GatherArgs {
+    const int64_t* const* X;     // [K] dataset pointers (device table)
+    const int64_t* const* y;
+    int64_t* const* Xst;         // [K] staging pointers (device table)
+    int64_t* const* yst;
+    int* dyn;                    // {row0, batch index}
+    int S, row0, B, step;
+};
+
+__global__ __launch_bounds__(256) void ls_gather_kernel(const GatherArgs a) {
+    const int f = blockIdx.z;
+    const int64_t* X = a.X[f] + (long)a.row0 * a.S;
+    int64_t* Xs = a.Xst[f];
+    const int n = a.B * a.S;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) Xs[i] = X[i];
+    if (blockIdx.x == 0) {
+        const int64_t* y = a.y[f] + a.row0;
+        int64_t* ys = a.yst[f];
+        for (int i = threadIdx.x; i < a.B; i += 256) ys[i] = y[i];
+        if (f == 0 && threadIdx.x == 0) {
+            a.dyn[0] = a.row0;
+            a.dyn[1] = a.step;
+        }
+    }
+}
+
+struct MergedOp {
+    const void* fn;
+    dim3 grid, block;
+    size_t lds;
+    int kind;
+    std::vector<char> arg0;      // by-value first kernel argument (any fit's; unused when the table is set)
+    void* tab;                   // device: K packs, or the concatenated job table
+    int* blockmap;               // device: block -> job (group kinds)
+    const char* what;
+};
+struct Program {
+    std::vector<MergedOp> ops;
+};
+
+}  // namespace slnlp
+
+using namespace slnlp;
+
+struct slnlp_tf_lockstep {
+    std::vector<slnlp_tf_plan*> plans;
+    int K = 0, S = 0, maxB = 0;
+    char* ws = nullptr;
+    size_t ws_bytes = 0, ws_used = 0;
+    std::vector<int64_t*> Xst, yst;                 // per-fit staging (device)
+    int64_t** d_Xst = nullptr;                      // device tables of the above
+    int64_t** d_yst = nullptr;
+    int* dyn = nullptr;
+    struct Slot {
+        bool set = false;
+        int64_t rows = 0;
+        const int64_t** d_X = nullptr;              // device tables [K]
+        const int64_t** d_y = nullptr;
+        std::vector<float*> logp, loss;             // per-fit output buffers (device, caller-owned)
+    } slot[LS_SLOTS];
+    std::map<std::tuple<int, int, int>, Program> programs;   // (slot, B, train)
+
+    void* take(size_t bytes) {
+        ws_used = (ws_used + 255) & ~(size_t)255;
+        if (ws_used + bytes > ws_bytes) return nullptr;
+        void* p = ws + ws_used;
+        ws_used += bytes;
+        return p;
+    }
+};
+
+static int upload(slnlp_tf_lockstep* ls, const void* host, size_t bytes, void** dev, hipStream_t st) {
+    void* d = ls->take(bytes);
+    SLNLP_CHECK_ARG(d, "lockstep: workspace exhausted (%zu of %zu bytes used, %zu more needed)", ls->ws_used, ls->ws_bytes, bytes);
+    // synchronous with respect to the host buffer (pageable memory); ordered on `st` before the launches that read it
+    if (hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error("lockstep: table upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    *dev = d;
+    return 0;
+}
+
+static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& prog, hipStream_t st) {
+    const int K = (int)recs.size();
+    const size_t nops = recs[0].ops.size();
+    for (int f = 1; f < K; ++f)
+        SLNLP_CHECK_ARG(recs[f].ops.size() == nops, "lockstep: fit %d recorded %zu launches, fit 0 %zu -- not the same shape", f,
+                        recs[f].ops.size(), nops);
+    for (size_t i = 0; i < nops; ++i) {
+        const RecOp& o0 = recs[0].ops[i];
+        for (int f = 1; f < K; ++f) {
+            const RecOp& o = recs[f].ops[i];
+            SLNLP_CHECK_ARG(o.fn == o0.fn && o.kind == o0.kind && o.block.x == o0.block.x && o.lds == o0.lds &&
+                                o.args.size() == o0.args.size() && (o.kind != REC_Z || (o.grid.x == o0.grid.x && o.grid.y == o0.grid.y)),
+                            "lockstep: call site %zu (%s) differs between fit 0 and fit %d", i, o0.what, f);
+        }
+        MergedOp m;
+        m.fn = o0.fn; m.block = o0.block; m.lds = o0.lds; m.kind = o0.kind; m.arg0 = o0.args; m.what = o0.what;
+        m.tab = nullptr; m.blockmap = nullptr;
+        if (o0.kind == REC_Z) {
+            SLNLP_CHECK_ARG(o0.grid.z == 1, "lockstep: call site %zu (%s) already uses grid.z", i, o0.what);
+            std::vector<char> tab(o0.args.size() * K);
+            for (int f = 0; f < K; ++f) memcpy(tab.data() + (size_t)f * o0.args.size(), recs[f].ops[i].args.data(), o0.args.size());
+            SLNLP_TRY(upload(ls, tab.data(), tab.size(), &m.tab, st));
+            m.grid = dim3(o0.grid.x, o0.grid.y, K);
+        } else if (o0.kind == REC_PLANE_GROUP) {
+            std::vector<PlaneJob> jobs;
+            std::vector<int> map;
+            for (int f = 0; f < K; ++f) {
+                const PlaneGroupParams* P = reinterpret_cast<const PlaneGroupParams*>(recs[f].ops[i].args.data());
+                for (int j = 0; j < P->njobs; ++j) {
+                    PlaneJob job = P->job[j];
+                    const int blocks = job.tiles_x * job.tiles_y * job.nks, padded = (blocks + 7) & ~7;
+                    job.block_begin = (int)map.size();
+                    map.insert(map.end(), padded, (int)jobs.size());
+                    jobs.push_back(job);
+                }
+            }
+            SLNLP_TRY(upload(ls, jobs.data(), jobs.size() * sizeof(PlaneJob), &m.tab, st));
+            void* bm = nullptr;
+            SLNLP_TRY(upload(ls, map.data(), map.size() * sizeof(int), &bm, st));
+            m.blockmap = (int*)bm;
+            m.grid = dim3((unsigned)map.size());
+        } else {
+            std::vector<GemmJob> jobs;
+            std::vector<int> map;
+            for (int f = 0; f < K; ++f) {
+                const GemmGroupParams* P = reinterpret_cast<const GemmGroupParams*>(recs[f].ops[i].args.data());
+                for (int j = 0; j < P->njobs; ++j) {
+                    GemmJob job;
+                    job.p = P->job[j]; job.variant = P->variant[j]; job.gx = P->gx[j]; job.gy = P->gy[j];
+                    job.block_begin = (int)map.size();
+                    map.insert(map.end(), job.gx * job.gy, (int)jobs.size());
+                    jobs.push_back(job);
+                }
+            }
+            SLNLP_TRY(upload(ls, jobs.data(), jobs.size() * sizeof(GemmJob), &m.tab, st));
+            void* bm = nullptr;
+            SLNLP_TRY(upload(ls, map.data(), map.size() * sizeof(int), &bm, st));
+            m.blockmap = (int*)bm;
+            m.grid = dim3((unsigned)map.size());
+        }
+        prog.ops.push_back(std::move(m));
+    }
+    return 0;
+}
+
+static int replay(const Program& prog, hipStream_t st) {
+    for (const MergedOp& m : prog.ops) {
+        void* tab = m.tab;
+        void* bm = m.blockmap;
+        void* args[3] = {(void*)m.arg0.data(), &tab, &bm};
+        if (hipLaunchKernel(m.fn, m.grid, m.block, args, m.lds, st) != hipSuccess) {
+            set_error("lockstep: launch of %s failed: %s", m.what, hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+    }
+    return 0;
+}
+
+extern "C" {
+
+int64_t slnlp_tf_lockstep_workspace_bytes(const slnlp_tf_config* cfg, int K) {
+    if (!cfg || K < 1 || K > LS_MAX_FITS) return -1;
+    // staging + pointer tables + argument / job tables of the cached programs.  A program has ~45 + 55 N call sites;
+    // a z-table entry is <= 256 B per fit, a grouped-GEMM job ~400 B with up to 4 jobs per fit and a block map of
+    // 4 B per workgroup (<= ~1200 per fit at E 1024): budget 24 KiB per call site and fit, for 8 programs.
+    const size_t staging = (size_t)K * ((size_t)cfg->B * cfg->S + cfg->B + 64) * sizeof(int64_t);
+    const size_t sites = 45 + 55 * (size_t)cfg->N;
+    return (int64_t)(staging + 65536 + 8 * sites * (size_t)K * 24576);
+}
+
+int slnlp_tf_lockstep_create(slnlp_tf_plan** plans, int K, void* workspace, int64_t workspace_bytes, void* stream,
+                             slnlp_tf_lockstep** out) {
+    SLNLP_CHECK_ARG(plans && out && K >= 1 && K <= LS_MAX_FITS, "lockstep_create: 1..%d plans", LS_MAX_FITS);
+    SLNLP_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "lockstep_create: workspace must be 256-byte aligned");
+    const slnlp_tf_config& c0 = plans[0]->cfg;
+    for (int f = 0; f < K; ++f) {
+        SLNLP_CHECK_ARG(plans[f], "lockstep_create: null plan %d", f);
+        const slnlp_tf_config& c = plans[f]->cfg;
+        SLNLP_CHECK_ARG(c.E == c0.E && c.H == c0.H && c.N == c0.N && c.F == c0.F && c.Vs == c0.Vs && c.Vt == c0.Vt && c.B == c0.B &&
+                            c.S == c0.S && c.precision == c0.precision && (c.dropout > 0.f) == (c0.dropout > 0.f),
+                        "lockstep_create: plan %d does not have the shape of plan 0 (lr, dropout rate and seed may differ; "
+                        "dropout on/off may not)", f);
+        for (int g = 0; g < f; ++g) SLNLP_CHECK_ARG(plans[g] != plans[f], "lockstep_create: plan %d listed twice", f);
+    }
+    slnlp_tf_lockstep* ls = new slnlp_tf_lockstep();
+    ls->plans.assign(plans, plans + K);
+    ls->K = K; ls->S = c0.S; ls->maxB = c0.B;
+    ls->ws = (char*)workspace; ls->ws_bytes = (size_t)workspace_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
+    for (int f = 0; f < K && !rc; ++f) {
+        int64_t* x = (int64_t*)ls->take((size_t)c0.B * c0.S * sizeof(int64_t));
+        int64_t* y = (int64_t*)ls->take((size_t)c0.B * sizeof(int64_t));
+        if (!x || !y) { set_error("lockstep_create: workspace too small"); rc = SLNLP_ERR_INVALID_ARG; break; }
+        ls->Xst.push_back(x);
+        ls->yst.push_back(y);
+    }
+    ls->dyn = rc ? nullptr : (int*)ls->take(64);
+    if (!rc && !ls->dyn) { set_error("lockstep_create: workspace too small"); rc = SLNLP_ERR_INVALID_ARG; }
+    if (!rc) rc = upload(ls, ls->Xst.data(), K * sizeof(void*), (void**)&ls->d_Xst, st);
+    if (!rc) rc = upload(ls, ls->yst.data(), K * sizeof(void*), (void**)&ls->d_yst, st);
+    if (rc) { delete ls; return rc; }
+    *out = ls;
+    return 0;
+}
+
+void slnlp_tf_lockstep_destroy(slnlp_tf_lockstep* ls) {
+    if (!ls) return;
+    (void)hipDeviceSynchronize();      // tables live in caller memory that may be freed next
+    for (slnlp_tf_plan* p : ls->plans) { p->ls_logp = nullptr; p->ls_loss = nullptr; p->ls_dyn = nullptr; }
+    delete ls;
+}
+
+// Slot `slot` of every fit: dataset X[f] int64 [rows, S] / y[f] int64 [rows] and where its outputs go: logp[f] float
+// [rows, Vt] (log-probs of every batch of a pass) and loss[f] float [ceil(rows / batch)] (loss per batch).
+int slnlp_tf_lockstep_set_data(slnlp_tf_lockstep* ls, int slot, const int64_t* const* X, const int64_t* const* y, int64_t rows,
+                               float* const* logp, float* const* loss, void* stream) {
+    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && X && y && logp && loss && rows > 0, "lockstep_set_data: bad arguments");
+    slnlp_tf_lockstep::Slot& s = ls->slot[slot];
+    for (auto it = ls->programs.begin(); it != ls->programs.end();)     // programs of this slot baked the old output pointers
+        it = std::get<0>(it->first) == slot ? ls->programs.erase(it) : std::next(it);
+    s.rows = rows;
+    s.logp.assign(logp, logp + ls->K);
+    s.loss.assign(loss, loss + ls->K);
+    SLNLP_TRY(upload(ls, X, ls->K * sizeof(void*), (void**)&s.d_X, (hipStream_t)stream));
+    SLNLP_TRY(upload(ls, y, ls->K * sizeof(void*), (void**)&s.d_y, (hipStream_t)stream));
+    s.set = true;
+    return 0;
+}
+
+// One lockstep step of every fit on rows [row0, row0 + B) of slot `slot`: train != 0 -> forward + criterion + backward +
+// clip + SGD (what slnlp_tf_train_step does for one fit), else an eval-mode forward + criterion.
+int slnlp_tf_lockstep_step(slnlp_tf_lockstep* ls, int slot, int64_t row0, int B, int step_index, int train, float momentum,
+                           float max_norm, void* stream) {
+    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && ls->slot[slot].set, "lockstep_step: slot %d has no data", slot);
+    slnlp_tf_lockstep::Slot& s = ls->slot[slot];
+    SLNLP_CHECK_ARG(B > 0 && B <= ls->maxB && row0 >= 0 && row0 + B <= s.rows, "lockstep_step: rows [%ld, %ld) outside 0..%ld or batch > %d",
+                    (long)row0, (long)(row0 + B), (long)s.rows, ls->maxB);
+    hipStream_t st = (hipStream_t)stream;
+    for (slnlp_tf_plan* pl : ls->plans) SLNLP_TRY(pl->prepare_planes(B, st));      // re-zero plane padding when B changes
+    const auto key = std::make_tuple(slot, B, train ? 1 : 0);
+    auto it = ls->programs.find(key);
+    if (it == ls->programs.end()) {
+        std::vector<Recorder> recs(ls->K);
+        int rc = 0;
+        for (int f = 0; f < ls->K && !rc; ++f) {
+            slnlp_tf_plan* pl = ls->plans[f];
+            pl->ls_logp = s.logp[f]; pl->ls_loss = s.loss[f]; pl->ls_dyn = ls->dyn;
+            set_recorder(&recs[f]);
+            rc = pl->forward_impl(ls->Xst[f], ls->yst[f], B, train, nullptr, st, false);
+            if (!rc && train) rc = slnlp_tf_backward(pl, st);
+            if (!rc && train) rc = slnlp_tf_optim(pl, momentum, max_norm, st);
+            set_recorder(nullptr);
+        }
+        if (rc) return rc;
+        Program prog;
+        SLNLP_TRY(merge(ls, recs, prog, st));
+        it = ls->programs.emplace(key, std::move(prog)).first;
+    } else {
+        for (slnlp_tf_plan* pl : ls->plans) { pl->last_B = B; pl->last_p = train ? pl->cfg.dropout : 0.f; }
+    }
+    GatherArgs g;
+    g.X = s.d_X; g.y = s.d_y; g.Xst = ls->d_Xst; g.yst = ls->d_yst; g.dyn = ls->dyn;
+    g.S = ls->S; g.row0 = (int)row0; g.B = B; g.step = step_index;
+    int gx = (B * ls->S + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(ls_gather_kernel, dim3(gx, 1, ls->K), dim3(256), 0, st, g);
+    SLNLP_CHECK_LAUNCH("lockstep gather");
+    return replay(it->second, st);
+}
+
+// One pass over slot `slot` in dataset order, batches of `batch` rows (the last one may be shorter).
+int slnlp_tf_lockstep_epoch(slnlp_tf_lockstep* ls, int slot, int batch, int train, float momentum, float max_norm, void* stream) {
+    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && ls->slot[slot].set && batch > 0, "lockstep_epoch: bad arguments");
+    const int64_t rows = ls->slot[slot].rows;
+    int step = 0;
+    for (int64_t r = 0; r < rows; r += batch, ++step) {
+        const int B = (int)(rows - r < batch ? rows - r : batch);
+        SLNLP_TRY(slnlp_tf_lockstep_step(ls, slot, r, B, step, train, momentum, max_norm, stream));
+    }
+    return 0;
+}
+
+int slnlp_tf_lockstep_num_launches(slnlp_tf_lockstep* ls, int slot, int B, int train) {
+    if (!ls) return -1;
+    auto it = ls->programs.find(std::make_tuple(slot, B, train ? 1 : 0));
+    return it == ls->programs.end() ? -1 : (int)it->second.ops.size() + 1;
+}
+
+}  // extern "C"

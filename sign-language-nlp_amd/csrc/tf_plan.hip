@@ -15,477 +15,10 @@
 #include <vector>
 
 #include "common.hpp"
-
-namespace slnlp {
-
-static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
-
-struct ParamEnt {
-    std::string name;
-    int64_t shape[2];
-    int ndim;
-    int64_t off, numel;
-};
-struct EncP { long in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b; };
-struct DecP {
-    long sin_w, sin_b, sout_w, sout_b, cin_w, cin_b, cout_w, cout_b, l1_w, l1_b, l2_w, l2_b;
-    long n1_w, n1_b, n2_w, n2_b, n3_w, n3_b;
-};
-struct Layout {
-    std::vector<ParamEnt> ents;
-    long src_emb, tgt_emb, encn_w, encn_b, decn_w, decn_b, lin_w, lin_b, total;
-    std::vector<EncP> enc;
-    std::vector<DecP> dec;
-};
-
-// Reference state_dict order (transformer.py:32-47 construction order; the
-// *_pos_encoding.pe buffers are not parameters and live outside the arena).
-// Every tensor starts on a 16-byte boundary so float4 access is always legal.
-static Layout build_layout(const slnlp_tf_config& c) {
-    Layout L;
-    long cur = 0;
-    auto add = [&](const std::string& n, long d0, long d1) -> long {
-        ParamEnt e;
-        e.name = n;
-        e.shape[0] = d0;
-        e.shape[1] = d1;
-        e.ndim = d1 > 0 ? 2 : 1;
-        e.numel = d1 > 0 ? d0 * d1 : d0;
-        e.off = cur;
-        cur = align_up(cur + e.numel, 4);
-        L.ents.push_back(e);
-        return e.off;
-    };
-    const long E = c.E, F = c.F;
-    L.src_emb = add("src_embedding.weight", c.Vs, E);
-    L.tgt_emb = add("tgt_embedding.weight", c.Vt, E);
-    for (int i = 0; i < c.N; ++i) {
-        const std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
-        EncP e;
-        e.in_w = add(p + "self_attn.in_proj_weight", 3 * E, E);
-        e.in_b = add(p + "self_attn.in_proj_bias", 3 * E, 0);
-        e.out_w = add(p + "self_attn.out_proj.weight", E, E);
-        e.out_b = add(p + "self_attn.out_proj.bias", E, 0);
-        e.l1_w = add(p + "linear1.weight", F, E);
-        e.l1_b = add(p + "linear1.bias", F, 0);
-        e.l2_w = add(p + "linear2.weight", E, F);
-        e.l2_b = add(p + "linear2.bias", E, 0);
-        e.n1_w = add(p + "norm1.weight", E, 0);
-        e.n1_b = add(p + "norm1.bias", E, 0);
-        e.n2_w = add(p + "norm2.weight", E, 0);
-        e.n2_b = add(p + "norm2.bias", E, 0);
-        L.enc.push_back(e);
-    }
-    L.encn_w = add("transformer.encoder.norm.weight", E, 0);
-    L.encn_b = add("transformer.encoder.norm.bias", E, 0);
-    for (int i = 0; i < c.N; ++i) {
-        const std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
-        DecP d;
-        d.sin_w = add(p + "self_attn.in_proj_weight", 3 * E, E);
-        d.sin_b = add(p + "self_attn.in_proj_bias", 3 * E, 0);
-        d.sout_w = add(p + "self_attn.out_proj.weight", E, E);
-        d.sout_b = add(p + "self_attn.out_proj.bias", E, 0);
-        d.cin_w = add(p + "multihead_attn.in_proj_weight", 3 * E, E);
-        d.cin_b = add(p + "multihead_attn.in_proj_bias", 3 * E, 0);
-        d.cout_w = add(p + "multihead_attn.out_proj.weight", E, E);
-        d.cout_b = add(p + "multihead_attn.out_proj.bias", E, 0);
-        d.l1_w = add(p + "linear1.weight", F, E);
-        d.l1_b = add(p + "linear1.bias", F, 0);
-        d.l2_w = add(p + "linear2.weight", E, F);
-        d.l2_b = add(p + "linear2.bias", E, 0);
-        d.n1_w = add(p + "norm1.weight", E, 0);
-        d.n1_b = add(p + "norm1.bias", E, 0);
-        d.n2_w = add(p + "norm2.weight", E, 0);
-        d.n2_b = add(p + "norm2.bias", E, 0);
-        d.n3_w = add(p + "norm3.weight", E, 0);
-        d.n3_b = add(p + "norm3.bias", E, 0);
-        L.dec.push_back(d);
-    }
-    L.decn_w = add("transformer.decoder.norm.weight", E, 0);
-    L.decn_b = add("transformer.decoder.norm.bias", E, 0);
-    L.lin_w = add("linear.weight", c.Vt, E);
-    L.lin_b = add("linear.bias", c.Vt, 0);
-    L.total = cur;
-    return L;
-}
-
-static int check_cfg(const slnlp_tf_config* c) {
-    SLNLP_CHECK_ARG(c, "tf: null config");
-    SLNLP_CHECK_ARG(c->E > 0 && c->H > 0 && c->E % c->H == 0, "tf: E=%d not divisible by H=%d", c->E, c->H);
-    const int dh = c->E / c->H;
-    SLNLP_CHECK_ARG(c->E % 4 == 0 && c->E <= 1024, "tf: E=%d must be a multiple of 4 and <= 1024", c->E);
-    SLNLP_CHECK_ARG(dh % 4 == 0 && dh <= 256 && (dh <= 64 || dh % 64 == 0), "tf: head_dim %d unsupported", dh);
-    SLNLP_CHECK_ARG(c->F > 0 && c->F % 4 == 0, "tf: hidden_size %d must be a multiple of 4", c->F);
-    SLNLP_CHECK_ARG(c->N > 0 && c->Vs > 1 && c->Vt > 1, "tf: bad N/vocab");
-    SLNLP_CHECK_ARG(c->B > 0 && c->B <= 1024, "tf: batch %d outside 1..1024", c->B);
-    SLNLP_CHECK_ARG(c->S > 0 && c->S <= 64, "tf: seq_len %d outside 1..64 (single-tile attention)", c->S);
-    SLNLP_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "tf: dropout %f", c->dropout);
-    SLNLP_CHECK_ARG(c->precision == 1 || c->precision == 3, "tf: precision %d", c->precision);
-    return 0;
-}
-
-// ------------------------------------------------------------- workspace ----
-struct Bump {
-    char* base;
-    size_t cur = 0;
-    explicit Bump(void* b) : base((char*)b) {}
-    template <typename T>
-    T* take(size_t n) {
-        cur = (cur + 255) & ~(size_t)255;
-        T* p = (T*)(base + cur);
-        cur += n * sizeof(T);
-        return p;
-    }
-};
-
-// forward activations kept for backward + this layer's gradient buffers.  Every gradient buffer is
-// written exactly once per step, so work forked to a side stream (wgrads) can keep reading it while
-// the main stream moves on -- there is nothing to overwrite until the next step.
-// bf16 hi/lo planes of a GEMM operand (same logical shape / row stride as its fp32 twin, rows
-// zero-padded to a multiple of 64): written once by the producer, read by gemm_planes.hip
-struct PP {
-    unsigned short *hi = nullptr, *lo = nullptr;
-    PlaneOut out() const { PlaneOut o; o.hi = hi; o.lo = lo; return o; }
-};
-struct EncA {
-    float *qkv, *probs, *ctx, *y1, *st1, *x1, *h, *y2, *st2, *x2, *lnp1, *lnp2;
-    float *gA2, *gB2, *gh, *gx1, *gA1, *gB1, *gctx, *gqkv, *gx0;
-    PP ctxp, x1p, hp, x2p, d2p, ghp, d1p, gqkvp;
-};
-struct DecA {
-    float *v, *y1, *st1, *t1, *q, *kv, *xprobs, *xctx, *y2, *st2, *t2, *h, *y3, *st3, *t3, *lnp1, *lnp2, *lnp3;
-    float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gkv, *gt1, *gA1, *gB1, *gv, *gt0;
-    PP gkvp;
-};
-struct Ws {
-    float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp, *row_nll;
-    std::vector<EncA> enc;
-    std::vector<DecA> dec;
-    float *gfin, *gtl, *gmem, *gxl;     // d tfin, d t_last, d memory, d x_last
-    void *emb_scratch_src, *emb_scratch_tgt;
-    unsigned char* emb_keep;   // 4 keep bits per float4 of the source embedding's dropout (read by its backward)
-    PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
-    char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
-    float* opt_partials;
-    char* gscr[2];          // split-K scratch of the grouped GEMM launches: [0] main stream, [1] side stream
-    size_t gscr_bytes;
-    slnlp_ln_reduce_entry* ln_table;
-    size_t bytes;
-};
-
-constexpr int MAX_SPLITK = 8;
-// weight-gradient GEMMs contract over the T tokens: aim at ~10 K-tiles (of 64) per workgroup
-static int splitk_for(int T) {
-    const int n = ((T + 63) / 64 + 5) / 10;
-    return n < 1 ? 1 : n > MAX_SPLITK ? MAX_SPLITK : n;
-}
-
-static Ws carve(const slnlp_tf_config& c, void* base) {
-    Ws w;
-    Bump b(base);
-    const size_t B = c.B, S = c.S, E = c.E, F = c.F, H = c.H, M = B * S, Vp = align_up(c.Vt, 4);
-    const size_t lnp = (size_t)SLNLP_LN_MAX_PARTIALS * 2 * E;
-    w.x0 = b.take<float>(M * E);
-    w.t0 = b.take<float>(B * E);
-    for (int i = 0; i < c.N; ++i) {
-        EncA a;
-        a.qkv = b.take<float>(M * 3 * E);
-        a.probs = b.take<float>(B * H * S * S);
-        a.ctx = b.take<float>(M * E);
-        a.y1 = b.take<float>(M * E);
-        a.st1 = b.take<float>(M * 2);
-        a.x1 = b.take<float>(M * E);
-        a.h = b.take<float>(M * F);
-        a.y2 = b.take<float>(M * E);
-        a.st2 = b.take<float>(M * 2);
-        a.x2 = b.take<float>(M * E);
-        a.lnp1 = b.take<float>(lnp);
-        a.lnp2 = b.take<float>(lnp);
-        a.gA2 = b.take<float>(M * E);
-        a.gB2 = b.take<float>(M * E);
-        a.gh = b.take<float>(M * F);
-        a.gx1 = b.take<float>(M * E);
-        a.gA1 = b.take<float>(M * E);
-        a.gB1 = b.take<float>(M * E);
-        a.gctx = b.take<float>(M * E);
-        a.gqkv = b.take<float>(M * 3 * E);
-        a.gx0 = b.take<float>(M * E);
-        w.enc.push_back(a);
-    }
-    w.mem = b.take<float>(M * E);
-    w.st_mem = b.take<float>(M * 2);
-    w.lnp_mem = b.take<float>(lnp);
-    for (int i = 0; i < c.N; ++i) {
-        DecA a;
-        a.v = b.take<float>(B * E);
-        a.y1 = b.take<float>(B * E);
-        a.st1 = b.take<float>(B * 2);
-        a.t1 = b.take<float>(B * E);
-        a.q = b.take<float>(B * E);
-        a.kv = b.take<float>(M * 2 * E);
-        a.xprobs = b.take<float>(B * H * S);
-        a.xctx = b.take<float>(B * E);
-        a.y2 = b.take<float>(B * E);
-        a.st2 = b.take<float>(B * 2);
-        a.t2 = b.take<float>(B * E);
-        a.h = b.take<float>(B * F);
-        a.y3 = b.take<float>(B * E);
-        a.st3 = b.take<float>(B * 2);
-        a.t3 = b.take<float>(B * E);
-        a.lnp1 = b.take<float>(lnp);
-        a.lnp2 = b.take<float>(lnp);
-        a.lnp3 = b.take<float>(lnp);
-        a.gA3 = b.take<float>(B * E);
-        a.gB3 = b.take<float>(B * E);
-        a.gh = b.take<float>(B * F);
-        a.gt2 = b.take<float>(B * E);
-        a.gA2 = b.take<float>(B * E);
-        a.gB2 = b.take<float>(B * E);
-        a.gxctx = b.take<float>(B * E);
-        a.gq = b.take<float>(B * E);
-        a.gkv = b.take<float>(M * 2 * E);
-        a.gt1 = b.take<float>(B * E);
-        a.gA1 = b.take<float>(B * E);
-        a.gB1 = b.take<float>(B * E);
-        a.gv = b.take<float>(B * E);
-        a.gt0 = b.take<float>(B * E);
-        w.dec.push_back(a);
-    }
-    w.tfin = b.take<float>(B * E);
-    w.st_fin = b.take<float>(B * 2);
-    w.lnp_fin = b.take<float>(lnp);
-    w.logits = b.take<float>(B * Vp);
-    w.dlogits = b.take<float>(B * Vp);
-    w.logp = b.take<float>(B * c.Vt);
-    w.row_nll = b.take<float>(B);
-    w.gfin = b.take<float>(B * E);
-    w.gtl = b.take<float>(B * E);
-    w.gmem = b.take<float>(M * E);
-    w.gxl = b.take<float>(M * E);
-    w.emb_scratch_src = b.take<char>(embed_bwd_scratch_bytes(c.B, c.S, c.E));
-    w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
-    w.emb_keep = b.take<unsigned char>(M * E / 4);
-    w.opt_partials = b.take<float>(1024);
-    w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
-    // ---- bf16 operand planes (only used when E and F are multiples of 64)
-    const size_t Mp = (M + 63) / 64 * 64;
-    auto pp = [&](size_t cols) { PP q; q.hi = b.take<unsigned short>(Mp * cols); q.lo = b.take<unsigned short>(Mp * cols); return q; };
-    const size_t wtot = (size_t)build_layout(c).total + 64 * 3 * (E > F ? E : F);   // tail pad: tiles may over-read rows
-    w.wp.hi = b.take<unsigned short>(wtot);
-    w.wp.lo = b.take<unsigned short>(wtot);
-    b.cur = (b.cur + 255) & ~(size_t)255;
-    w.planes_begin = b.base + b.cur;
-    w.x0p = pp(E);
-    w.memp = pp(E);
-    for (int i = 0; i < c.N; ++i) {
-        EncA& a = w.enc[i];
-        a.ctxp = pp(E); a.x1p = pp(E); a.hp = pp(F); a.x2p = pp(E);
-        a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
-        w.dec[i].gkvp = pp(2 * E);
-    }
-    {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
-        const size_t tx = ((E > F ? E : F) + 63) / 64, ty = ((3 * E > F ? 3 * E : F) + 63) / 64;
-        w.gscr_bytes = 16384 + tx * ty * MAX_SPLITK * (512 * 8 * sizeof(float)) + ty * MAX_SPLITK * 64 * sizeof(float);
-        w.gscr_bytes = (w.gscr_bytes + 255) & ~(size_t)255;
-        for (int i = 0; i < 2; ++i) w.gscr[i] = b.take<char>(w.gscr_bytes);
-    }
-    b.cur = (b.cur + 255) & ~(size_t)255;
-    w.planes_end = b.base + b.cur;
-    w.bytes = (b.cur + 255) & ~(size_t)255;
-    return w;
-}
-
-}  // namespace slnlp
+#include "launch.hpp"
+#include "tf_plan.hpp"
 
 using namespace slnlp;
-
-// dropout site ids
-enum { SITE_SRC_EMB = 1, SITE_TGT_EMB = 2, SITE_LAYER0 = 16, SITE_PER_LAYER = 8 };
-
-constexpr int NSIDE = 2;
-
-struct slnlp_tf_plan {
-    slnlp_tf_config cfg;
-    slnlp_tf_buffers buf;
-    Layout L;
-    Ws w;
-    int last_B = 0;       // batch of the last forward
-    float last_p = 0.f;   // dropout used by the last forward (0 in eval)
-    const int64_t* last_X = nullptr;
-    const int64_t* last_y = nullptr;
-    std::map<int, hipGraphExec_t> graphs;   // one captured train step per batch size, kept until destroy
-    int nbE = 0, nbD = 0;  // LN-backward block counts of the FULL batch (fixed: the reduce table is static)
-    // Side streams: independent work (weight gradients, the memory K/V projections, embedding
-    // gradients, the scalar loss) is forked off the dependent chain with events and joined before the
-    // optimizer.  A single B=50 fit cannot fill 256 CUs with one kernel at a time; under stream
-    // capture the forks become parallel branches of the hipGraph.
-    hipStream_t side[NSIDE] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev_kv;
-    bool side_dirty[NSIDE] = {false, false};
-    bool use_planes = false;   // E, F multiples of 64: M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
-    int planes_B = -1;         // batch size the activation planes' zero padding is valid for
-
-    float* P(long off) const { return buf.params + off; }
-    float* G(long off) const { return buf.grads + off; }
-    int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
-    int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
-
-    // side[k] may start once everything enqueued on `main` so far has finished
-    int fork(hipStream_t main, int k) {
-        if (hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side[k], ev_fork, 0) != hipSuccess) {
-            set_error("tf: fork to side stream failed: %s", hipGetErrorString(hipGetLastError()));
-            return SLNLP_ERR_LAUNCH;
-        }
-        side_dirty[k] = true;
-        return 0;
-    }
-    // `main` waits for everything enqueued on side[k]
-    int join(hipStream_t main, int k) {
-        if (!side_dirty[k]) return 0;
-        if (hipEventRecord(ev_join[k], side[k]) != hipSuccess || hipStreamWaitEvent(main, ev_join[k], 0) != hipSuccess) {
-            set_error("tf: join of side stream failed: %s", hipGetErrorString(hipGetLastError()));
-            return SLNLP_ERR_LAUNCH;
-        }
-        side_dirty[k] = false;
-        return 0;
-    }
-    int join_all(hipStream_t main) {
-        for (int k = 0; k < NSIDE; ++k) SLNLP_TRY(join(main, k));
-        return 0;
-    }
-
-    int dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const;
-
-    // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
-    int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
-               float p, int site, const float* resid, hipStream_t st, int drop_head_dim = 0) const {
-        slnlp_gemm_args a;
-        memset(&a, 0, sizeof(a));
-        a.A = x; a.lda = K; a.a_kmajor = 1;
-        a.B = W; a.ldb = K; a.b_kmajor = 1;
-        a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
-        a.bias = bias; a.relu = relu;
-        a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
-        a.resid = resid; a.ldr = ldy;
-        a.precision = cfg.precision;
-        a.drop_head_dim = drop_head_dim;
-        return gemm(a, st);
-    }
-    // dx[M,Kin] = dy[M,Nout] W[Nout,Kin]  (*gate) (+resid)
-    slnlp_gemm_args dgrad_args(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx,
-                               const float* gate, float gate_scale, const float* resid) const {
-        slnlp_gemm_args a;
-        memset(&a, 0, sizeof(a));
-        a.A = dy; a.lda = ldy; a.a_kmajor = 1;
-        a.B = W; a.ldb = Kin; a.b_kmajor = 0;
-        a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
-        a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
-        a.resid = resid; a.ldr = Kin;
-        a.precision = cfg.precision;
-        return a;
-    }
-    int dgrad(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx, const float* gate,
-              float gate_scale, const float* resid, hipStream_t st) const {
-        return gemm(dgrad_args(dy, ldy, M, Nout, W, Kin, dx, gate, gate_scale, resid), st);
-    }
-    // dW[Nout,Kin] = dy[T,Nout]^T x[T,Kin];  db[Nout] = colsum(dy)
-    slnlp_gemm_args wgrad_args(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db) const {
-        slnlp_gemm_args a;
-        memset(&a, 0, sizeof(a));
-        a.A = dy; a.lda = ldy; a.a_kmajor = 0;
-        a.B = x; a.ldb = Kin; a.b_kmajor = 0;
-        a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
-        a.rowsum_a = db;
-        a.precision = cfg.precision;
-        return a;
-    }
-    int wgrad(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db,
-              hipStream_t st) const {
-        return gemm(wgrad_args(dy, ldy, T, Nout, x, Kin, dW, db), st);
-    }
-    // weight- and data-gradient of one dY (fp32 operands) in one launch
-    int wd_group_f(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, hipStream_t st) const {
-        const slnlp_gemm_args jobs[2] = {wg, dg};
-        return gemm_group(jobs, 2, st);
-    }
-    // ---- the same three GEMM roles over pre-split planes; weights: planes of the arena at offset woff
-    int linear_p(const PP& x, int M, int K, long woff, int N, const float* bias, float* y, long ldy, int relu, float p,
-                 int site, const float* resid, const PP* outp, hipStream_t st) const {
-        slnlp_gemm_args a;
-        memset(&a, 0, sizeof(a));
-        a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
-        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; a.b_kmajor = 1;
-        a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
-        a.bias = bias; a.relu = relu;
-        a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
-        a.resid = resid; a.ldr = ldy;
-        if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
-        a.precision = cfg.precision;
-        return gemm(a, st);
-    }
-    slnlp_gemm_args dgrad_p_args(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
-                                 float gate_scale, const float* resid, const PP* outp) const {
-        slnlp_gemm_args a;
-        memset(&a, 0, sizeof(a));
-        a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = ldy; a.a_kmajor = 1;
-        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = Kin; a.b_kmajor = 0;
-        a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
-        a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
-        a.resid = resid; a.ldr = Kin;
-        if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = Kin; }
-        a.precision = cfg.precision;
-        return a;
-    }
-    int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
-                float gate_scale, const float* resid, const PP* outp, hipStream_t st) const {
-        return gemm(dgrad_p_args(dy, ldy, M, Nout, woff, Kin, dx, gate, gate_scale, resid, outp), st);
-    }
-    slnlp_gemm_args wgrad_p_args(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db) const {
-        slnlp_gemm_args a;
-        memset(&a, 0, sizeof(a));
-        a.A_hi = dy.hi; a.A_lo = dy.lo; a.lda_p = ldy; a.a_kmajor = 0;
-        a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
-        a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
-        a.rowsum_a = db;
-        a.precision = cfg.precision;
-        return a;
-    }
-    int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {
-        return gemm(wgrad_p_args(dy, ldy, T, Nout, x, Kin, dW, db), st);
-    }
-    // weight gradient (split-K over the tokens) and data gradient of one dY in ONE launch: the wgrad's workgroups
-    // fill the CUs the dgrad leaves idle, and there is no cross-queue edge to pay for (measured 4-10 us each)
-    int wd_group(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, int which_scratch, hipStream_t st) const {
-        const slnlp_gemm_args jobs[2] = {wg, dg};
-        // Split factor of the weight gradient (K loop = tokens): the plane GEMM keeps 2 workgroups per CU resident
-        // (512 slots) and a K-step costs about the same in every workgroup, so estimate
-        //   time ~ rounds(total workgroups / 512) x longest K loop   (+1 step for the split-K meeting)
-        // and take the best split; more workgroups than slots only adds a second, mostly empty round.
-        auto cd = [](int a, int b) { return (a + b - 1) / b; };
-        const int tw = cd(wg.M, 64) * cd(wg.N, 64), td = cd(dg.M, 64) * cd(dg.N, 64), kw = cd(wg.K, 64), kd = cd(dg.K, 64);
-        int best = 1, best_cost = 1 << 30;
-        for (int n = 1; n <= MAX_SPLITK && n <= kw; ++n) {
-            const int len = cd(kw, n) + (n > 1 ? 1 : 0);
-            const int cost = cd(tw * n + td, 512) * (len > kd ? len : kd);
-            if (cost < best_cost) { best_cost = cost; best = n; }
-        }
-        const int split[2] = {best, 1};
-        return gemm_planes_group(jobs, split, 2, w.gscr[which_scratch], w.gscr_bytes, st);
-    }
-    // zero padding of the activation planes is per batch size: re-zero when it changes (outside any capture)
-    int prepare_planes(int B, hipStream_t st) {
-        if (!use_planes || B == planes_B) return 0;
-        if (hipMemsetAsync(w.planes_begin, 0, (size_t)(w.planes_end - w.planes_begin), st) != hipSuccess) {
-            set_error("tf: zeroing operand planes failed");
-            return SLNLP_ERR_LAUNCH;
-        }
-        planes_B = B;
-        return 0;
-    }
-    int forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
-                     bool defer_join);
-};
 
 extern "C" {
 
@@ -672,7 +205,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         else
             SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0,
                                  0.f, 0, nullptr, side[0]));
-        if (hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
+        if (!recording() && hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
             set_error("tf_forward: event record failed");
             return SLNLP_ERR_LAUNCH;
         }
@@ -684,7 +217,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         const DecA& a = w.dec[l];
         if (l == 0) SLNLP_TRY(join(st, 1));                     // layer 0's block ran on side[1] (above)
         else SLNLP_TRY(dec_self_block(l, t, B, p, st));
-        if (hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
+        if (!recording() && hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
             set_error("tf_forward: wait for K/V projection failed");
             return SLNLP_ERR_LAUNCH;
         }
@@ -700,13 +233,11 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
     SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
     // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70)
+    // the caller's copy of the log-probs is written by the same kernel (no device-to-device copy); in lockstep it lands
+    // in the epoch buffer at the batch's row offset and the loss in the epoch's loss history
     SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp,
-                      w.row_nll, st, nullptr));
-    if (logp_out &&
-        hipMemcpyAsync(logp_out, w.logp, (size_t)B * c.Vt * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-        set_error("tf_forward: copy of log-probs failed");
-        return SLNLP_ERR_LAUNCH;
-    }
+                      w.row_nll, st, nullptr, logp_out ? logp_out : ls_logp, logp_out ? nullptr : ls_dyn,
+                      logp_out ? nullptr : ls_loss, (!logp_out && ls_dyn) ? ls_dyn + 1 : nullptr));
     (void)defer_join;
     return 0;
 }

@@ -131,6 +131,13 @@ SIGNATURES = {
     "slnlp_tf_graph_capture_train": (i32, [vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_tf_graph_launch": (i32, [vp, i32, vp]),
     "slnlp_tf_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
+    "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),
+    "slnlp_tf_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),
+    "slnlp_tf_lockstep_destroy": (None, [vp]),
+    "slnlp_tf_lockstep_set_data": (i32, [vp, i32, vp, vp, i64, vp, vp, vp]),
+    "slnlp_tf_lockstep_step": (i32, [vp, i32, i64, i32, i32, i32, C.c_float, C.c_float, vp]),
+    "slnlp_tf_lockstep_epoch": (i32, [vp, i32, i32, i32, C.c_float, C.c_float, vp]),
+    "slnlp_tf_lockstep_num_launches": (i32, [vp, i32, i32, i32]),
 }
 
 _lib = None

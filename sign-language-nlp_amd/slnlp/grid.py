@@ -67,19 +67,21 @@ def build_tasks(param_grid, y, cv, seq_len=48, defaults=None):
     return cands, folds, tasks, order
 
 
-SHAPE_KEYS_EXCLUDED = ("lr", "optimizer__momentum", "module__dropout")
+SHAPE_KEYS_EXCLUDED = ("lr", "module__dropout")
 
 
 def build_units(cands, folds, tasks, order, lockstep=1):
     """Pack the cost-ordered task list into work units of up to ``lockstep`` tasks that can advance through one
-    launch sequence: same candidate shapes (every parameter except lr / momentum / dropout) and the same train-fold
+    launch sequence: same candidate shapes (every parameter except lr / dropout rate) and the same train-fold
     size (=> the same number and sizes of batches).  ``lockstep <= 1``: one task per unit."""
     if lockstep <= 1:
         return [[t] for t in order]
     units, open_units = [], {}
     for t in order:
         ci, fi = tasks[t]
+        drop = cands[ci].get("module__dropout")
         key = (tuple(sorted((k, repr(v)) for k, v in cands[ci].items() if k not in SHAPE_KEYS_EXCLUDED)),
+               None if drop is None else bool(drop > 0),          # dropout on / off changes the launch sequence, its rate does not
                len(folds[fi][0]), len(folds[fi][1]))
         u = open_units.get(key)
         if u is None:

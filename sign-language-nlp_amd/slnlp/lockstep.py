@@ -1,0 +1,192 @@
+"""K fits of one shape advancing in lockstep through ONE launch sequence (libslnlp ``slnlp_tf_lockstep_*``).
+
+The reference runs the (candidate x fold) fits of its grid one at a time per worker
+(/root/reference/main.py:70-78, helper.py:490-526).  One batch-50 fit cannot fill an MI355X -- its decoder stages
+are 50-row kernels -- and fits on separate streams only reach 1.26x.  Fits of one work unit (same shapes; own
+weights, lr, dropout rate, seed and data) therefore share every kernel launch: a 50-row stage becomes a K x 50-row
+stage at the same latency, the grouped GEMM launches carry K times the tiles.  Each fit's arithmetic is untouched,
+so its history, weights and scores are bit-identical to a solo fit (tests/test_lockstep_gpu.py).
+
+``LockstepGroup`` owns the C object; ``fit_lockstep`` is ``NeuralNetClassifier.partial_fit`` for K estimators at once
+(the per-epoch callbacks are the same ``_FitRun`` code); ``fit_and_score_group`` is what ``ShardedGridSearchCV(lockstep=k)``
+calls per work unit.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from ._lib import check, load, ptr, stream_ptr
+
+TRAIN, VALID, TEST = 0, 1, 2
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+class LockstepGroup:
+    """The fits' TransformerEngines (same configuration up to the dropout rate) stepping together."""
+
+    def __init__(self, engines):
+        cfg = engines[0].cfg
+        self.engines, self.K, self.device = list(engines), len(engines), engines[0].device
+        nbytes = int(load().slnlp_tf_lockstep_workspace_bytes(C.byref(cfg), self.K))
+        if nbytes < 0:
+            raise RuntimeError("lockstep: bad configuration")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        handles = (C.c_void_p * self.K)(*[e.handle for e in self.engines])
+        out = C.c_void_p()
+        check(load().slnlp_tf_lockstep_create(handles, self.K, ptr(self.workspace), nbytes, stream_ptr(), C.byref(out)),
+              "tf_lockstep_create")
+        self.handle = out
+        self.data, self.logp, self.loss, self.rows = {}, {}, {}, {}
+
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            load().slnlp_tf_lockstep_destroy(h)
+
+    __del__ = close
+
+    def set_data(self, slot, Xs, ys, batch):
+        """Per-fit datasets of one slot (device int64 [rows, S] / [rows], the same number of rows for every fit).  Allocates
+        the slot's output buffers: ``logp[slot][f]`` [rows, Vt] and ``loss[slot][f]`` [ceil(rows / batch)]."""
+        rows = int(Xs[0].shape[0])
+        assert len(Xs) == len(ys) == self.K and all(x.shape[0] == rows and x.is_contiguous() for x in Xs)
+        Vt = self.engines[0].cfg.Vt
+        nb = (rows + batch - 1) // batch
+        self.data[slot] = (list(Xs), list(ys))           # keep the tensors alive: the C side holds raw pointers
+        self.logp[slot] = [torch.empty(rows, Vt, dtype=torch.float32, device=self.device) for _ in range(self.K)]
+        self.loss[slot] = [torch.zeros(nb, dtype=torch.float32, device=self.device) for _ in range(self.K)]
+        self.rows[slot] = rows
+        check(load().slnlp_tf_lockstep_set_data(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), rows,
+                                                _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), stream_ptr()),
+              "tf_lockstep_set_data")
+
+    def step(self, slot, row0, B, step_index, train, momentum=0.9, max_norm=0.5):
+        check(load().slnlp_tf_lockstep_step(self.handle, slot, row0, B, step_index, int(train), momentum, max_norm, stream_ptr()),
+              "tf_lockstep_step")
+
+    def epoch(self, slot, batch, train, momentum=0.9, max_norm=0.5):
+        """One pass over the slot in dataset order; no host synchronisation.  Results: ``logp[slot]``, ``loss[slot]``."""
+        check(load().slnlp_tf_lockstep_epoch(self.handle, slot, batch, int(train), momentum, max_norm, stream_ptr()),
+              "tf_lockstep_epoch")
+
+    def num_launches(self, slot, B, train):
+        return int(load().slnlp_tf_lockstep_num_launches(self.handle, slot, B, int(train)))
+
+    def results(self, slot, f, batch):
+        """What ``NeuralNetClassifier._run_epoch`` returns for fit ``f``: (batch-size weighted mean loss, log-probs [rows, Vt],
+        [(batch loss, batch size)]).  Call after a synchronisation point."""
+        rows = self.rows[slot]
+        sizes = [min(batch, rows - r) for r in range(0, rows, batch)]
+        per_batch = self.loss[slot][f].float().cpu()
+        w = torch.tensor(sizes, dtype=torch.float32)
+        mean = float((per_batch * w).sum() / w.sum())
+        return mean, self.logp[slot][f], list(zip(per_batch.tolist(), sizes))
+
+
+def lockstep_supported(net):
+    """Fused SGD + CrossEntropyLoss on a Transformer module: what the lockstep launch sequence implements."""
+    return bool(getattr(net, "_fused", False)) and type(net.module_).__name__ == "Transformer"
+
+
+def fit_lockstep(nets, datasets):
+    """``net.partial_fit(ds)`` for every (net, ds) pair, all fits advancing together.  The nets must be initialised,
+    of one shape (lr and dropout rate may differ) and their datasets of one size; fits that stop early (EarlyStopping)
+    leave the group, the others go on."""
+    from .net import _FitRun
+    K = len(nets)
+    runs = [_FitRun(n, d) for n, d in zip(nets, datasets)]
+    r0 = runs[0]
+    assert all(lockstep_supported(n) for n in nets), "lockstep: fused SGD + CrossEntropyLoss on model.Transformer only"
+    assert all((r.bs, r.momentum, r.max_norm, len(r.tr), (len(r.va) if r.va is not None else 0)) ==
+               (r0.bs, r0.momentum, r0.max_norm, len(r0.tr), (len(r0.va) if r0.va is not None else 0)) for r in runs), \
+        "lockstep: the fits of a group share batch size, momentum, clipping and split sizes"
+    S = r0.Xtr.shape[1]
+    engines = [n.module_.engine(r0.bs, S) for n in nets]
+    stream = nets[0]._stream
+    active, group = [i for i in range(K) if not runs[i].done], None
+    members = None
+    with torch.cuda.stream(stream):
+        while active:
+            if members != active:                       # a fit left (or first epoch): regroup the ones still training
+                if group is not None:
+                    torch.cuda.synchronize()
+                    group.close()
+                group = LockstepGroup([engines[i] for i in active])
+                group.set_data(TRAIN, [runs[i].Xtr for i in active], [runs[i].ytr for i in active], r0.bs)
+                if r0.va is not None:
+                    group.set_data(VALID, [runs[i].Xva for i in active], [runs[i].yva for i in active], r0.bs)
+                members = list(active)
+            for i in active:
+                engines[i].set_lr(nets[i].lr_)
+                nets[i].module_.train()
+                runs[i].begin_epoch()
+            group.epoch(TRAIN, r0.bs, True, r0.momentum, r0.max_norm)
+            if r0.va is not None:
+                group.epoch(VALID, r0.bs, False, r0.momentum, r0.max_norm)
+            torch.cuda.synchronize()                    # one host sync per epoch for all K fits
+            nxt = []
+            for j, i in enumerate(active):
+                tr = group.results(TRAIN, j, r0.bs)
+                va = group.results(VALID, j, r0.bs) if r0.va is not None else None
+                if not runs[i].end_epoch(tr, va):
+                    nxt.append(i)
+            active = nxt
+    torch.cuda.synchronize()
+    if group is not None:
+        group.close()
+    return nets
+
+
+def predict_proba_lockstep(nets, datasets):
+    """``net.predict_proba(ds)`` for every pair through one launch sequence (eval-mode forward, softmax of the log-probs as
+    skorch's predict_nonlinearity='auto' does)."""
+    bs = int(nets[0].batch_size)
+    dev = [n._device_data(d) for n, d in zip(nets, datasets)]
+    S = dev[0][0].shape[1]
+    engines = [n.module_.engine(bs, S) for n in nets]
+    with torch.cuda.stream(nets[0]._stream):
+        for n in nets:
+            n.module_.eval()
+        group = LockstepGroup(engines)
+        group.set_data(TEST, [d[0] for d in dev], [d[2] for d in dev], bs)
+        group.epoch(TEST, bs, False)
+        out = [torch.softmax(lp, dim=-1) if n.predict_nonlinearity == "auto" else lp for n, lp in zip(nets, group.logp[TEST])]
+        torch.cuda.synchronize()
+        out = [o.cpu().numpy() for o in out]
+        group.close()
+    return out
+
+
+def fit_and_score_group(estimator_factory, params_list, trains, tests, scoring="neg_log_loss", seeds=None):
+    """``grid.default_fit_and_score`` for the tasks of one work unit: fresh estimators (seeded one after another, like the
+    one-at-a-time path), one lockstep fit, one lockstep scoring pass over the test folds.  Falls back to one fit at a time for
+    anything the lockstep sequence does not implement (other modules / optimizers) -- same results, just not merged."""
+    from .grid import default_fit_and_score
+    from .net import INIT_LOCK, ScoringWrapper, _CachedPredictor
+    seeds = seeds or [None] * len(params_list)
+    nets = []
+    for params, seed in zip(params_list, seeds):
+        net = estimator_factory().set_params(**params)
+        if "checkpoint_dir" in net.get_params():
+            net.set_params(checkpoint_dir=None)
+        with INIT_LOCK:
+            if seed is not None:
+                torch.manual_seed(seed)
+            net.initialize()
+        nets.append(net)
+    if not all(lockstep_supported(n) for n in nets) or len({len(t) for t in trains}) != 1 or len({len(t) for t in tests}) != 1:
+        del nets
+        return [default_fit_and_score(estimator_factory, p, tr, te, scoring, seed=s)
+                for p, tr, te, s in zip(params_list, trains, tests, seeds)]
+    fit_lockstep(nets, trains)
+    probas = predict_proba_lockstep(nets, tests)
+    scores = []
+    for net, train, test, proba in zip(nets, trains, tests, probas):
+        wr = ScoringWrapper(scoring, train.labels() if scoring == "neg_log_loss" else None)
+        scores.append(float(wr(_CachedPredictor(proba, net.classes_), None, test.y)))
+    return scores

@@ -81,6 +81,98 @@ class _CachedPredictor(ClassifierMixin, BaseEstimator):
         return self.classes_[self._proba.argmax(-1)]
 
 
+class _FitRun:
+    """One estimator's fit between epochs: the internal split, the device-resident data, and skorch's per-epoch callbacks
+    (EpochScoring on the cached predictions, Checkpoint, LRScheduler(ReduceLROnPlateau), EarlyStopping; helper.py:197-273).
+    ``partial_fit`` drives one of these with its own batch loop; ``slnlp.lockstep`` drives K of them with one launch
+    sequence per step -- the epoch bookkeeping is this one piece of code either way."""
+
+    def __init__(self, net, ds):
+        self.net = net
+        net.classes_ = np.arange(len(ds.vocab_y)) if ds.vocab_y is not None else np.arange(int(ds.y.max()) + 1)
+        labels = net.labels if net.labels is not None else ds.labels()
+        idx_tr, idx_va = net._train_split(ds)
+        self.tr, self.va = ds[idx_tr], (ds[idx_va] if idx_va is not None else None)
+        self.Xtr, self.Ltr, self.ytr = net._device_data(self.tr)
+        if self.va is not None:
+            self.Xva, self.Lva, self.yva = net._device_data(self.va)
+        self.wrappers = [ScoringWrapper(s, labels) for s in (net.scoring or [])]
+        # the fast metrics index the probability columns by class id: valid when the labels are exactly the columns
+        self.fast_ok = labels is not None and list(labels) == list(range(len(net.classes_)))
+        es, clip, sched = net.early_stopping, net.gradient_clipping, net.lr_scheduler
+        self.es = es
+        self.max_norm = float(clip["gradient_clip_value"]) if clip and clip.get("gradient_clip_value") else 0.0
+        self.momentum = float(net._opt_kwargs.get("momentum", 0.0))
+        self.plateau = None
+        if sched:
+            assert sched.get("policy", "ReduceLROnPlateau") == "ReduceLROnPlateau", "only ReduceLROnPlateau is wired"
+            dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=net.lr_)
+            self.plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(
+                dummy, **{k: v for k, v in sched.items() if k not in ("policy", "monitor", "step_every")})
+        self.best_valid, self.misses, self.dyn_thr = float("inf"), 0, float("inf")
+        self.bs = int(net.batch_size)
+        self.epochs_left = int(net.max_epochs)
+        self.done = self.epochs_left <= 0
+
+    def begin_epoch(self):
+        self.t0 = time.time()
+
+    def end_epoch(self, tr, va):
+        """tr / va: (sample-weighted mean loss, log-probs [n, V] on the device, [(batch loss, batch size)]) of the epoch's
+        train and valid passes (va None without a valid split).  Returns True when the fit is over."""
+        net = self.net
+        tr_loss, tr_logp, tr_batches = tr
+        epoch = len(net.history) + 1
+        row = {"epoch": epoch, "train_loss": tr_loss, "lr": net.lr_,
+               "batches": [{"train_loss": l, "train_batch_size": n} for l, n in tr_batches]}   # skorch history layout
+        if va is not None:
+            va_loss, va_logp, va_batches = va
+            row["batches"] += [{"valid_loss": l, "valid_batch_size": n} for l, n in va_batches]
+            row["valid_loss"] = va_loss
+            row["valid_loss_best"] = bool(va_loss < self.best_valid)
+            self.best_valid = min(self.best_valid, va_loss)
+        # EpochScoring on the epoch's cached predictions: the reference's five metrics from one device-side
+        # reduction (slnlp/metrics.py, same numbers as the sklearn scorers); anything else through sklearn
+        splits = [("train", tr_logp, self.ytr, self.tr)] + ([("valid", va_logp, self.yva, self.va)] if va is not None else [])
+        names = [wr.score for wr in self.wrappers]
+        fast = {sp: metrics.epoch_scores(names, lp, yd, part.y) if self.fast_ok and names else {} for sp, lp, yd, part in splits}
+        proba = {}
+        for wr in self.wrappers:
+            for sp, lp, yd, part in splits:
+                if wr.score in fast[sp]:
+                    row[f"{sp}_{wr.score}"] = fast[sp][wr.score]
+                    continue
+                if sp not in proba:
+                    proba[sp] = np.exp(lp.cpu().numpy())
+                row[f"{sp}_{wr.score}"] = float(wr(_CachedPredictor(proba[sp], net.classes_), None, part.y))
+        row["dur"] = time.time() - self.t0
+        net.history.append(row)
+        if net.verbose:
+            print("  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in row.items() if k != "batches"))
+        if net.checkpoint_dir and row.get("valid_loss_best"):
+            net.save_params(net.checkpoint_dir)
+        monitor = row.get("valid_loss", tr_loss)
+        if self.plateau is not None:                         # LRScheduler(monitor=valid_loss, step_every=epoch)
+            self.plateau.step(monitor)
+            net._set_lr(self.plateau.optimizer.param_groups[0]["lr"])
+        self.epochs_left -= 1
+        if self.es:                                          # skorch EarlyStopping, lower_is_better
+            es = self.es
+            if monitor < self.dyn_thr:
+                self.misses = 0
+                thr = float(es.get("threshold", 1e-4))
+                self.dyn_thr = monitor - (thr * monitor if es.get("threshold_mode", "rel") == "rel" else thr)
+            else:
+                self.misses += 1
+            if self.misses == int(es.get("patience", 5)):
+                if net.verbose:
+                    print(f"Stopping since valid_loss has not improved in the last {self.misses} epochs.")
+                self.done = True
+        if self.epochs_left <= 0:
+            self.done = True
+        return self.done
+
+
 class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
     _OWN = ("module", "criterion", "optimizer", "lr", "max_epochs", "batch_size", "device", "warm_start", "verbose",
             "predict_nonlinearity", "scoring", "labels", "early_stopping", "gradient_clipping", "lr_scheduler",
@@ -214,77 +306,18 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
     def partial_fit(self, X, y=None, **fit_params):
         if not self.initialized_:
             self.initialize()
-        ds = self._as_dataset(X, y)
-        self.classes_ = np.arange(len(ds.vocab_y)) if ds.vocab_y is not None else np.arange(int(ds.y.max()) + 1)
-        labels = self.labels if self.labels is not None else ds.labels()
-        idx_tr, idx_va = self._train_split(ds)
-        tr, va = ds[idx_tr], (ds[idx_va] if idx_va is not None else None)
-        Xtr, Ltr, ytr = self._device_data(tr)
-        if va is not None:
-            Xva, Lva, yva = self._device_data(va)
-        wrappers = [ScoringWrapper(s, labels) for s in (self.scoring or [])]
-        # the fast metrics index the probability columns by class id: valid when the labels are exactly the columns
-        fast_ok = labels is not None and list(labels) == list(range(len(self.classes_)))
-        es, clip, sched = self.early_stopping, self.gradient_clipping, self.lr_scheduler
-        max_norm = float(clip["gradient_clip_value"]) if clip and clip.get("gradient_clip_value") else 0.0
-        momentum = float(self._opt_kwargs.get("momentum", 0.0))
-        plateau = None
-        if sched:
-            assert sched.get("policy", "ReduceLROnPlateau") == "ReduceLROnPlateau", "only ReduceLROnPlateau is wired"
-            dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=self.lr_)
-            plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(
-                dummy, **{k: v for k, v in sched.items() if k not in ("policy", "monitor", "step_every")})
-        best_valid, misses, dyn_thr = float("inf"), 0, float("inf")
-        bs = int(self.batch_size)
+        run = _FitRun(self, self._as_dataset(X, y))
         with torch.cuda.stream(self._stream):
-            for epoch in range(len(self.history) + 1, len(self.history) + int(self.max_epochs) + 1):
-                t0 = time.time()
+            for _ in range(int(self.max_epochs)):
+                run.begin_epoch()
                 self.module_.train()
-                tr_loss, tr_logp, tr_batches = self._run_epoch(Xtr, Ltr, ytr, bs, True, momentum, max_norm)
-                row = {"epoch": epoch, "train_loss": tr_loss, "lr": self.lr_,
-                       "batches": [{"train_loss": l, "train_batch_size": n} for l, n in tr_batches]}   # skorch history layout
-                if va is not None:
+                tr = self._run_epoch(run.Xtr, run.Ltr, run.ytr, run.bs, True, run.momentum, run.max_norm)
+                va = None
+                if run.va is not None:
                     self.module_.eval()
-                    va_loss, va_logp, va_batches = self._run_epoch(Xva, Lva, yva, bs, False, momentum, max_norm)
-                    row["batches"] += [{"valid_loss": l, "valid_batch_size": n} for l, n in va_batches]
-                    row["valid_loss"] = va_loss
-                    row["valid_loss_best"] = bool(va_loss < best_valid)
-                    best_valid = min(best_valid, va_loss)
-                # EpochScoring on the epoch's cached predictions: the reference's five metrics from one device-side
-                # reduction (slnlp/metrics.py, same numbers as the sklearn scorers); anything else through sklearn
-                splits = [("train", tr_logp, ytr, tr)] + ([("valid", va_logp, yva, va)] if va is not None else [])
-                names = [wr.score for wr in wrappers]
-                fast = {sp: metrics.epoch_scores(names, lp, yd, part.y) if fast_ok and names else {} for sp, lp, yd, part in splits}
-                proba = {}
-                for wr in wrappers:
-                    for sp, lp, yd, part in splits:
-                        if wr.score in fast[sp]:
-                            row[f"{sp}_{wr.score}"] = fast[sp][wr.score]
-                            continue
-                        if sp not in proba:
-                            proba[sp] = np.exp(lp.cpu().numpy())
-                        row[f"{sp}_{wr.score}"] = float(wr(_CachedPredictor(proba[sp], self.classes_), None, part.y))
-                row["dur"] = time.time() - t0
-                self.history.append(row)
-                if self.verbose:
-                    print("  ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in row.items() if k != "batches"))
-                if self.checkpoint_dir and row.get("valid_loss_best"):
-                    self.save_params(self.checkpoint_dir)
-                monitor = row.get("valid_loss", tr_loss)
-                if plateau is not None:                         # LRScheduler(monitor=valid_loss, step_every=epoch)
-                    plateau.step(monitor)
-                    self._set_lr(plateau.optimizer.param_groups[0]["lr"])
-                if es:                                          # skorch EarlyStopping, lower_is_better
-                    if monitor < dyn_thr:
-                        misses = 0
-                        thr = float(es.get("threshold", 1e-4))
-                        dyn_thr = monitor - (thr * monitor if es.get("threshold_mode", "rel") == "rel" else thr)
-                    else:
-                        misses += 1
-                    if misses == int(es.get("patience", 5)):
-                        if self.verbose:
-                            print(f"Stopping since valid_loss has not improved in the last {misses} epochs.")
-                        break
+                    va = self._run_epoch(run.Xva, run.Lva, run.yva, run.bs, False, run.momentum, run.max_norm)
+                if run.end_epoch(tr, va):
+                    break
         torch.cuda.synchronize()
         return self
 
