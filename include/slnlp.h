@@ -351,6 +351,8 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* plan, int B, void* stream);
 /* test helper: copy a named activation tap ("enc0", "memory", "dec1", "logits", ...) */
 int slnlp_tf_tap(slnlp_tf_plan* plan, const char* name, float* out, int64_t max_floats,
                  int64_t* n_out, void* stream);
+/* test / debug helper: "name byte_offset" lines of the workspace's activation and gradient buffers, in layout order */
+int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_bytes);
 
 /* ---------------------------------------------------------------- lockstep --
  * K Transformer fits of ONE shape (own weights, lr, dropout rate, seed and data) advancing through one launch

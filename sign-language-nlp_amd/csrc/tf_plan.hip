@@ -84,6 +84,7 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     p->w = carve(*cfg, buf->workspace);
     bool ok = attn_init() == 0 && gemm_planes_init() == 0;
     p->use_planes = (cfg->E % 64 == 0) && (cfg->F % 64 == 0);
+    if (const char* e = getenv("SLNLP_TF_SIDE_STREAMS")) p->side_mode = atoi(e);
     for (int k = 0; ok && k < NSIDE; ++k)
         ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
@@ -156,9 +157,12 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     // The target side up to the first cross-attention (embedding, layer 0's single-key self-attention block and its
     // query projection: five B-row launches) depends on nothing the encoder computes: it runs on side[1] next to the
     // encoder and is joined right before layer 0's cross-attention.
+    in_backward = false;
+    hipStream_t f0 = side_or(st, 0), f1 = side_or(st, 1);
+    const bool fwd_forks = forks_on();
     SLNLP_TRY(fork(st, 1));
-    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, side[1]));
-    SLNLP_TRY(dec_self_block(0, w.t0, B, p, side[1]));
+    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, f1));
+    SLNLP_TRY(dec_self_block(0, w.t0, B, p, f1));
     const bool up = use_planes;
     if (up) {   // weights as bf16 planes, once per forward (they changed in the optimizer step / load_state_dict)
         SLNLP_TRY(prepare_planes(B, st));
@@ -201,11 +205,11 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         const DecP& q = L.dec[l];
         if (up)
             SLNLP_TRY(pl->linear_p(w.memp, M, E, q.cin_w + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0, 0.f, 0,
-                                   nullptr, nullptr, side[0]));
+                                   nullptr, nullptr, f0));
         else
             SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0,
-                                 0.f, 0, nullptr, side[0]));
-        if (!recording() && hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
+                                 0.f, 0, nullptr, f0));
+        if (fwd_forks && hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
             set_error("tf_forward: event record failed");
             return SLNLP_ERR_LAUNCH;
         }
@@ -217,7 +221,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         const DecA& a = w.dec[l];
         if (l == 0) SLNLP_TRY(join(st, 1));                     // layer 0's block ran on side[1] (above)
         else SLNLP_TRY(dec_self_block(l, t, B, p, st));
-        if (!recording() && hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
+        if (fwd_forks && hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
             set_error("tf_forward: wait for K/V projection failed");
             return SLNLP_ERR_LAUNCH;
         }
@@ -259,7 +263,8 @@ int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
 int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
-    hipStream_t s0 = pl->side[0], s1 = pl->side[1];
+    pl->in_backward = true;
+    hipStream_t s0 = pl->side_or(st, 0), s1 = pl->side_or(st, 1);
     const slnlp_tf_config& c = pl->cfg;
     const Ws& w = pl->w;
     const Layout& L = pl->L;
@@ -386,6 +391,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st, w.emb_keep));
     SLNLP_TRY(pl->join_all(st));
     SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
+    pl->in_backward = false;
     return 0;
 }
 
@@ -452,6 +458,44 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* pl, int B, void* stream) {
         set_error("tf_graph_launch: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
+    return 0;
+}
+
+// Debug helper: "name offset" lines (byte offsets into the workspace, in carve order) of every fp32 activation /
+// gradient buffer -- lets a test locate a difference between two plans' workspaces.
+int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_bytes) {
+    SLNLP_TRY(check_cfg(cfg));
+    SLNLP_CHECK_ARG(out && out_bytes > 0, "tf_debug_layout: no output buffer");
+    const Ws w = carve(*cfg, nullptr);
+    std::string s;
+    auto add = [&](const std::string& n, const void* p) { s += n + " " + std::to_string((size_t)(const char*)p) + "\n"; };
+#define F(pre, st, f) add(pre + std::string(#f), st.f)
+    add("x0", w.x0); add("t0", w.t0);
+    for (int i = 0; i < cfg->N; ++i) {
+        const EncA& a = w.enc[i];
+        const std::string pre = "enc" + std::to_string(i) + ".";
+        F(pre, a, qkv); F(pre, a, probs); F(pre, a, ctx); F(pre, a, y1); F(pre, a, st1); F(pre, a, x1); F(pre, a, h); F(pre, a, y2); F(pre, a, st2);
+        F(pre, a, x2); F(pre, a, lnp1); F(pre, a, lnp2); F(pre, a, gA2); F(pre, a, gB2); F(pre, a, gh); F(pre, a, gx1); F(pre, a, gA1); F(pre, a, gB1);
+        F(pre, a, gctx); F(pre, a, gqkv); F(pre, a, gx0);
+    }
+    add("mem", w.mem); add("st_mem", w.st_mem); add("lnp_mem", w.lnp_mem);
+    for (int i = 0; i < cfg->N; ++i) {
+        const DecA& a = w.dec[i];
+        const std::string pre = "dec" + std::to_string(i) + ".";
+        F(pre, a, v); F(pre, a, y1); F(pre, a, st1); F(pre, a, t1); F(pre, a, q); F(pre, a, kv); F(pre, a, xprobs); F(pre, a, xctx); F(pre, a, y2);
+        F(pre, a, st2); F(pre, a, t2); F(pre, a, h); F(pre, a, y3); F(pre, a, st3); F(pre, a, t3); F(pre, a, lnp1); F(pre, a, lnp2); F(pre, a, lnp3);
+        F(pre, a, gA3); F(pre, a, gB3); F(pre, a, gh); F(pre, a, gt2); F(pre, a, gA2); F(pre, a, gB2); F(pre, a, gxctx); F(pre, a, gq); F(pre, a, gkv);
+        F(pre, a, gt1); F(pre, a, gA1); F(pre, a, gB1); F(pre, a, gv); F(pre, a, gt0);
+    }
+#undef F
+    add("tfin", w.tfin); add("st_fin", w.st_fin); add("lnp_fin", w.lnp_fin); add("logits", w.logits); add("dlogits", w.dlogits);
+    add("logp", w.logp); add("row_nll", w.row_nll); add("gfin", w.gfin); add("gtl", w.gtl); add("gmem", w.gmem); add("gxl", w.gxl);
+    add("emb_scratch_src", w.emb_scratch_src); add("emb_scratch_tgt", w.emb_scratch_tgt); add("emb_keep", w.emb_keep);
+    add("opt_partials", w.opt_partials); add("ln_table", w.ln_table); add("wp.hi", w.wp.hi); add("wp.lo", w.wp.lo);
+    add("planes_begin", w.planes_begin); add("gscr0", w.gscr[0]); add("gscr1", w.gscr[1]); add("planes_end", w.planes_end);
+    add("end", (const char*)nullptr + w.bytes);
+    SLNLP_CHECK_ARG((int64_t)s.size() + 1 <= out_bytes, "tf_debug_layout: needs %zu bytes", s.size() + 1);
+    memcpy(out, s.c_str(), s.size() + 1);
     return 0;
 }
 

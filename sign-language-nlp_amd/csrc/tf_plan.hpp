@@ -329,8 +329,19 @@ struct slnlp_tf_plan {
     int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
 
     // side[k] may start once everything enqueued on `main` so far has finished
+    // side_mode: which phases may fork work to the side streams: 0 = none -- every launch on the caller's stream (default),
+    // 1 = forward only, 2 = forward and backward (env SLNLP_TF_SIDE_STREAMS at plan creation; experiments only).
+    // Round 2 measurements at cfg2 (tools/debug_race2.py): the serial step is as fast as the forked one (3.23 vs 3.21 ms;
+    // forward-only forks 3.35 ms) and it is the only fully deterministic one: with the backward forks 7 of 16 identical
+    // steps differed from the single-stream result (first wrong value: one row of decoder layer l's norm1 LayerNorm
+    // backward while the d-memory / K|V weight-gradient group of that layer ran on side[0]; gone under
+    // AMD_SERIALIZE_KERNEL=3, never seen at cfg1).  Its mechanism was not isolated -- the forks are off.
+    int side_mode = 0;
+    bool in_backward = false;
+    bool forks_on() const { return !recording() && side_mode > (in_backward ? 1 : 0); }
+    hipStream_t side_or(hipStream_t main, int k) const { return forks_on() ? side[k] : main; }
     int fork(hipStream_t main, int k) {
-        if (recording()) return 0;     // a recorded program is one serial launch list in program order
+        if (!forks_on()) return 0;     // serial: a recorded program is one launch list in program order
         if (hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side[k], ev_fork, 0) != hipSuccess) {
             set_error("tf: fork to side stream failed: %s", hipGetErrorString(hipGetLastError()));
             return SLNLP_ERR_LAUNCH;
@@ -340,7 +351,7 @@ struct slnlp_tf_plan {
     }
     // `main` waits for everything enqueued on side[k]
     int join(hipStream_t main, int k) {
-        if (recording() || !side_dirty[k]) return 0;
+        if (recording() || !side_dirty[k]) return 0;   // (a disabled fork never marked the side stream dirty)
         if (hipEventRecord(ev_join[k], side[k]) != hipSuccess || hipStreamWaitEvent(main, ev_join[k], 0) != hipSuccess) {
             set_error("tf: join of side stream failed: %s", hipGetErrorString(hipGetLastError()));
             return SLNLP_ERR_LAUNCH;
