@@ -123,41 +123,50 @@ def dominant_kernel_roofline(c, precision, dev, workload):
                     "MFMA passes are not counted; bytes = operand planes (hi+lo) read once + fp32 results + result planes"}
 
 
-def concurrent_fits(c, precision, dev, k=4, steps=40):
-    """Aggregate seq/s of k independent fits sharing this GPU (one engine, one stream, one batch sequence each; plain
-    launches issued round-robin from this host thread) -- how ShardedGridSearchCV(fits_per_gpu=k) runs a rank's
-    share of the grid.  A single batch-50 fit leaves most CUs idle during its decoder phases."""
+def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
+    """Aggregate train seq/s of K independent fits of this workload sharing the GPU by advancing in LOCKSTEP through one
+    launch sequence (slnlp/lockstep.py: own weights, lr, seed and data per fit; bit-identical to solo fits) -- how
+    ShardedGridSearchCV(lockstep=k) runs a work unit.  A single batch-50 fit leaves most CUs idle in its decoder stages."""
     from slnlp import synth, tf_engine as te
+    from slnlp.lockstep import LockstepGroup
     B, S = c["B"], c["S"]
-    engs, streams, data = [], [], []
-    for i in range(k):
-        cfg, sd = build_sd(c, seed=101 + i)
-        e = te.TransformerEngine(cfg, device=dev, seed=101 + i)
-        e.load_state(sd)
-        e.set_lr(LR)
-        Xn, Ln, yn = synth.make_batch(20 * B, S, c["Vs"], c["Vt"], seed=101 + i)
-        engs.append(e)
-        streams.append(torch.cuda.Stream(device=dev))
-        data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev)))
+    rows = steps * B
+    out = []
+    st = torch.cuda.Stream(device=dev)
+    for k in ks:
+        engs, data = [], []
+        for i in range(k):
+            cfg, sd = build_sd(c, seed=101 + i)
+            e = te.TransformerEngine(cfg, device=dev, seed=101 + i)
+            e.load_state(sd)
+            e.set_lr(LR)
+            Xn, _, yn = synth.make_batch(rows, S, c["Vs"], c["Vt"], seed=101 + i)
+            engs.append(e)
+            data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev)))
+        with torch.cuda.stream(st):
+            grp = LockstepGroup(engs)
+            grp.set_data(0, [d[0] for d in data], [d[1] for d in data], B)
+            grp.epoch(0, B, True, MOMENTUM, MAX_NORM)          # records the launch program
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            grp.epoch(0, B, True, MOMENTUM, MAX_NORM)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            n = grp.num_launches(0, B, True)
+            grp.close()
+        out.append({"fits": k, "value": round(k * rows / dt, 1), "unit": "seq/s (aggregate)", "ms_per_lockstep_step": round(dt / steps * 1e3, 3),
+                    "launches_per_step": n})
+        del engs, data, grp
+        torch.cuda.empty_cache()
+    return {"mode": "lockstep (one launch sequence for all fits)", "runs": out,
+            "note": f"{steps} steps per fit, every fit its own weights / data; the step's kernels carry a fit index (grid.z) or a merged job table"}
 
-    def run(n):
-        for it in range(n):
-            j = (it % 20) * B
-            for e, st, (X, y) in zip(engs, streams, data):
-                with torch.cuda.stream(st):
-                    e.train_step(X[j:j + B], y[j:j + B], MOMENTUM, MAX_NORM)
-    run(5)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    return {"fits": k, "value": round(k * steps * B / dt, 1), "unit": "seq/s (aggregate)",
-            "ms_per_round": round(dt / steps * 1e3, 3), "note": f"{k} independent fits, {steps} steps each, one stream per fit"}
 
-
-GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__embedding_size": [512, 128],
-               "module__num_layers": [4, 2]}                 # 24 of config-transformer.yaml's 324 candidates (F 256, H 4)
+# 24 of config-transformer.yaml's 324 candidates: every lr and dropout at embedding_size 512, num_layers 2, two
+# hidden sizes and both head counts -> 4 shapes x 30 (candidate, fold) fits.  With lockstep 5 that is 24 work units of
+# nearly equal cost: a multiple of 8, so the strong-scaling leg divides evenly over 1 / 2 / 4 / 8 GPUs.
+GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__hidden_size": [512, 256], "module__num_heads": [8, 4]}
+GRID_FIXED = {"module__embedding_size": 512, "module__num_layers": 2}
 GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 8, 2000
 
 
@@ -165,17 +174,18 @@ def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
     from slnlp.net import NeuralNetClassifier
     return lambda: NeuralNetClassifier(
         module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
-        module__embedding_size=128, module__num_heads=4, module__num_layers=2, module__hidden_size=256, module__dropout=0.1,
-        criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=max_epochs, batch_size=50,
+        module__embedding_size=GRID_FIXED["module__embedding_size"], module__num_heads=4, module__num_layers=GRID_FIXED["module__num_layers"],
+        module__hidden_size=256, module__dropout=0.1, criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=max_epochs, batch_size=50,
         device=str(dev), gradient_clipping={"gradient_clip_value": 0.5},
         scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
 
 
-def grid_folds_per_hour(dev, world, rank, fits_per_gpu=4, lockstep=1):
+def grid_folds_per_hour(dev, world, rank, fits_per_gpu=1, lockstep=5):
     """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
     on a bounded sample of config-transformer.yaml's grid -- 24 candidates x cv 5 = 120 fits of 8 epochs over 2000
     synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
-    ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling)."""
+    ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling).  Work unit =
+    `lockstep` shape-compatible fits advancing through one launch sequence."""
     import warnings
     from slnlp.data import synthetic_dataset
     from slnlp.grid import ShardedGridSearchCV
@@ -183,8 +193,8 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=4, lockstep=1):
     warnings.filterwarnings("ignore", message="The least populated class")    # 2000 samples over 200 labels
     ds = synthetic_dataset(GRID_SAMPLES, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8)
     # untimed warm-up on every rank (code objects, allocator pools, plan creation paths): one tiny fit per shape
-    warm = ShardedGridSearchCV(grid_factory(ds.truncated(200), dev, 1), {"module__embedding_size": [512, 128], "module__num_layers": [4, 2]},
-                               cv=2, refit=False, device=str(dev), fits_per_gpu=1, schedule="static", lockstep=lockstep)
+    warm = ShardedGridSearchCV(grid_factory(ds.truncated(200), dev, 1), {k: GRID_SAMPLE[k] for k in ("module__hidden_size", "module__num_heads")},
+                               cv=2, refit=False, device=str(dev), fits_per_gpu=1, schedule="static", lockstep=min(lockstep, 2))
     warm_t0 = time.perf_counter()
     _fit_local(warm, ds.truncated(200))       # every rank warms up on the whole warm-up grid, not on a shard of it
     warm_s = time.perf_counter() - warm_t0
@@ -196,11 +206,11 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=4, lockstep=1):
                              fits_per_gpu=fits_per_gpu, lockstep=lockstep).fit(ds if rank == 0 else None)
     dt = time.perf_counter() - t0
     return {"value": round(gs.n_tasks_ / dt * 3600.0, 0), "unit": "folds/hr", "fits": gs.n_tasks_, "seconds": round(dt, 2),
-            "fits_per_gpu": fits_per_gpu, "lockstep": lockstep, "ranks": world, "schedule": gs.schedule,
+            "fits_per_gpu": fits_per_gpu, "lockstep": lockstep, "work_units": gs.n_units_, "ranks": world, "schedule": gs.schedule,
             "rank_seconds": [round(v, 2) for v in gs.rank_seconds_], "rank_fits": gs.rank_tasks_, "warmup_seconds": round(warm_s, 2),
             "best_index": gs.best_index_, "best_score": round(gs.best_score_, 5),
-            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x embedding_size x num_layers of config-transformer.yaml; "
-                      f"F 256, H 4) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
+            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x hidden_size x num_heads of config-transformer.yaml at "
+                      f"embedding_size 512, num_layers 2) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
                       "the reference's 5 epoch metrics on both; includes the dataset broadcast and the score all_gather"}
 
 
@@ -328,8 +338,8 @@ def main():
     ap.add_argument("--precision", type=int, default=3, choices=[1, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true", help="skip the folds/hr leg")
-    ap.add_argument("--fits-per-gpu", type=int, default=4, help="concurrent fits per GPU in the grid leg")
-    ap.add_argument("--lockstep", type=int, default=1, help="fits advanced through one launch sequence in the grid leg")
+    ap.add_argument("--fits-per-gpu", type=int, default=1, help="host threads per GPU in the grid leg (each runs work units)")
+    ap.add_argument("--lockstep", type=int, default=5, help="fits per work unit, advanced through one launch sequence, in the grid leg")
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")
     ap.add_argument("--eager", action="store_true", help="same as --launch eager")

@@ -337,6 +337,11 @@ int slnlp_tf_seed_dlogp(slnlp_tf_plan* plan, const float* dlogp, void* stream);
 int slnlp_tf_backward(slnlp_tf_plan* plan, void* stream);
 /* clip + SGD-momentum on the arena; scalars[1] = pre-clip grad norm */
 int slnlp_tf_optim(slnlp_tf_plan* plan, float momentum, float max_norm, void* stream);
+/* clip + torch.optim.Adam (amsgrad False) on the arena -- north_star's "fused SGD-momentum/Adam update"; the reference
+ * reaches any torch.optim class through pydoc.locate (helper.py:91-104).  exp_avg = buf.momentum, exp_avg_sq = an
+ * arena-shaped buffer of the caller's (zero before the first step), step count = scalars[2] (device-side). */
+int slnlp_tf_optim_adam(slnlp_tf_plan* plan, float* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay,
+                        float max_norm, void* stream);
 /* forward(train) + loss + backward + optim in one call */
 int slnlp_tf_train_step(slnlp_tf_plan* plan, const int64_t* X, const int64_t* y, int B,
                         float momentum, float max_norm, float* logp, void* stream);
@@ -351,6 +356,9 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* plan, int B, void* stream);
 /* test helper: copy a named activation tap ("enc0", "memory", "dec1", "logits", ...) */
 int slnlp_tf_tap(slnlp_tf_plan* plan, const char* name, float* out, int64_t max_floats,
                  int64_t* n_out, void* stream);
+/* The parameter arena was written from outside the library (load_state_dict, a torch optimizer, an in-place edit):
+ * data derived from it (the bf16 weight planes the fused update keeps current) is rebuilt by the next forward. */
+int slnlp_tf_params_changed(slnlp_tf_plan* plan);
 /* test / debug helper: "name byte_offset" lines of the workspace's activation and gradient buffers, in layout order */
 int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_bytes);
 

@@ -194,5 +194,13 @@ int add_rows(const float* in, int64_t ld_in, float* out, int64_t ld_out, int R, 
 int tanh_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t st);
 int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                   float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
-                  hipStream_t st);
+                  hipStream_t st, PlaneOut wp = {});
+int clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                   float beta1, float beta2, float eps, float weight_decay, float max_norm, float* partials, float* norm_out,
+                   unsigned long long* rng, float* step_f, hipStream_t st, PlaneOut wp = {});
+// Which version of a parameter arena a plan's derived data (bf16 weight planes) was made from: every optimizer step and
+// every slnlp_*_params_changed() call moves the arena to a new generation (process-wide table keyed by the arena pointer,
+// because several plans -- one per sequence length -- may share one arena).
+unsigned long long params_generation(const float* params);
+unsigned long long bump_params_generation(const float* params);
 }  // namespace slnlp

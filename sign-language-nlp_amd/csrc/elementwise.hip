@@ -611,7 +611,10 @@ SLNLP_ZKERNEL(sumsq_kernel, 256, sumsq_body)
 __device__ __forceinline__ void sgd_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   long n4, const float* __restrict__ lr_dev, float momentum,
                                                   float max_norm, const float* __restrict__ partials,
-                                                  float* __restrict__ norm_out, unsigned long long* __restrict__ rng) {
+                                                  float* __restrict__ norm_out, unsigned long long* __restrict__ rng,
+                                                  PlaneOut wp) {
+    // wp (optional): the updated weights also leave as bf16 hi / lo planes (same offsets as the arena) -- the operand
+    // form the plane GEMMs of the NEXT step stage by LDS-DMA -- instead of a separate pass that re-reads the arena
     __shared__ float red[4];
     // every block re-derives the total in the same fixed order: deterministic, no third launch
     float s = 0.f;
@@ -632,6 +635,7 @@ __device__ __forceinline__ void sgd_body(float* __restrict__ p, const float* __r
         w.x -= lr * b.x; w.y -= lr * b.y; w.z -= lr * b.z; w.w -= lr * b.w;
         reinterpret_cast<float4*>(buf)[i] = b;
         reinterpret_cast<float4*>(p)[i] = w;
+        store_planes4(wp, i * 4, w);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (norm_out) norm_out[0] = norm;
@@ -642,7 +646,7 @@ SLNLP_ZKERNEL(sgd_kernel, 256, sgd_body)
 
 int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                   float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
-                  hipStream_t st) {
+                  hipStream_t st, PlaneOut wp) {
     SLNLP_CHECK_ARG(params && grads && momentum_buf && lr_dev && partials, "clip_sgd_step: null pointer");
     SLNLP_CHECK_ARG(n > 0 && n % 4 == 0, "clip_sgd_step: n=%ld must be a positive multiple of 4", (long)n);
     SLNLP_CHECK_ARG(((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0 && ((uintptr_t)momentum_buf & 15) == 0,
@@ -652,7 +656,76 @@ int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_
     int grid = ceil_div(n / 4, 256);
     if (grid > 2048) grid = 2048;
     SLNLP_TRY(zlaunch(sgd_kernel, dim3(grid), 256, 0, st, "sgd",
-                      params, grads, momentum_buf, (long)(n / 4), lr_dev, momentum, max_norm, partials, norm_out, rng));
+                      params, grads, momentum_buf, (long)(n / 4), lr_dev, momentum, max_norm, partials, norm_out, rng, wp));
+    return 0;
+}
+
+// torch.optim.Adam (amsgrad False, maximize False) fused with clip_grad_norm_, same two-launch shape as clip + SGD:
+//   g' = g * clip_coef (+ weight_decay * p);  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)            (torch/optim/adam.py _single_tensor_adam)
+// The step count t lives in device memory (step_f[0], a float: exact to 2^24 steps) and is advanced here, so a captured
+// or recorded step needs no host-side argument that changes per step.
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                          float* __restrict__ v, long n4, const float* __restrict__ lr_dev, float beta1,
+                                          float beta2, float eps, float weight_decay, float max_norm,
+                                          const float* __restrict__ partials, float* __restrict__ norm_out,
+                                          unsigned long long* __restrict__ rng, float* __restrict__ step_f, PlaneOut wp) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < OPT_BLOCKS; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    const float lr = lr_dev[0];
+    const float t = step_f[0] + 1.f;                       // every block reads the OLD count (adam_count_kernel advances it afterwards)
+    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+    const float step_size = lr / bc1, rsq_bc2 = 1.f / sqrtf(bc2);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i], w = reinterpret_cast<float4*>(p)[i];
+        float ge[4] = {gv.x * coef, gv.y * coef, gv.z * coef, gv.w * coef};
+        float me[4] = {mm.x, mm.y, mm.z, mm.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w}, we[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (weight_decay != 0.f) ge[e] += weight_decay * we[e];
+            me[e] += (1.f - beta1) * (ge[e] - me[e]);
+            ve[e] = beta2 * ve[e] + (1.f - beta2) * ge[e] * ge[e];
+            we[e] -= step_size * (me[e] / (sqrtf(ve[e]) * rsq_bc2 + eps));
+        }
+        reinterpret_cast<float4*>(m)[i] = make_float4(me[0], me[1], me[2], me[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+        const float4 wn = make_float4(we[0], we[1], we[2], we[3]);
+        reinterpret_cast<float4*>(p)[i] = wn;
+        store_planes4(wp, i * 4, wn);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (norm_out) norm_out[0] = norm;
+        if (rng) rng[1] += 1ull;
+    }
+}
+SLNLP_ZKERNEL(adam_kernel, 256, adam_body)
+
+// the count is advanced by its own one-thread launch AFTER the update (every block of adam_kernel must read the same old value)
+__device__ __forceinline__ void adam_count_body(float* __restrict__ step_f) { if (threadIdx.x == 0 && blockIdx.x == 0) step_f[0] += 1.f; }
+SLNLP_ZKERNEL(adam_count_kernel, 64, adam_count_body)
+
+int clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                   float beta1, float beta2, float eps, float weight_decay, float max_norm, float* partials, float* norm_out,
+                   unsigned long long* rng, float* step_f, hipStream_t st, PlaneOut wp) {
+    SLNLP_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && lr_dev && partials && step_f, "clip_adam_step: null pointer");
+    SLNLP_CHECK_ARG(n > 0 && n % 4 == 0, "clip_adam_step: n=%ld must be a positive multiple of 4", (long)n);
+    SLNLP_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                    "clip_adam_step: arenas must be 16-byte aligned");
+    SLNLP_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "clip_adam_step: bad betas / eps");
+    SLNLP_TRY(zlaunch(sumsq_kernel, dim3(OPT_BLOCKS), 256, 0, st, "sumsq", grads, (long)(n / 4), partials));
+    int grid = ceil_div(n / 4, 256);
+    if (grid > 2048) grid = 2048;
+    SLNLP_TRY(zlaunch(adam_kernel, dim3(grid), 256, 0, st, "adam", params, grads, exp_avg, exp_avg_sq, (long)(n / 4), lr_dev, beta1, beta2,
+                      eps, weight_decay, max_norm, partials, norm_out, rng, step_f, wp));
+    SLNLP_TRY(zlaunch(adam_count_kernel, dim3(1), 64, 0, st, "adam_count", step_f));
     return 0;
 }
 

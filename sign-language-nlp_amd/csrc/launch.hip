@@ -1,7 +1,23 @@
 // launch.hip -- the thread-local launch recorder behind zlaunch() and a recordable zero-fill (see launch.hpp).
+#include <mutex>
+#include <unordered_map>
+
 #include "launch.hpp"
 
 namespace slnlp {
+
+static std::mutex gen_mutex;
+static std::unordered_map<const float*, unsigned long long> gen_table;
+
+unsigned long long params_generation(const float* params) {
+    std::lock_guard<std::mutex> lk(gen_mutex);
+    auto it = gen_table.find(params);
+    return it == gen_table.end() ? 0ull : it->second;
+}
+unsigned long long bump_params_generation(const float* params) {
+    std::lock_guard<std::mutex> lk(gen_mutex);
+    return ++gen_table[params];
+}
 
 static thread_local Recorder* tl_recorder = nullptr;
 

@@ -275,7 +275,10 @@ int slnlp_tf_lockstep_step(slnlp_tf_lockstep* ls, int slot, int64_t row0, int B,
     SLNLP_CHECK_ARG(B > 0 && B <= ls->maxB && row0 >= 0 && row0 + B <= s.rows, "lockstep_step: rows [%ld, %ld) outside 0..%ld or batch > %d",
                     (long)row0, (long)(row0 + B), (long)s.rows, ls->maxB);
     hipStream_t st = (hipStream_t)stream;
-    for (slnlp_tf_plan* pl : ls->plans) SLNLP_TRY(pl->prepare_planes(B, st));      // re-zero plane padding when B changes
+    for (slnlp_tf_plan* pl : ls->plans) {
+        SLNLP_TRY(pl->prepare_planes(B, st));      // re-zero plane padding when B changes
+        SLNLP_TRY(pl->ensure_wplanes(st));         // never part of a recorded program: the update kernel keeps the planes current
+    }
     const auto key = std::make_tuple(slot, B, train ? 1 : 0);
     auto it = ls->programs.find(key);
     if (it == ls->programs.end()) {
@@ -304,7 +307,10 @@ int slnlp_tf_lockstep_step(slnlp_tf_lockstep* ls, int slot, int64_t row0, int B,
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(ls_gather_kernel, dim3(gx, 1, ls->K), dim3(256), 0, st, g);
     SLNLP_CHECK_LAUNCH("lockstep gather");
-    return replay(it->second, st);
+    SLNLP_TRY(replay(it->second, st));
+    if (train)
+        for (slnlp_tf_plan* pl : ls->plans) pl->params_stepped();
+    return 0;
 }
 
 // One pass over slot `slot` in dataset order, batches of `batch` rows (the last one may be shorter).

@@ -164,9 +164,9 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, f1));
     SLNLP_TRY(dec_self_block(0, w.t0, B, p, f1));
     const bool up = use_planes;
-    if (up) {   // weights as bf16 planes, once per forward (they changed in the optimizer step / load_state_dict)
+    if (up) {   // weights as bf16 planes: current unless the arena changed outside the fused optimizer step
         SLNLP_TRY(prepare_planes(B, st));
-        SLNLP_TRY(split_planes(pl->buf.params, L.total, 1, (int)L.total, w.wp.hi, w.wp.lo, L.total, st));
+        SLNLP_TRY(ensure_wplanes(st));
     }
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st,
                         up ? w.x0p.out() : PlaneOut{}, w.emb_keep));
@@ -397,8 +397,31 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
 
 int slnlp_tf_optim(slnlp_tf_plan* pl, float momentum, float max_norm, void* stream) {
     SLNLP_CHECK_ARG(pl, "tf_optim: null plan");
-    return clip_sgd_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, pl->L.total, pl->buf.lr, momentum, max_norm,
-                         pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, (hipStream_t)stream);
+    SLNLP_TRY(clip_sgd_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, pl->L.total, pl->buf.lr, momentum, max_norm,
+                            pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, (hipStream_t)stream,
+                            pl->use_planes ? pl->w.wp.out() : PlaneOut{}));
+    if (!recording()) pl->params_stepped();      // (a lockstep replay does this per step itself)
+    return 0;
+}
+
+// clip_grad_norm_ + torch.optim.Adam on the arena: exp_avg = buf.momentum, exp_avg_sq = the caller's arena-shaped
+// buffer, step count = scalars[2] (advanced on the device).
+int slnlp_tf_optim_adam(slnlp_tf_plan* pl, float* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay,
+                        float max_norm, void* stream) {
+    SLNLP_CHECK_ARG(pl && exp_avg_sq, "tf_optim_adam: null argument");
+    SLNLP_TRY(clip_adam_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, exp_avg_sq, pl->L.total, pl->buf.lr, beta1, beta2, eps,
+                             weight_decay, max_norm, pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, pl->buf.scalars + 2,
+                             (hipStream_t)stream, pl->use_planes ? pl->w.wp.out() : PlaneOut{}));
+    if (!recording()) pl->params_stepped();
+    return 0;
+}
+
+// The parameter arena was written from outside the library (load_state_dict, a torch optimizer, an in-place edit):
+// derived data is stale.  The Python engines call this when the arena tensor's version counter has moved.
+int slnlp_tf_params_changed(slnlp_tf_plan* pl) {
+    SLNLP_CHECK_ARG(pl, "tf_params_changed: null plan");
+    bump_params_generation(pl->buf.params);
+    return 0;
 }
 
 int slnlp_tf_train_step(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, float momentum, float max_norm,
@@ -427,6 +450,7 @@ int slnlp_tf_graph_capture_train(slnlp_tf_plan* pl, const int64_t* X, const int6
         set_error("tf_graph_capture_train: begin capture failed: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
+    pl->wplanes_gen = 0;      // the captured step always re-splits the weights: a replay cannot check the arena's generation
     int rc = slnlp_tf_train_step(pl, X, y, B, momentum, max_norm, logp, stream);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(st, &g);
@@ -458,6 +482,7 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* pl, int B, void* stream) {
         set_error("tf_graph_launch: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
+    pl->params_stepped();
     return 0;
 }
 

@@ -320,6 +320,22 @@ struct slnlp_tf_plan {
     float* ls_logp = nullptr;       // [rows of the epoch, Vt]
     float* ls_loss = nullptr;       // [batches of the epoch]
     const int* ls_dyn = nullptr;    // {first row of the batch, index of the batch}
+    unsigned long long wplanes_gen = 0;   // generation of the parameter arena the weight planes were made from (0: never)
+    // weights as bf16 planes: made by the optimizer kernel of the previous step, or here when the arena has changed since
+    int ensure_wplanes(hipStream_t st) {
+        if (!use_planes) return 0;
+        unsigned long long g = params_generation(buf.params);
+        if (g != 0 && g == wplanes_gen) return 0;
+        SLNLP_TRY(split_planes(buf.params, L.total, 1, (int)L.total, w.wp.hi, w.wp.lo, L.total, st));
+        if (g == 0) g = bump_params_generation(buf.params);
+        wplanes_gen = g;
+        return 0;
+    }
+    // the optimizer just rewrote the arena (and, with planes, the planes with it)
+    void params_stepped() {
+        const unsigned long long g = bump_params_generation(buf.params);
+        if (use_planes) wplanes_gen = g;
+    }
     bool use_planes = false;   // E, F multiples of 64: M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
     int planes_B = -1;         // batch size the activation planes' zero padding is valid for
 

@@ -68,8 +68,16 @@ class ArenaModule(nn.Module):
             n = self._arena.numel()
             st = self._opt_state = {
                 "grads": torch.zeros(n, dtype=torch.float32, device=dev), "momentum": torch.zeros(n, dtype=torch.float32, device=dev),
-                "rng": torch.tensor([self.seed, 0], dtype=torch.int64, device=dev), "lr": torch.zeros(1, dtype=torch.float32, device=dev)}
+                "rng": torch.tensor([self.seed, 0], dtype=torch.int64, device=dev), "lr": torch.zeros(1, dtype=torch.float32, device=dev),
+                "scalars": torch.zeros(4, dtype=torch.float32, device=dev)}
         return st
+
+    def adam_second_moment(self):
+        """Arena-shaped exp_avg_sq buffer of the fused Adam update (allocated on first use)."""
+        st = self._shared_state()
+        if "exp_avg_sq" not in st:
+            st["exp_avg_sq"] = torch.zeros_like(st["momentum"])
+        return st["exp_avg_sq"]
 
     def _state_order(self, views):
         raise NotImplementedError

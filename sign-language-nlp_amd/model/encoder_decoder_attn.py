@@ -94,7 +94,7 @@ class EncoderDecoderAttnBase(ArenaModule):
         from slnlp import rnn_engine as re_
         cfg = re_.make_config(B=B, S=S, **self._cfg_args)
         eng = re_.RnnEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
-                            grads=shared["grads"], momentum=shared["momentum"], rng=shared["rng"], lr=shared["lr"])
+                            grads=shared["grads"], momentum=shared["momentum"], rng=shared["rng"], lr=shared["lr"], scalars=shared["scalars"])
         if getattr(self, "persistent_kernels", False):        # opt-in (never when several fits share the GPU)
             eng.set_persistent(True)
         return eng

@@ -93,7 +93,7 @@ class Transformer(ArenaModule):
         from slnlp import tf_engine as te
         cfg = te.make_config(B=B, S=S, **self._cfg_args)
         return te.TransformerEngine(cfg, device=self._arena.device, seed=self.seed, params=self._arena,
-                                    grads=shared["grads"], momentum=shared["momentum"], rng=shared["rng"], lr=shared["lr"],
+                                    grads=shared["grads"], momentum=shared["momentum"], rng=shared["rng"], lr=shared["lr"], scalars=shared["scalars"],
                                     pe=self._pe.view(-1, self.embedding_size))
 
     def forward(self, X, y, lengths=None, **kwargs):

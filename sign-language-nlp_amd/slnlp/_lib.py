@@ -131,6 +131,8 @@ SIGNATURES = {
     "slnlp_tf_graph_capture_train": (i32, [vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_tf_graph_launch": (i32, [vp, i32, vp]),
     "slnlp_tf_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
+    "slnlp_tf_params_changed": (i32, [vp]),
+    "slnlp_tf_optim_adam": (i32, [vp, vp, f32, f32, f32, f32, f32, vp]),
     "slnlp_tf_debug_layout": (i32, [vp, C.c_char_p, i64]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),
     "slnlp_tf_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),

@@ -66,11 +66,15 @@ class LockstepGroup:
               "tf_lockstep_set_data")
 
     def step(self, slot, row0, B, step_index, train, momentum=0.9, max_norm=0.5):
+        for e in self.engines:
+            e.sync_params_version()
         check(load().slnlp_tf_lockstep_step(self.handle, slot, row0, B, step_index, int(train), momentum, max_norm, stream_ptr()),
               "tf_lockstep_step")
 
     def epoch(self, slot, batch, train, momentum=0.9, max_norm=0.5):
         """One pass over the slot in dataset order; no host synchronisation.  Results: ``logp[slot]``, ``loss[slot]``."""
+        for e in self.engines:
+            e.sync_params_version()
         check(load().slnlp_tf_lockstep_epoch(self.handle, slot, batch, int(train), momentum, max_norm, stream_ptr()),
               "tf_lockstep_epoch")
 
@@ -90,7 +94,7 @@ class LockstepGroup:
 
 def lockstep_supported(net):
     """Fused SGD + CrossEntropyLoss on a Transformer module: what the lockstep launch sequence implements."""
-    return bool(getattr(net, "_fused", False)) and type(net.module_).__name__ == "Transformer"
+    return getattr(net, "_fused_kind", None) == "sgd" and type(net.module_).__name__ == "Transformer"
 
 
 def fit_lockstep(nets, datasets):

@@ -272,9 +272,15 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         self.criterion_ = _resolve(self.criterion)(**self._sub("criterion"))
         self._opt_cls = _resolve(self.optimizer)
         ok = self._opt_kwargs = self._sub("optimizer")
-        self._fused = (self._opt_cls is torch.optim.SGD and isinstance(self.criterion_, torch.nn.CrossEntropyLoss)
-                       and not ok.get("nesterov", False) and not ok.get("weight_decay", 0) and not ok.get("dampening", 0)
-                       and hasattr(self.module_, "engine"))
+        ce = isinstance(self.criterion_, torch.nn.CrossEntropyLoss) and hasattr(self.module_, "engine")
+        self._fused_kind = None                   # which fused clip + update kernel replaces the torch optimizer
+        if ce and self._opt_cls is torch.optim.SGD and not ok.get("nesterov", False) and not ok.get("weight_decay", 0) \
+                and not ok.get("dampening", 0) and not ok.get("maximize", False):
+            self._fused_kind = "sgd"
+        elif ce and self._opt_cls is torch.optim.Adam and not ok.get("amsgrad", False) and not ok.get("maximize", False) \
+                and type(self.module_).__name__ == "Transformer":
+            self._fused_kind = "adam"
+        self._fused = self._fused_kind is not None
         if not self._fused:
             self.optimizer_ = self._opt_cls(self.module_.parameters(), lr=self.lr, **ok)
         self.lr_ = float(self.lr)
@@ -349,7 +355,12 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             if train and self._fused:
                 eng = self.module_.engine(xb.shape[0], xb.shape[1])
                 eng.set_lr(self.lr_)
-                logp = eng.step(xb, yb, lb, momentum, max_norm, graph=self.use_graph if self.use_graph == "auto" else bool(self.use_graph))
+                if self._fused_kind == "adam":
+                    ok = self._opt_kwargs
+                    logp = eng.train_step_adam(xb, yb, self.module_.adam_second_moment(), tuple(ok.get("betas", (0.9, 0.999))),
+                                               float(ok.get("eps", 1e-8)), float(ok.get("weight_decay", 0.0)), max_norm)
+                else:
+                    logp = eng.step(xb, yb, lb, momentum, max_norm, graph=self.use_graph if self.use_graph == "auto" else bool(self.use_graph))
                 losses.append(eng.scalars[0].clone())
             elif train:
                 self.optimizer_.zero_grad()
@@ -404,27 +415,43 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         in ``module.parameters()`` order, plus the param group with the current lr -- what skorch's Checkpoint writes as
         optimizer.pt (helper.py:211-213) and what ``torch.optim.SGD.load_state_dict`` reads back."""
         params = dict(self.module_.named_parameters())
-        opt = torch.optim.SGD([p for n, p in params.items()], lr=self.lr_, **self._opt_kwargs)
+        opt = self._opt_cls([p for n, p in params.items()], lr=self.lr_, **self._opt_kwargs)
         st = self.module_._shared_state()
         mom = st["momentum"]
+        adam = self._fused_kind == "adam"
+        step = None
+        if adam:
+            step = float(st["scalars"][2])
+            v2 = self.module_.adam_second_moment()
         for name, shape, off in self.module_._entries:
             if name in self.module_._dead_params:
                 continue                                   # never receives a gradient: torch keeps no state for it
             n = 1
             for d in shape:
                 n *= d
-            opt.state[params[name]]["momentum_buffer"] = mom[off:off + n].view(*shape).detach().cpu().clone()
+            view = lambda arena: arena[off:off + n].view(*shape).detach().cpu().clone()
+            if adam:
+                opt.state[params[name]].update(step=torch.tensor(step), exp_avg=view(mom), exp_avg_sq=view(v2))
+            else:
+                opt.state[params[name]]["momentum_buffer"] = view(mom)
         return opt.state_dict()
 
     def _load_sgd_state_dict(self, sd):
         names = [n for n, _ in self.module_.named_parameters()]
         ent = {n: (shape, off) for n, shape, off in self.module_._entries}
         st = self.module_._shared_state()
+        step = None
         for idx, state in sd.get("state", {}).items():
             shape, off = ent[names[int(idx)]]
-            buf = state.get("momentum_buffer")
+            buf = state.get("momentum_buffer", state.get("exp_avg"))
             if buf is not None:
                 st["momentum"][off:off + buf.numel()].copy_(buf.reshape(-1).to(st["momentum"].device, torch.float32))
+            if state.get("exp_avg_sq") is not None:
+                v2 = self.module_.adam_second_moment()
+                v2[off:off + buf.numel()].copy_(state["exp_avg_sq"].reshape(-1).to(v2.device, torch.float32))
+                step = float(state.get("step", 0.0))
+        if step is not None:                           # the device-side Adam step count (shared by every plan of the module)
+            st["scalars"][2] = step
         groups = sd.get("param_groups") or [{}]
         if "lr" in groups[0]:
             self._set_lr(groups[0]["lr"])

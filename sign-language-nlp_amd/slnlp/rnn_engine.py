@@ -32,7 +32,7 @@ def layout(cfg):
 
 
 class RnnEngine:
-    def __init__(self, cfg, device="cuda", seed=0, params=None, grads=None, momentum=None, rng=None, lr=None):
+    def __init__(self, cfg, device="cuda", seed=0, params=None, grads=None, momentum=None, rng=None, lr=None, scalars=None):
         _lib.require_gpu()
         self.cfg, self.device = cfg, torch.device(device)
         self.entries, self.arena_floats = layout(cfg)
@@ -46,7 +46,7 @@ class RnnEngine:
         # plans (one per sequence length) hands every plan the same two tensors
         self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev) if rng is None else rng
         self.lr = torch.zeros(1, dtype=torch.float32, device=dev) if lr is None else lr
-        self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(4, dtype=torch.float32, device=dev) if scalars is None else scalars   # {loss, grad norm, Adam step count, -}
         self.logp = torch.empty(cfg.B, cfg.Vt, dtype=torch.float32, device=dev)
         bufs = TfBuffers(ptr(self.params), ptr(self.grads), ptr(self.momentum), None, ptr(self.workspace),
                          ptr(self.rng), ptr(self.lr), ptr(self.scalars))

@@ -51,7 +51,7 @@ def layout(cfg):
 class TransformerEngine:
     """One plan = one (config, max batch) on one GPU / one stream."""
 
-    def __init__(self, cfg, device="cuda", seed=0, max_len=5000, params=None, grads=None, momentum=None, pe=None, rng=None, lr=None):
+    def __init__(self, cfg, device="cuda", seed=0, max_len=5000, params=None, grads=None, momentum=None, pe=None, rng=None, lr=None, scalars=None):
         """``params`` / ``grads`` / ``momentum`` / ``pe``: adopt arenas owned by the caller (the
         drop-in ``model.Transformer`` keeps its nn.Parameters as views of ``params``)."""
         _lib.require_gpu()
@@ -70,7 +70,7 @@ class TransformerEngine:
         # plans (one per sequence length) hands every plan the same two tensors
         self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev) if rng is None else rng
         self.lr = torch.zeros(1, dtype=torch.float32, device=dev) if lr is None else lr
-        self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(4, dtype=torch.float32, device=dev) if scalars is None else scalars   # {loss, grad norm, Adam step count, -}
         self.logp = torch.empty(cfg.B, cfg.Vt, dtype=torch.float32, device=dev)
         bufs = TfBuffers(ptr(self.params), ptr(self.grads), ptr(self.momentum), ptr(self.pe), ptr(self.workspace),
                          ptr(self.rng), ptr(self.lr), ptr(self.scalars))
@@ -80,6 +80,16 @@ class TransformerEngine:
         self._graph_keys = {}
         self._launch = LaunchPolicy()
         self._xbuf = self._ybuf = None
+        self._pv = None
+
+    def sync_params_version(self):
+        """The fused update keeps the bf16 weight planes current; a write to the arena from the torch side (load_state_dict,
+        a torch optimizer, an in-place edit -- all of which move the tensor's version counter, which kernel launches through
+        raw pointers do not) makes them stale: tell the plan before the next launch."""
+        v = self.params._version
+        if v != self._pv:
+            check(load().slnlp_tf_params_changed(self.handle), "tf_params_changed")
+            self._pv = v
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -114,6 +124,7 @@ class TransformerEngine:
     def forward(self, X, y, train=False):
         """X int64 [B,S], y int64 [B] on the device -> log-probs [B,Vt] (a view
         of the engine's output buffer, valid until the next call)."""
+        self.sync_params_version()
         B = X.shape[0]
         X = X.contiguous()
         y = y.contiguous()
@@ -131,9 +142,22 @@ class TransformerEngine:
     def optim(self, momentum=0.9, max_norm=0.5):
         check(load().slnlp_tf_optim(self.handle, momentum, max_norm, stream_ptr()), "tf_optim")
 
+    def optim_adam(self, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
+        """clip_grad_norm_ + torch.optim.Adam fused (exp_avg = the momentum arena, exp_avg_sq = ``exp_avg_sq``, step count in
+        ``scalars[2]``)."""
+        check(load().slnlp_tf_optim_adam(self.handle, ptr(exp_avg_sq), betas[0], betas[1], eps, weight_decay, max_norm, stream_ptr()),
+              "tf_optim_adam")
+
+    def train_step_adam(self, X, y, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
+        logp = self.forward(X, y, train=True)
+        self.backward()
+        self.optim_adam(exp_avg_sq, betas, eps, weight_decay, max_norm)
+        return logp
+
     def train_step(self, X, y, momentum=0.9, max_norm=0.5):
         """Eager fwd + criterion + bwd + clip + SGD; returns log-probs view.
         loss / grad-norm stay on the device in ``scalars[0:2]``."""
+        self.sync_params_version()
         B = X.shape[0]
         X = X.contiguous()
         y = y.contiguous()
@@ -145,6 +169,7 @@ class TransformerEngine:
     def train_step_graph(self, X, y, momentum=0.9, max_norm=0.5):
         """Same step replayed from a captured hipGraph (one per batch size):
         the batch is copied into fixed staging buffers, then one graph launch."""
+        self.sync_params_version()
         B = X.shape[0]
         key = (B, float(momentum), float(max_norm))
         if self._xbuf is None:

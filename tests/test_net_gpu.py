@@ -315,3 +315,42 @@ def test_fit_trajectory_g8_vs_reference(lr):
               f"(ref {hist[ep, cols.index('valid_accuracy')]:.3f})  worst rel err {worst[ep]:.2e}")
     gold.check_summary(g, f"wfinal_lr{lr}", {k: v.detach().cpu() for k, v in net.module_.state_dict().items() if not k.endswith(".pe")},
                        2e-3 if lr == 0.001 else 3e-2)
+
+
+def test_fused_adam_equals_torch_adam():
+    """optimizer=torch.optim.Adam: the fused clip + Adam kernel (north_star's "fused SGD-momentum/Adam update") against
+    torch.optim.Adam stepping the same module through the autograd bridge -- same gradients, so this isolates the update
+    arithmetic (torch/optim/adam.py, _single_tensor_adam): weights within 2e-6 after two epochs; optimizer.pt is a
+    torch.optim.Adam state_dict."""
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(80, seq_len=12, src_vocab=64, n_labels=6, seed=6, min_len=3)
+    kw = dict(optimizer="torch.optim.Adam", optimizer__momentum=None, lr=3e-3, max_epochs=2)
+    nets = []
+    for extra in ({}, {"optimizer__amsgrad": False, "optimizer__foreach": False}):       # 2nd: an unknown kwarg forces the torch path
+        torch.manual_seed(11)
+        from slnlp.net import NeuralNetClassifier
+        args = dict(module="model.Transformer", module__dropout=0.0, module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y,
+                    module__batch_first=True, **CFG, criterion="torch.nn.CrossEntropyLoss", criterion__ignore_index=1,
+                    optimizer="torch.optim.Adam", optimizer__betas=(0.9, 0.99), optimizer__eps=1e-8, lr=3e-3, max_epochs=2, batch_size=20,
+                    device="cuda", gradient_clipping={"gradient_clip_value": 0.5}, **extra)
+        net = NeuralNetClassifier(**args)
+        net.initialize()
+        if extra:
+            net._fused, net._fused_kind = False, None
+            net.optimizer_ = net._opt_cls(net.module_.parameters(), lr=net.lr, **net._opt_kwargs)
+        net.partial_fit(ds)
+        nets.append(net)
+    assert nets[0]._fused_kind == "adam" and nets[1]._fused_kind is None
+    la, lb = [h["train_loss"] for h in nets[0].history], [h["train_loss"] for h in nets[1].history]
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    sa, sb = nets[0].module_.state_dict(), nets[1].module_.state_dict()
+    for k in sa:
+        assert torch.allclose(sa[k], sb[k], rtol=0, atol=2e-6 * max(1.0, float(sb[k].abs().max()))), k
+    ref = nets[1].optimizer_.state_dict()
+    got = nets[0]._sgd_state_dict()
+    assert got["param_groups"][0]["betas"] == (0.9, 0.99) and float(got["state"][0]["step"]) == float(ref["state"][0]["step"]) == 8.0
+    for i in ref["state"]:
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = got["state"][i][key], ref["state"][i][key].cpu()
+            assert torch.allclose(a, b, rtol=0, atol=1e-6 * max(1e-3, float(b.abs().max()))), (i, key)
+    torch.optim.Adam(nets[1].module_.parameters(), lr=1.0).load_state_dict(got)         # the stock optimizer accepts it
