@@ -189,6 +189,12 @@ int slnlp_clip_sgd_step(float* params, const float* grads, float* momentum_buf, 
                         float* partials /* [1024] scratch */, float* norm_out,
                         unsigned long long* rng, void* stream);
 
+/* clip_grad_norm_ + torch.optim.Adam (amsgrad False; torch/optim/adam.py _single_tensor_adam) over one flat arena:
+ * step_count[0] (float, device) holds the number of steps taken so far and is advanced by one. */
+int slnlp_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                         float* partials /* [1024] scratch */, float* norm_out, float* step_count, void* stream);
+
 /* debug / test helper: materialise the keep mask (1.0 / 0.0) of a dropout site */
 int slnlp_dropout_mask(float* out, int R, int C, float p, int site,
                        const unsigned long long* rng, void* stream);

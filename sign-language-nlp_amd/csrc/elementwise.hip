@@ -782,6 +782,12 @@ int slnlp_clip_sgd_step(float* params, const float* grads, float* momentum_buf, 
     return slnlp::clip_sgd_step(params, grads, momentum_buf, n, lr_dev, momentum, max_norm, partials, norm_out, rng,
                                 (hipStream_t)stream);
 }
+int slnlp_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                         float beta1, float beta2, float eps, float weight_decay, float max_norm, float* partials, float* norm_out,
+                         float* step_count, void* stream) {
+    return slnlp::clip_adam_step(params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, weight_decay, max_norm, partials,
+                                 norm_out, nullptr, step_count, (hipStream_t)stream);
+}
 int slnlp_dropout_mask(float* out, int R, int C, float p, int site, const unsigned long long* rng, void* stream) {
     if (!out || !rng || R <= 0 || C <= 0 || p < 0.f || p >= 1.f) {
         slnlp::set_error("slnlp_dropout_mask: bad args");

@@ -91,6 +91,7 @@ SIGNATURES = {
     "slnlp_lsm_nll": (i32, [vp, i64, vp, i32, i32, i64, vp, vp, vp, i64, vp, vp]),
     "slnlp_lsm_bwd": (i32, [vp, vp, i32, i32, vp, i64, vp]),
     "slnlp_clip_sgd_step": (i32, [vp, vp, vp, i64, vp, f32, f32, vp, vp, vp, vp]),
+    "slnlp_clip_adam_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp]),
     "slnlp_dropout_mask": (i32, [vp, i32, i32, f32, i32, vp, vp]),
     "slnlp_rnn_cell_fwd": (i32, [i32, C.POINTER(RnnCellDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, vp]),
     "slnlp_rnn_layer_fwd": (i32, [i32, C.POINTER(RnnLayerDir), i32, i32, i32, i32, vp, f32, i64, f32, i32, vp, i32, vp,

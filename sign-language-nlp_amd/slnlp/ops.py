@@ -221,6 +221,16 @@ def clip_sgd_step(params, grads, buf, lr_dev, *, momentum=0.9, max_norm=0.5, rng
     return norm
 
 
+def clip_adam_step(params, grads, exp_avg, exp_avg_sq, lr_dev, step_count, *, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
+    """In-place clip + Adam on flat fp32 arenas; ``step_count`` [1] float (device) is advanced.  Returns the pre-clip norm [1]."""
+    _lib.require_gpu()
+    partials = torch.empty(1024, dtype=torch.float32, device=params.device)
+    norm = torch.empty(1, dtype=torch.float32, device=params.device)
+    check(load().slnlp_clip_adam_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), ptr(lr_dev), betas[0], betas[1],
+                                      eps, weight_decay, max_norm, ptr(partials), ptr(norm), ptr(step_count), stream_ptr()), "clip_adam_step")
+    return norm
+
+
 def dropout_mask(R, C_, p, site, rng):
     _lib.require_gpu()
     out = torch.empty(R, C_, dtype=torch.float32, device=rng.device)

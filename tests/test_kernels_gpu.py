@@ -265,6 +265,29 @@ def test_clip_sgd(ops):
         assert int(rng[1]) == 42                            # dropout step counter advanced
 
 
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_clip_adam_vs_torch(ops, wd):
+    """Fused clip + Adam against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the same gradients, 5 steps (bias
+    corrections from the device-side step count)."""
+    n = 1 << 18
+    p0 = rnd(n, seed=1)
+    P, M1, M2 = p0.cuda().clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lr, cnt = torch.tensor([3e-3], device="cuda"), torch.zeros(1, device="cuda")
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([ref], lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    for step in range(5):
+        g = rnd(n, seed=10 + step, scale=1e-2 if step % 2 else 1e-4)
+        norm = ops.clip_adam_step(P, g.cuda(), M1, M2, lr, cnt, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd, max_norm=0.5)
+        ref.grad = g.clone().double()
+        total = torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        opt.step()
+        assert abs(float(norm) - float(total)) < 1e-5 * float(total)
+        assert float((P.cpu().double() - ref.detach()).abs().max()) < 2e-7 * (step + 1), step
+    assert float(cnt) == 5.0
+    st = opt.state[ref]
+    assert rel(M1, st["exp_avg"].float()) < 1e-5 and rel(M2, st["exp_avg_sq"].float()) < 1e-5
+
+
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
 @pytest.mark.parametrize("M,N,K", [(2400, 512, 512), (50, 202, 512), (50, 512, 202), (64, 64, 64), (130, 70, 100),
