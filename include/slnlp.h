@@ -135,6 +135,13 @@ int slnlp_attn_self_bwd(const float* qkv, const float* probs, const float* dctx,
  * memory positions, no masks (transformer.py:82-87 passes neither memory_mask
  * nor memory_key_padding_mask).  q [B,E]; kv rows m = s*B+b with row stride
  * ld_kv, k at column 0 and v at column E; probs [B,H,S]. */
+/* Sequences longer than 64 (any S up to the reference's 5000-row positional table) take wave-per-row kernels instead of
+ * the one-tile MFMA kernels -- same arguments and semantics; only the self-attention backward needs more: a scratch buffer
+ * of slnlp_attn_long_scratch_bytes(B, S, H) bytes (the dS tensor between its row pass and its column pass). */
+int64_t slnlp_attn_long_scratch_bytes(int B, int S, int H);
+int slnlp_attn_self_bwd_long(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh,
+                             float* dqkv, float* scratch, float drop_p, int drop_site, const unsigned long long* rng,
+                             void* stream);
 int slnlp_attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh,
                          float* ctx, float* probs,
                          float drop_p, int drop_site, const unsigned long long* rng, void* stream);

@@ -577,6 +577,18 @@ int attn_init() {
     return 0;
 }
 
+// S > 64: the wave-per-row kernels of attention_long.hip
+int attn_self_fwd_long(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S, int H,
+                       int dh, float* ctx, float* probs, float drop_p, int drop_site, const unsigned long long* rng,
+                       hipStream_t st, PlaneOut po);
+int attn_self_bwd_long(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
+                       float* scratch, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po);
+int attn_cross_fwd_long(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx, float* probs,
+                        float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int attn_cross_bwd_long(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B, int S, int H,
+                        int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site, const unsigned long long* rng,
+                        hipStream_t st, PlaneOut po);
+
 static int check_attn(const char* who, int B, int S, int H, int dh) {
     SLNLP_CHECK_ARG(B > 0 && H > 0, "%s: bad B=%d H=%d", who, B, H);
     SLNLP_CHECK_ARG(S > 0 && S <= SMAX, "%s: S=%d outside 1..%d (single-tile kernel)", who, S, SMAX);
@@ -589,19 +601,21 @@ static int check_attn(const char* who, int B, int S, int H, int dh) {
 int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
                   const unsigned long long* rng, hipStream_t st, PlaneOut po) {
-    SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
+    if (S > SMAX) return attn_self_fwd_long(qkv, ids, ld_ids, pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, drop_site, rng, st, po);
+    SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
     SLNLP_TRY(zlaunch(attn_self_fwd_mfma_kernel, dim3(B * H), 256, 0, st, "attn_self_fwd",
                       qkv, (const long*)ids, (long)ld_ids, (long)pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng, po));
     return 0;
 }
 
 int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
-                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po) {
-    SLNLP_TRY(check_attn("attn_self_bwd", B, S, H, dh));
+                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po, float* long_scratch) {
     SLNLP_CHECK_ARG(qkv && probs && dctx && dqkv, "attn_self_bwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
+    if (S > SMAX) return attn_self_bwd_long(qkv, probs, dctx, B, S, H, dh, dqkv, long_scratch, drop_p, drop_site, rng, st, po);
+    SLNLP_TRY(check_attn("attn_self_bwd", B, S, H, dh));
     SLNLP_TRY(attn_init());
     SLNLP_TRY(zlaunch(attn_self_bwd_mfma_kernel, dim3(B * H), 256, (dh <= MFMA_DH ? 8 : 10) * ATILE * sizeof(unsigned short), st, "attn_self_bwd",
                       qkv, probs, dctx, B, S, H, dh, dqkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po));
@@ -610,10 +624,11 @@ int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B
 
 int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
                    float* probs, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st) {
-    SLNLP_TRY(check_attn("attn_cross_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(q && kv && ctx && probs, "attn_cross_fwd: null pointer");
     SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh, "attn_cross_fwd: ld_kv=%ld", (long)ld_kv);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_fwd: bad dropout args");
+    if (S > SMAX) return attn_cross_fwd_long(q, kv, ld_kv, B, S, H, dh, ctx, probs, drop_p, drop_site, rng, st);
+    SLNLP_TRY(check_attn("attn_cross_fwd", B, S, H, dh));
     SLNLP_TRY(zlaunch(attn_cross_fwd_kernel, dim3(B * H), 256, 0, st, "attn_cross_fwd",
                       q, kv, (long)ld_kv, B, S, H, dh, ctx, probs, drop_p, dropout_threshold(drop_p), drop_site, rng));
     return 0;
@@ -622,10 +637,11 @@ int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S,
 int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
                    int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
                    const unsigned long long* rng, hipStream_t st, PlaneOut po) {
-    SLNLP_TRY(check_attn("attn_cross_bwd", B, S, H, dh));
     SLNLP_CHECK_ARG(q && kv && probs && dctx && dq && dkv, "attn_cross_bwd: null pointer");
     SLNLP_CHECK_ARG(ld_kv % 4 == 0 && ld_kv >= 2L * H * dh && ld_dkv >= 2L * H * dh && ld_dkv % 4 == 0, "attn_cross_bwd: bad ld");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_cross_bwd: bad dropout args");
+    if (S > SMAX) return attn_cross_bwd_long(q, kv, ld_kv, probs, dctx, B, S, H, dh, dq, dkv, ld_dkv, drop_p, drop_site, rng, st, po);
+    SLNLP_TRY(check_attn("attn_cross_bwd", B, S, H, dh));
     SLNLP_TRY(zlaunch(attn_cross_bwd_kernel, dim3(B * H), 256, 0, st, "attn_cross_bwd",
                       q, kv, (long)ld_kv, probs, dctx, B, S, H, dh, dq, dkv, (long)ld_dkv, drop_p, dropout_threshold(drop_p), drop_site, rng, po));
     return 0;
@@ -643,6 +659,13 @@ int slnlp_attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, in
 int slnlp_attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh,
                         float* dqkv, float drop_p, int drop_site, const unsigned long long* rng, void* stream) {
     return slnlp::attn_self_bwd(qkv, probs, dctx, B, S, H, dh, dqkv, drop_p, drop_site, rng, (hipStream_t)stream);
+}
+int64_t slnlp_attn_long_scratch_bytes(int B, int S, int H) {
+    return (B > 0 && S > 64 && H > 0) ? (int64_t)slnlp::attn_long_scratch_bytes(B, S, H) : 0;
+}
+int slnlp_attn_self_bwd_long(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh,
+                             float* dqkv, float* scratch, float drop_p, int drop_site, const unsigned long long* rng, void* stream) {
+    return slnlp::attn_self_bwd(qkv, probs, dctx, B, S, H, dh, dqkv, drop_p, drop_site, rng, (hipStream_t)stream, slnlp::PlaneOut{}, scratch);
 }
 int slnlp_attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
                          float* probs, float drop_p, int drop_site, const unsigned long long* rng, void* stream) {

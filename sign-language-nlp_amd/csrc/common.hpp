@@ -156,7 +156,9 @@ int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t 
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
                   const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
 int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
-                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
+                  float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po = {},
+                  float* long_scratch = nullptr);   // S > 64: attn_long_scratch_bytes(B, S, H) bytes
+size_t attn_long_scratch_bytes(int B, int S, int H);
 int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S, int H, int dh, float* ctx,
                    float* probs, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
 int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,

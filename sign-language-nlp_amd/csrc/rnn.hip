@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void rnn_cell_bwd_kernel(slnlp_rnn_cell_bwd_di
 // bkp.py:304-327 with one query per sequence: scores[s] = w_e . tanh(q + proj_key[s]); positions
 // where the source token is <pad> are masked (bkp.py:404-406); softmax; context = alphas . value.
 // One workgroup per sequence b; rows of proj_key / value are time-major (m = s*B + b).
-constexpr int BAH_MAXS = 64;
+constexpr int BAH_MAXS = 2048;   // source positions per sequence held in LDS (the softmax walks them 64 at a time)
 
 __global__ __launch_bounds__(256) void bahdanau_fwd_kernel(const float* __restrict__ q, const float* __restrict__ pk,
                                                            const float* __restrict__ val, const float* __restrict__ we,
@@ -146,14 +146,17 @@ __global__ __launch_bounds__(256) void bahdanau_fwd_kernel(const float* __restri
         if (lane == 0) sc[s] = (ids[(long)b * ld_ids + s] == pad) ? -INFINITY : a;
     }
     __syncthreads();
-    if (wave == 0) {
-        const float v = lane < S ? sc[lane] : -INFINITY;
-        const float m = wave_max(v);
-        const float e = expf(v - m);
-        const float p = e / wave_sum(e);
-        if (lane < S) {
-            sc[lane] = p;
-            alphas[(long)b * S + lane] = p;
+    if (wave == 0) {                     // softmax over the S scores, 64 at a time (S <= 64: one trip, one value per lane)
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, sc[s]);
+        m = wave_max(m);
+        float e = 0.f;
+        for (int s = lane; s < S; s += 64) e += expf(sc[s] - m);
+        const float tot = wave_sum(e);
+        for (int s = lane; s < S; s += 64) {
+            const float p = expf(sc[s] - m) / tot;
+            sc[s] = p;
+            alphas[(long)b * S + s] = p;
         }
     }
     __syncthreads();
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void bahdanau_bwd_kernel(const float* __restri
                                                            float* __restrict__ dval, float* __restrict__ dwe_part) {
     __shared__ float al[BAH_MAXS], dsc[BAH_MAXS];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, V2 = 2 * Hd;
-    if (threadIdx.x < BAH_MAXS) al[threadIdx.x] = threadIdx.x < S ? alphas[(long)b * S + threadIdx.x] : 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) al[s] = alphas[(long)b * S + s];
     __syncthreads();
     // dalpha[s] = dctx . value[s];  dvalue[s] = alpha[s] * dctx
     for (int s = wave; s < S; s += 4) {
@@ -191,9 +194,10 @@ __global__ __launch_bounds__(256) void bahdanau_bwd_kernel(const float* __restri
     }
     __syncthreads();
     if (wave == 0) {  // softmax backward
-        const float a = lane < S ? al[lane] : 0.f, da = lane < S ? dsc[lane] : 0.f;
-        const float dot = wave_sum(a * da);
-        if (lane < S) dsc[lane] = a * (da - dot);
+        float part = 0.f;
+        for (int s = lane; s < S; s += 64) part += al[s] * dsc[s];
+        const float dot = wave_sum(part);
+        for (int s = lane; s < S; s += 64) dsc[s] = al[s] * (dsc[s] - dot);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < Hd; j += 256) {

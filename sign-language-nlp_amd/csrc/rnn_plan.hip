@@ -92,7 +92,8 @@ static int check_rcfg(const slnlp_rnn_config* c) {
     SLNLP_CHECK_ARG(c->Hd > 0 && c->Hd % 4 == 0, "rnn: hidden_size %d must be a positive multiple of 4", c->Hd);
     SLNLP_CHECK_ARG(c->N > 0 && c->Vs > 1 && c->Vt > 1, "rnn: bad num_layers / vocab");
     SLNLP_CHECK_ARG(c->B > 0 && c->B <= 1024, "rnn: batch %d outside 1..1024", c->B);
-    SLNLP_CHECK_ARG(c->S > 0 && c->S <= 64, "rnn: seq_len %d outside 1..64", c->S);
+    SLNLP_CHECK_ARG(c->S > 0 && c->S <= 2048, "rnn: seq_len %d outside 1..2048", c->S);
+    SLNLP_CHECK_ARG((long)c->B * c->S <= 65536, "rnn: batch %d x seq_len %d exceeds 65536 tokens per step", c->B, c->S);
     SLNLP_CHECK_ARG(c->bos_idx >= 0 && c->bos_idx < c->Vt, "rnn: bos_idx %d outside the target vocabulary", c->bos_idx);
     SLNLP_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "rnn: dropout %f", c->dropout);
     SLNLP_CHECK_ARG(c->precision == 1 || c->precision == 3, "rnn: precision %d", c->precision);

@@ -376,13 +376,13 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         if (up) {
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.d1p, E, M, E, a.ctxp, E, pl->G(q.out_w), pl->G(q.out_b)),
                                    pl->dgrad_p_args(a.d1p, E, M, E, q.out_w, E, a.gctx, nullptr, 0.f, nullptr, nullptr), 0, st));
-            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st, a.gqkvp.out()));
+            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st, a.gqkvp.out(), w.attn_scratch));
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, xp_in, E, pl->G(q.in_w), pl->G(q.in_b)),
                                    pl->dgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, q.in_w, E, a.gx0, nullptr, 0.f, a.gA1, nullptr), 0, st));
         } else {
             SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d1, E, M, E, a.ctx, E, pl->G(q.out_w), pl->G(q.out_b)),
                                      pl->dgrad_args(d1, E, M, E, pl->P(q.out_w), E, a.gctx, nullptr, 0.f, nullptr), st));
-            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st));
+            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st, PlaneOut{}, w.attn_scratch));
             SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gqkv, 3 * E, M, 3 * E, x_in, E, pl->G(q.in_w), pl->G(q.in_b)),
                                      pl->dgrad_args(a.gqkv, 3 * E, M, 3 * E, pl->P(q.in_w), E, a.gx0, nullptr, 0.f, a.gA1), st));
         }

@@ -110,7 +110,10 @@ static int check_cfg(const slnlp_tf_config* c) {
     SLNLP_CHECK_ARG(c->F > 0 && c->F % 4 == 0, "tf: hidden_size %d must be a multiple of 4", c->F);
     SLNLP_CHECK_ARG(c->N > 0 && c->Vs > 1 && c->Vt > 1, "tf: bad N/vocab");
     SLNLP_CHECK_ARG(c->B > 0 && c->B <= 1024, "tf: batch %d outside 1..1024", c->B);
-    SLNLP_CHECK_ARG(c->S > 0 && c->S <= 64, "tf: seq_len %d outside 1..64 (single-tile attention)", c->S);
+    // S <= 64: one-tile MFMA attention; longer sequences take the wave-per-row kernels (attention_long.hip).  5000 = rows of
+    // the reference's positional table (positional_encoding.py:23); B * S <= 65536: the embedding backward's chunk table
+    SLNLP_CHECK_ARG(c->S > 0 && c->S <= 5000, "tf: seq_len %d outside 1..5000", c->S);
+    SLNLP_CHECK_ARG((long)c->B * c->S <= 65536, "tf: batch %d x seq_len %d exceeds 65536 tokens per step", c->B, c->S);
     SLNLP_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "tf: dropout %f", c->dropout);
     SLNLP_CHECK_ARG(c->precision == 1 || c->precision == 3, "tf: precision %d", c->precision);
     return 0;
@@ -159,6 +162,7 @@ struct Ws {
     PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
     char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
     float* opt_partials;
+    float* attn_scratch;    // S > 64: dS of one self-attention backward ([B,H,S,S], shared by all layers)
     char* gscr[2];          // split-K scratch of the grouped GEMM launches: [0] main stream, [1] side stream
     size_t gscr_bytes;
     slnlp_ln_reduce_entry* ln_table;
@@ -258,6 +262,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     w.emb_scratch_tgt = b.take<char>(embed_bwd_scratch_bytes(c.B, 1, c.E));
     w.emb_keep = b.take<unsigned char>(M * E / 4);
     w.opt_partials = b.take<float>(1024);
+    w.attn_scratch = c.S > 64 ? (float*)b.take<char>(attn_long_scratch_bytes(c.B, c.S, c.H)) : nullptr;
     w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
     // ---- bf16 operand planes (only used when E and F are multiples of 64)
     const size_t Mp = (M + 63) / 64 * 64;

@@ -83,6 +83,8 @@ SIGNATURES = {
     "slnlp_embed_bwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, f32, i64, f32, i32, vp, vp, vp]),
     "slnlp_attn_self_fwd": (i32, [vp, vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     "slnlp_attn_self_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, f32, i32, vp, vp]),
+    "slnlp_attn_long_scratch_bytes": (i64, [i32, i32, i32]),
+    "slnlp_attn_self_bwd_long": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     "slnlp_attn_cross_fwd": (i32, [vp, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     "slnlp_attn_cross_bwd": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, i64, f32, i32, vp, vp]),
     "slnlp_layernorm_fwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp]),

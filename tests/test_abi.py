@@ -68,9 +68,12 @@ def test_argument_validation_returns_codes_not_aborts(lib):
     bad = te.make_config(130, 4, 2, 256, 3000, 202, 50, 48)       # head_dim 32.5
     assert lib.slnlp_tf_num_params(C.byref(bad)) == -1
     assert b"divisible" in lib.slnlp_last_error()
-    bad = te.make_config(128, 4, 2, 256, 3000, 202, 50, 65)       # S > 64
+    bad = te.make_config(128, 4, 2, 256, 3000, 202, 5, 5001)      # beyond the reference's 5000-row positional table
     assert lib.slnlp_tf_workspace_bytes(C.byref(bad)) == -1
     assert b"seq_len" in lib.slnlp_last_error()
+    assert lib.slnlp_tf_workspace_bytes(C.byref(te.make_config(128, 4, 2, 256, 3000, 202, 50, 65))) > 0      # S > 64 is fine
+    bad = te.make_config(128, 4, 2, 256, 3000, 202, 1024, 65)     # more tokens per step than the embedding backward indexes
+    assert lib.slnlp_tf_workspace_bytes(C.byref(bad)) == -1 and b"tokens" in lib.slnlp_last_error()
     a = _lib.GemmArgs()
     assert lib.slnlp_gemm(C.byref(a), None) == 1                  # null operands -> SLNLP_ERR_INVALID_ARG
     assert lib.slnlp_gemm(None, None) == 1

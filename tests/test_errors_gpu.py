@@ -21,7 +21,8 @@ def _engine(c, sd=None, **over):
 
 
 @pytest.mark.parametrize("over, msg", [
-    (dict(S=65), "seq_len"),              # single-tile attention: S <= 64
+    (dict(S=5001), "seq_len"),            # beyond the reference's 5000-row positional table
+    (dict(S=4000, B=50), "tokens"),       # B * S above the embedding backward's 65536-token chunk table
     (dict(E=30, H=4), "not divisible"),   # head_dim must divide
     (dict(E=2048, H=8), "E="),            # arena / kernel limit
     (dict(B=0), "batch"),
@@ -62,4 +63,4 @@ def test_rnn_bad_config_and_lengths():
     with pytest.raises(RuntimeError):
         re_.RnnEngine(re_.make_config("lstm", 32, 30, 2, 64, 16, 4, 12, 1, 1, 0, 0.0, 3))       # Hd % 4 != 0
     with pytest.raises(RuntimeError):
-        re_.RnnEngine(re_.make_config("lstm", 32, 32, 2, 64, 16, 4, 65, 1, 1, 0, 0.0, 3))       # S > 64
+        re_.RnnEngine(re_.make_config("lstm", 32, 32, 2, 64, 16, 4, 2049, 1, 1, 0, 0.0, 3))     # S > 2048 (Bahdanau scores in LDS)
