@@ -123,6 +123,39 @@ def dominant_kernel_roofline(c, precision, dev, workload):
                     "MFMA passes are not counted; bytes = operand planes (hi+lo) read once + fp32 results + result planes"}
 
 
+FP8_DENSE_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: ~5 PF dense fp8 (reached only by the block-scaled K=128 MFMA; the plain
+                                  # v_mfma_f32_16x16x32_fp8_fp8 this kernel issues runs at the bf16 rate, 2.5 PF)
+
+
+def fp8_kernel_roofline(c, dev):
+    """precision 8's own kernel: the largest forward product of an encoder layer, in_proj [B*S, E] x [3E, E]^T, on e4m3
+    planes (slnlp_gemm with precision 8), timed back to back with HIP events."""
+    from slnlp import ops
+    M, E = c["B"] * c["S"], c["E"]
+    g = torch.Generator().manual_seed(0)
+    X, W = torch.randn(M, E, generator=g).to(dev), (torch.randn(3 * E, E, generator=g) * 0.05).to(dev)
+    Xq, _ = ops.quant_rows_fp8(X)
+    Wq, sw = ops.quant_rows_fp8(W)
+    out = torch.empty(M, 3 * E, device=dev)
+    for _ in range(20):
+        ops.gemm_fp8(Xq, Wq, M=M, N=3 * E, K=E, col_scale=sw, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 200
+    e0.record()
+    for _ in range(n):
+        ops.gemm_fp8(Xq, Wq, M=M, N=3 * E, K=E, col_scale=sw, out=out)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    flops = 2.0 * M * 3 * E * E
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": f"gemm_planes_kernel fp8 tile, in_proj [{M}x{E}]x[{3 * E}x{E}]^T, {((M + 63) // 64) * (3 * E // 64)} workgroups",
+            "bound": "mfma", "achieved": round(tf, 1), "peak": FP8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP8_DENSE_PEAK_TFLOPS, 4),
+            "traffic": None, "us_per_launch_hip_events": round(us, 2), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 1.0 * (M * E + 3 * E * E) + 4.0 * M * 3 * E,
+            "note": "e4m3 operand planes (1 B/element) read once + fp32 result; plain fp8 MFMA (bf16 issue rate), priced against the 5 PF dense fp8 peak"}
+
+
 def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
     """Aggregate train seq/s of K independent fits of this workload sharing the GPU by advancing in LOCKSTEP through one
     launch sequence (slnlp/lockstep.py: own weights, lr, seed and data per fit; bit-identical to solo fits) -- how
@@ -162,30 +195,34 @@ def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
             "note": f"{steps} steps per fit, every fit its own weights / data; the step's kernels carry a fit index (grid.z) or a merged job table"}
 
 
-# 24 of config-transformer.yaml's 324 candidates: every lr and dropout at embedding_size 512, num_layers 2, two
-# hidden sizes and both head counts -> 4 shapes x 30 (candidate, fold) fits.  With lockstep 5 that is 24 work units of
-# nearly equal cost: a multiple of 8, so the strong-scaling leg divides evenly over 1 / 2 / 4 / 8 GPUs.
-GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__hidden_size": [512, 256], "module__num_heads": [8, 4]}
-GRID_FIXED = {"module__embedding_size": 512, "module__num_layers": 2}
-GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 8, 2000
+# 48 of config-transformer.yaml's 324 candidates: every lr and dropout, two embedding sizes, two hidden sizes and both head
+# counts at num_layers 2 -> 8 shapes x 30 (candidate, fold) fits.  With lockstep 5 that is 48 work units: 24 at
+# embedding_size 512 and 24 cheap ones at 128 that fill the gaps of the longest-first schedule, so the strong-scaling leg
+# divides evenly over 1 / 2 / 4 / 8 GPUs (6 units per GPU at N = 8).
+GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__embedding_size": [512, 128],
+               "module__hidden_size": [512, 256], "module__num_heads": [8, 4]}
+GRID_FIXED = {"module__num_layers": 2}
+GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 6, 2000
 
 
 def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
     from slnlp.net import NeuralNetClassifier
     return lambda: NeuralNetClassifier(
         module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
-        module__embedding_size=GRID_FIXED["module__embedding_size"], module__num_heads=4, module__num_layers=GRID_FIXED["module__num_layers"],
+        module__embedding_size=512, module__num_heads=4, module__num_layers=GRID_FIXED["module__num_layers"],
         module__hidden_size=256, module__dropout=0.1, criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=max_epochs, batch_size=50,
         device=str(dev), gradient_clipping={"gradient_clip_value": 0.5},
         scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
 
 
-def grid_folds_per_hour(dev, world, rank, fits_per_gpu=1, lockstep=5):
+def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=5):
     """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
-    on a bounded sample of config-transformer.yaml's grid -- 24 candidates x cv 5 = 120 fits of 8 epochs over 2000
+    on a bounded sample of config-transformer.yaml's grid -- 48 candidates x cv 5 = 240 fits of 6 epochs over 2000
     synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
     ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling).  Work unit =
-    `lockstep` shape-compatible fits advancing through one launch sequence."""
+    `lockstep` shape-compatible fits advancing through one launch sequence; `fits_per_gpu` host threads per rank each run
+    one unit at a time, so one unit's host work (estimator construction, epoch metrics, scoring) hides under another's kernels
+    (measured on the 24-unit predecessor of this sample: 8.5 k folds/hr with 1 thread, 18.1 k with 2, 19.9 k with 3, 20.6 k with 4)."""
     import warnings
     from slnlp.data import synthetic_dataset
     from slnlp.grid import ShardedGridSearchCV
@@ -193,7 +230,7 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=1, lockstep=5):
     warnings.filterwarnings("ignore", message="The least populated class")    # 2000 samples over 200 labels
     ds = synthetic_dataset(GRID_SAMPLES, seq_len=48, src_vocab=3000, n_labels=200, seed=1, min_len=8)
     # untimed warm-up on every rank (code objects, allocator pools, plan creation paths): one tiny fit per shape
-    warm = ShardedGridSearchCV(grid_factory(ds.truncated(200), dev, 1), {k: GRID_SAMPLE[k] for k in ("module__hidden_size", "module__num_heads")},
+    warm = ShardedGridSearchCV(grid_factory(ds.truncated(200), dev, 1), {k: GRID_SAMPLE[k] for k in ("module__embedding_size", "module__hidden_size", "module__num_heads")},
                                cv=2, refit=False, device=str(dev), fits_per_gpu=1, schedule="static", lockstep=min(lockstep, 2))
     warm_t0 = time.perf_counter()
     _fit_local(warm, ds.truncated(200))       # every rank warms up on the whole warm-up grid, not on a shard of it
@@ -209,8 +246,8 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=1, lockstep=5):
             "fits_per_gpu": fits_per_gpu, "lockstep": lockstep, "work_units": gs.n_units_, "ranks": world, "schedule": gs.schedule,
             "rank_seconds": [round(v, 2) for v in gs.rank_seconds_], "rank_fits": gs.rank_tasks_, "warmup_seconds": round(warm_s, 2),
             "best_index": gs.best_index_, "best_score": round(gs.best_score_, 5),
-            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x hidden_size x num_heads of config-transformer.yaml at "
-                      f"embedding_size 512, num_layers 2) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
+            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x embedding_size x hidden_size x num_heads of config-transformer.yaml at "
+                      f"num_layers 2) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
                       "the reference's 5 epoch metrics on both; includes the dataset broadcast and the score all_gather"}
 
 
@@ -229,7 +266,7 @@ def rocprof_kernel_times(workload):
     """The committed rocprofv3 --kernel-trace view of the same kernel (tools/roofline_kernel_stats.py): its back-to-back
     launches (what the HIP events above time) and its launches inside train steps, or None."""
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", f"r01_bench_{workload}_roofline_kernel.json")))
+        e = json.load(open(os.path.join(ROOT, "profiles", f"r02_bench_{workload}_roofline_kernel.json")))
         return {"back_to_back_avg_us": e["back_to_back"]["avg_us"], "in_step_avg_us": e["in_step"]["avg_us"], "min_us": e["min_us"]}
     except Exception:
         return None
@@ -237,7 +274,7 @@ def rocprof_kernel_times(workload):
 
 def pmc_kernel_traffic(workload, shape):
     """HBM bytes of one launch of `shape` ("kernel xWORKGROUPS") from the same committed PMC passes, or None."""
-    f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}_step_traffic.json")
+    f = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}_step_traffic.json")
     try:
         e = json.load(open(f))["per_launch"][shape]
         return float(e["fetch_bytes"] + e["write_bytes"])
@@ -247,7 +284,7 @@ def pmc_kernel_traffic(workload, shape):
 
 def pmc_traffic(workload):
     """HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), or None."""
-    f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}_step_traffic.json")
+    f = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}_step_traffic.json")
     try:
         return float(json.load(open(f))["hbm_bytes_per_step"])
     except Exception:
@@ -335,10 +372,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", type=int, default=3, choices=[1, 3])
+    ap.add_argument("--precision", type=int, default=3, choices=[1, 3, 8],
+                    help="3: split-bf16 (parity grade, default); 1: single bf16 pass; 8: fp8 forward products (configs[4]'s \"fp8 MFMA weights\")")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true", help="skip the folds/hr leg")
-    ap.add_argument("--fits-per-gpu", type=int, default=1, help="host threads per GPU in the grid leg (each runs work units)")
+    ap.add_argument("--fits-per-gpu", type=int, default=3, help="host threads per GPU in the grid leg (each runs work units)")
     ap.add_argument("--lockstep", type=int, default=5, help="fits per work unit, advanced through one launch sequence, in the grid leg")
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")
@@ -459,7 +497,7 @@ def main():
             "metric": f"train seq/s (batch={B},len={S})", "value": round(seqs / wall, 1), "unit": "seq/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == 1 else "bf16x3",
+            "vs_baseline": None, "dtype": {1: "bf16", 3: "bf16x3", 8: "fp8 (forward products) + bf16x3 (backward)"}[args.precision],
             "data": "synthetic (numpy seed recipe: ids, lengths, labels; seed-recipe weights)",
             "config": {"workload": (f"{args.workload}: EncoderDecoder{c['rnn'].upper()}Attn train step E{c['E']} Hd{c['Hd']} N{c['N']} "
                                     if "rnn" in c else
@@ -479,11 +517,14 @@ def main():
             out["grid"] = grid
         if "rnn" not in c:
             with torch.cuda.stream(stream):
-                dk = dominant_kernel_roofline(c, args.precision, dev, args.workload)
+                dk = dominant_kernel_roofline(c, 3 if args.precision == 8 else args.precision, dev, args.workload)
+                if args.precision == 8:
+                    out["roofline_fp8"] = fp8_kernel_roofline(c, dev)
             if dk:
                 out["roofline"] = dk
             if world == 1 and not args.no_cpu_baseline:
-                out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
+                if args.precision != 8:
+                    out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
         out.setdefault("roofline", dict(out["roofline_step"]))   # RNN workloads: no single dominant GEMM, the step is the unit
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))

@@ -80,6 +80,12 @@ typedef struct slnlp_gemm_args {
      * attention-weight dropout when there is a single key (decoder self-attention, tgt length 1): the softmax
      * weight is the scalar 1 per (row, head).  fp32-operand GEMMs only. */
     int32_t drop_head_dim;
+    /* precision 8 -- "fp8 MFMA weights" (BASELINE.json configs[4]), forward products only, both operands k-major:
+     * A_hi / B_hi are then OCP e4m3 BYTE planes (row strides lda_p / ldb_p in bytes; rows zero-padded to multiples of 64, K
+     * to multiples of 128), contracted on the fp8 MFMA; col_scale[n] (optional) multiplies column n of the product -- the
+     * per-row scale of a quantised weight matrix.  C_q8 (optional): also emit the result as an e4m3 plane, row stride ldc_p. */
+    const float* col_scale;
+    uint8_t* C_q8;
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
@@ -94,6 +100,9 @@ int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
 int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs);
 int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
                      int64_t scratch_bytes, void* stream);
+/* fp32 [R,K] rows (row stride ld) -> OCP e4m3 rows with one fp32 scale per row: scale[r] = max|x[r,:]| / 448 (1 for an
+ * all-zero row), q[r,k] = e4m3(x[r,k] / scale[r]); row stride of q = ldq bytes.  The weight operand of precision 8. */
+int slnlp_quant_rows_fp8(const float* x, int64_t ld, int R, int K, uint8_t* q, int64_t ldq, float* scale, void* stream);
 /* fp32 [R,C] (row stride ld) -> bf16 hi/lo planes with row stride ldp (lo may be NULL); writes the valid
  * region only -- the planes' zero padding comes from their allocation. */
 int slnlp_split_planes(const float* x, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp, void* stream);

@@ -95,7 +95,16 @@ __device__ __forceinline__ bool dropout_keep(const unsigned long long* rng, int 
 struct PlaneOut {
     unsigned short* hi = nullptr;
     unsigned short* lo = nullptr;
+    unsigned char* q8 = nullptr;   // precision 8: the value as OCP e4m3 (scale 1), operand of the fp8 forward GEMMs
 };
+// fp32 -> OCP e4m3fn (gfx950's fp8), saturating at +-448 (a NaN stays a NaN)
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
 __device__ __forceinline__ void split_bf16(float x, unsigned short& h, unsigned short& l) {
     const unsigned u = __float_as_uint(x);
     h = (unsigned short)(u >> 16);
@@ -108,6 +117,7 @@ __device__ __forceinline__ void store_planes1(const PlaneOut& po, long idx, floa
     split_bf16(v, h, l);
     po.hi[idx] = h;
     po.lo[idx] = l;
+    if (po.q8) po.q8[idx] = (unsigned char)(pack_fp8x4(v, 0.f, 0.f, 0.f) & 0xFFu);
 }
 __device__ __forceinline__ void store_planes4(const PlaneOut& po, long idx, float4 v) {   // idx % 4 == 0
     if (!po.hi) return;
@@ -118,6 +128,7 @@ __device__ __forceinline__ void store_planes4(const PlaneOut& po, long idx, floa
     *reinterpret_cast<uint2*>(po.hi + idx) = w;
     w.x = l[0] | ((unsigned)l[1] << 16); w.y = l[2] | ((unsigned)l[3] << 16);
     *reinterpret_cast<uint2*>(po.lo + idx) = w;
+    if (po.q8) *reinterpret_cast<unsigned*>(po.q8 + idx) = pack_fp8x4(v.x, v.y, v.z, v.w);
 }
 
 // ------------------------------------------------------------- wave ops -----
@@ -144,6 +155,9 @@ int gemm_planes_init();
 int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs, void* scratch, size_t scratch_bytes,
                       hipStream_t s);
 size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs);
+struct QuantRow { long off; int K, pad; };   // one weight row of a precision-8 plan: offset into the arena (floats), length
+int quant_rows_fp8(const float* x, int64_t ld, int R, int K, unsigned char* q, int64_t ldq, float* scale, const void* row_table,
+                   hipStream_t st);   // row_table: device array of {long offset (floats); int K; int pad} or null
 int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, unsigned short* lo, int64_t ldp, hipStream_t st);
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,

@@ -245,6 +245,103 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
 }
 
 // `tab` != nullptr: a merged (lockstep) launch -- the jobs of K fits in a device-resident table, blockmap[block] = job
+// ---------------------------------------------------------------------------------------------- fp8 forward tile ---
+// precision 8: C[M,N] = epilogue( col_scale[n] * sum_k A8(m,k) B8(n,k) ), both operands OCP e4m3 byte planes, k-major.
+// Same skeleton as plane_tile -- 64x64 output tile, 8 waves (16x32 each), LDS-DMA ring, one barrier per K-step -- with
+// one byte per element: a K-step is 128 k (the 128-byte image row and its swizzle are those of the bf16 k-major image,
+// so the DMA pattern is unchanged), a stage is 16 KiB (A + B) instead of 32, the ring is 4 deep (3 tiles in flight in the
+// same 64 KiB), and a 16-byte fragment read feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes; the k order
+// inside a K-step is permuted the same way for A and B, which a contraction does not see).  Per algorithmic FLOP that is a
+// quarter of the operand bytes and a third of the MFMA issue slots of the three-pass split-bf16 kernel.
+constexpr int Q8_BK = 128;             // k (= bytes) per K-step
+constexpr int Q8_IMG = PT * Q8_BK;     // bytes per operand image (8 KiB)
+constexpr int Q8_STAGES = 4;
+
+__device__ __forceinline__ void dma_q8(const unsigned char* __restrict__ plane, long ld, int row0, int k0, unsigned char* img,
+                                       int wave, int lane) {
+    const int line = 8 * wave + (lane >> 3), ps = lane & 7;
+    const unsigned char* src = plane + (long)(row0 + line) * ld + k0 + ((ps ^ (line & 7)) << 4);
+    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(img + wave * 1024), 16, 0, 0);
+}
+
+__device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned char* smem) {
+    const slnlp_gemm_args& g = job.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 16, wn0 = (wave & 1) * 32;
+    int bx, by;
+    {
+        const int nwg = job.tiles_x * job.tiles_y;
+        const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+        by = t / job.tiles_x;
+        bx = t - by * job.tiles_x;
+    }
+    const int bm0 = by * PT, bn0 = bx * PT, M = g.M, N = g.N;
+    const int ktiles = (g.K + Q8_BK - 1) / Q8_BK;
+    const unsigned char* A8 = reinterpret_cast<const unsigned char*>(g.A_hi);
+    const unsigned char* B8 = reinterpret_cast<const unsigned char*>(g.B_hi);
+    auto issue = [&](int kt, int stage) {
+        const int k0 = (kt < ktiles ? kt : 0) * Q8_BK;          // past-the-end prefetch re-reads a valid tile (never consumed)
+        unsigned char* st = smem + stage * 2 * Q8_IMG;
+        dma_q8(A8, g.lda_p, bm0, k0, st, wave, lane);
+        dma_q8(B8, g.ldb_p, bn0, k0, st + Q8_IMG, wave, lane);
+    };
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int t = 0; t < Q8_STAGES - 1; ++t) issue(t, t);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((Q8_STAGES - 2) * 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(kt + Q8_STAGES - 1, (kt + Q8_STAGES - 1) % Q8_STAGES);
+        const unsigned char* sa = smem + (kt % Q8_STAGES) * 2 * Q8_IMG;
+        const unsigned char* sb = sa + Q8_IMG;
+        const int rowa = wm0 + (lane & 15), qd = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {                           // lane group qd reads 16-byte slot 4r + qd of its row
+            const int slot = 4 * r + qd;
+            const uint4 a = *reinterpret_cast<const uint4*>(sa + rowa * Q8_BK + ((slot ^ (rowa & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rowb = wn0 + 16 * j + (lane & 15);
+                const uint4 b = *reinterpret_cast<const uint4*>(sb + rowb * Q8_BK + ((slot ^ (rowb & 7)) << 4));
+                const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
+                const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // drain the dummy prefetches
+    // ---- epilogue: * col_scale -> +bias -> relu -> dropout -> +resid ; fp32 store (+ optional bf16 / fp8 planes)
+    const int crow = (lane >> 4) << 2, ccol = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gm0 = bm0 + wm0 + crow, gn = bn0 + wn0 + j * 16 + ccol;
+        if (gn >= N || gm0 >= M) continue;
+        const float cs = g.col_scale ? g.col_scale[gn] : 1.f, bias = g.bias ? g.bias[gn] : 0.f;
+        uint4 bits = make_uint4(0, 0, 0, 0);
+        if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = gm0 + r;
+            if (gm >= M) break;
+            float v = acc[j][r] * cs + bias;
+            if (g.relu == 1) v = fmaxf(v, 0.f);
+            else if (g.relu == 2) v = tanhf(v);
+            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+            if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
+            if (g.C) g.C[(long)gm * g.ldc + gn] = v;
+            if (g.C_hi) {
+                unsigned short h, l;
+                split_bf16(v, h, l);
+                g.C_hi[(long)gm * g.ldc_p + gn] = h;
+                if (g.C_lo) g.C_lo[(long)gm * g.ldc_p + gn] = l;
+            }
+            if (g.C_q8) g.C_q8[(long)gm * g.ldc_p + gn] = (unsigned char)(pack_fp8x4(v, 0.f, 0.f, 0.f) & 0xFFu);
+        }
+    }
+}
+
 template <int NSPLIT>
 __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
                                                                const int* __restrict__ blockmap) {
@@ -262,6 +359,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupP
     job.part = as_global(job.part); job.part_rs = as_global(job.part_rs); job.counters = as_global(job.counters);
     const int lid = blockIdx.x - job.block_begin;
     if (lid >= job.tiles_x * job.tiles_y * job.nks) return;                 // padding block of a merged launch (jobs start on multiples of 8)
+    if (job.variant == 3) { q8_tile(job, lid, reinterpret_cast<unsigned char*>(smem)); return; }
     if (job.variant == 0) plane_tile<NSPLIT, true, true>(job, lid, smem);
     else if (job.variant == 1) plane_tile<NSPLIT, true, false>(job, lid, smem);
     else plane_tile<NSPLIT, false, false>(job, lid, smem);
@@ -289,6 +387,16 @@ static int check_plane_job(const slnlp_gemm_args& a) {
     SLNLP_CHECK_ARG(a.A_hi && a.B_hi, "gemm_planes: operand planes required");
     SLNLP_CHECK_ARG(a.C || a.C_hi, "gemm_planes: no output");
     SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_planes: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.precision == 8) {
+        SLNLP_CHECK_ARG(a.a_kmajor && a.b_kmajor, "gemm_planes: precision 8 (fp8) is built for k-major operands (forward products)");
+        SLNLP_CHECK_ARG(a.lda_p % 128 == 0 && a.ldb_p % 128 == 0 && a.lda_p >= a.K && a.ldb_p >= a.K,
+                        "gemm_planes: fp8 plane row strides must be multiples of 128 bytes and cover K");
+        SLNLP_CHECK_ARG(!a.gate && !a.rowsum_a && a.drop_head_dim == 0, "gemm_planes: fp8 jobs take bias / relu / dropout / residual only");
+        SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.B_hi) & 15) == 0, "gemm_planes: planes must be 16-byte aligned");
+        SLNLP_CHECK_ARG(!a.C || a.ldc >= a.N, "gemm_planes: ldc < N");
+        SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "gemm_planes: bad dropout args");
+        return 0;
+    }
     SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo && a.B_lo), "gemm_planes: precision 3 needs lo planes");
     SLNLP_CHECK_ARG(a.lda_p % 64 == 0 && a.ldb_p % 64 == 0, "gemm_planes: plane row strides must be multiples of 64");
     SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.B_hi | (uintptr_t)a.A_lo | (uintptr_t)a.B_lo) & 15) == 0,
@@ -322,12 +430,15 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
     for (int i = 0; i < njobs; ++i) {
         const slnlp_gemm_args& a = jobs[i];
         SLNLP_TRY(check_plane_job(a));
-        SLNLP_CHECK_ARG(a.precision == jobs[0].precision, "gemm_group: jobs of one launch share the precision");
+        // fp8 jobs run inside the split-bf16 kernel's launch (its 64 KiB of LDS is their 4-stage ring); single-pass bf16 not
+        SLNLP_CHECK_ARG((a.precision == 8 ? 3 : a.precision) == (jobs[0].precision == 8 ? 3 : jobs[0].precision),
+                        "gemm_group: jobs of one launch share the precision");
         PlaneJob& j = P.job[i];
         j.a = a;
         j.drop_thr = dropout_threshold(a.drop_p);
         j.drop_scale = 1.f / (1.f - a.drop_p);
-        j.variant = (a.a_kmajor && a.b_kmajor) ? 0 : a.a_kmajor ? 1 : 2;
+        j.variant = a.precision == 8 ? 3 : (a.a_kmajor && a.b_kmajor) ? 0 : a.a_kmajor ? 1 : 2;
+        if (a.precision == 8) SLNLP_CHECK_ARG(!split_k || split_k[i] <= 1, "gemm_group: fp8 jobs do not split K");
         j.tiles_x = ceil_div(a.N, PT);
         j.tiles_y = ceil_div(a.M, PT);
         const int ktiles = ceil_div(a.K, PT);
@@ -354,9 +465,10 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
         blocks += tiles * nks;
     }
     SLNLP_TRY(gemm_planes_init());
+    const int kprec = jobs[0].precision == 8 ? 3 : jobs[0].precision;
     if (recording())
-        return record_op(gemm_planes_kernel_ptr(jobs[0].precision), dim3(blocks), dim3(PTHREADS), PLANE_LDS, REC_PLANE_GROUP, &P, sizeof(P), "gemm_planes");
-    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_planes_kernel<3>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P, (const PlaneJob*)nullptr, (const int*)nullptr);
+        return record_op(gemm_planes_kernel_ptr(kprec), dim3(blocks), dim3(PTHREADS), PLANE_LDS, REC_PLANE_GROUP, &P, sizeof(P), "gemm_planes");
+    if (kprec == 3) hipLaunchKernelGGL(gemm_planes_kernel<3>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P, (const PlaneJob*)nullptr, (const int*)nullptr);
     else hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(blocks), dim3(PTHREADS), PLANE_LDS, s, P, (const PlaneJob*)nullptr, (const int*)nullptr);
     SLNLP_CHECK_LAUNCH("gemm_planes");
     return 0;
@@ -406,7 +518,43 @@ int split_planes(const float* x, int64_t ld, int R, int C, unsigned short* hi, u
     return zlaunch(split_planes_kernel, dim3(grid), 256, 0, st, "split_planes", x, (long)ld, R, C, hi, lo, (long)ldp);
 }
 
+// fp32 rows -> e4m3 rows + one scale per row (one wave per row).  The weight operand of precision 8: scale = max|row| / 448.
+// `rows` != nullptr: a table of {source offset (floats), K} entries over one arena (q plane at the same offsets, scale[entry]).
+__device__ __forceinline__ void quant_rows_fp8_body(const float* __restrict__ x, long ld, int R, int K, unsigned char* __restrict__ q,
+                                                    long ldq, float* __restrict__ scale, const QuantRow* __restrict__ rows) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* src = rows ? x + rows[r].off : x + (long)r * ld;
+    unsigned char* dst = rows ? q + rows[r].off : q + (long)r * ldq;
+    const int k_len = rows ? rows[r].K : K;
+    float m = 0.f;
+    for (int k = lane * 4; k < k_len; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + k);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    const float sc = m > 0.f ? m * (1.f / 448.f) : 1.f, inv = 1.f / sc;
+    if (lane == 0) scale[r] = sc;
+    for (int k = lane * 4; k < k_len; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + k);
+        *reinterpret_cast<unsigned*>(dst + k) = pack_fp8x4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    }
+}
+SLNLP_ZKERNEL(quant_rows_fp8_kernel, 256, quant_rows_fp8_body)
+
+int quant_rows_fp8(const float* x, int64_t ld, int R, int K, unsigned char* q, int64_t ldq, float* scale, const void* row_table,
+                   hipStream_t st) {
+    SLNLP_CHECK_ARG(x && q && scale && R > 0, "quant_rows_fp8: bad arguments");
+    SLNLP_CHECK_ARG(row_table || (K > 0 && K % 4 == 0 && ld % 4 == 0 && ldq % 4 == 0 && ldq >= K), "quant_rows_fp8: K, ld, ldq must be multiples of 4");
+    return zlaunch(quant_rows_fp8_kernel, dim3(ceil_div(R, 4)), 256, 0, st, "quant_rows_fp8", x, (long)ld, R, K, q, (long)ldq, scale,
+                   (const QuantRow*)row_table);
+}
+
 }  // namespace slnlp
+
+extern "C" int slnlp_quant_rows_fp8(const float* x, int64_t ld, int R, int K, uint8_t* q, int64_t ldq, float* scale, void* stream) {
+    return slnlp::quant_rows_fp8(x, ld, R, K, q, ldq, scale, nullptr, (hipStream_t)stream);
+}
 
 extern "C" int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs) {
     if (!jobs || njobs < 1) return 0;

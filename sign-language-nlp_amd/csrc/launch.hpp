@@ -56,6 +56,7 @@ __device__ __forceinline__ T* as_global(T* p) {
 __device__ __forceinline__ PlaneOut as_global(PlaneOut po) {
     po.hi = as_global(po.hi);
     po.lo = as_global(po.lo);
+    po.q8 = as_global(po.q8);
     return po;
 }
 

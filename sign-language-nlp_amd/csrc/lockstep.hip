@@ -116,8 +116,20 @@ static int upload(slnlp_tf_lockstep* ls, const void* host, size_t bytes, void** 
     return 0;
 }
 
+// Tables of one program are staged in ONE host blob and uploaded with one copy; ops hold offsets until then.
+struct Blob {
+    std::vector<char> bytes;
+    size_t add(const void* p, size_t n) {
+        const size_t at = (bytes.size() + 255) & ~(size_t)255;
+        bytes.resize(at + n);
+        memcpy(bytes.data() + at, p, n);
+        return at;
+    }
+};
+
 static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& prog, hipStream_t st) {
     const int K = (int)recs.size();
+    Blob blob;
     const size_t nops = recs[0].ops.size();
     for (int f = 1; f < K; ++f)
         SLNLP_CHECK_ARG(recs[f].ops.size() == nops, "lockstep: fit %d recorded %zu launches, fit 0 %zu -- not the same shape", f,
@@ -137,7 +149,7 @@ static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& pr
             SLNLP_CHECK_ARG(o0.grid.z == 1, "lockstep: call site %zu (%s) already uses grid.z", i, o0.what);
             std::vector<char> tab(o0.args.size() * K);
             for (int f = 0; f < K; ++f) memcpy(tab.data() + (size_t)f * o0.args.size(), recs[f].ops[i].args.data(), o0.args.size());
-            SLNLP_TRY(upload(ls, tab.data(), tab.size(), &m.tab, st));
+            m.tab = (void*)(blob.add(tab.data(), tab.size()) + 1);          // offset + 1 until the blob is uploaded
             m.grid = dim3(o0.grid.x, o0.grid.y, K);
         } else if (o0.kind == REC_PLANE_GROUP) {
             std::vector<PlaneJob> jobs;
@@ -152,10 +164,8 @@ static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& pr
                     jobs.push_back(job);
                 }
             }
-            SLNLP_TRY(upload(ls, jobs.data(), jobs.size() * sizeof(PlaneJob), &m.tab, st));
-            void* bm = nullptr;
-            SLNLP_TRY(upload(ls, map.data(), map.size() * sizeof(int), &bm, st));
-            m.blockmap = (int*)bm;
+            m.tab = (void*)(blob.add(jobs.data(), jobs.size() * sizeof(PlaneJob)) + 1);
+            m.blockmap = (int*)(blob.add(map.data(), map.size() * sizeof(int)) + 1);
             m.grid = dim3((unsigned)map.size());
         } else {
             std::vector<GemmJob> jobs;
@@ -170,13 +180,17 @@ static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& pr
                     jobs.push_back(job);
                 }
             }
-            SLNLP_TRY(upload(ls, jobs.data(), jobs.size() * sizeof(GemmJob), &m.tab, st));
-            void* bm = nullptr;
-            SLNLP_TRY(upload(ls, map.data(), map.size() * sizeof(int), &bm, st));
-            m.blockmap = (int*)bm;
+            m.tab = (void*)(blob.add(jobs.data(), jobs.size() * sizeof(GemmJob)) + 1);
+            m.blockmap = (int*)(blob.add(map.data(), map.size() * sizeof(int)) + 1);
             m.grid = dim3((unsigned)map.size());
         }
         prog.ops.push_back(std::move(m));
+    }
+    void* base = nullptr;
+    SLNLP_TRY(upload(ls, blob.bytes.data(), blob.bytes.size(), &base, st));
+    for (MergedOp& m : prog.ops) {
+        if (m.tab) m.tab = (char*)base + ((size_t)m.tab - 1);
+        if (m.blockmap) m.blockmap = (int*)((char*)base + ((size_t)m.blockmap - 1));
     }
     return 0;
 }
@@ -278,6 +292,7 @@ int slnlp_tf_lockstep_step(slnlp_tf_lockstep* ls, int slot, int64_t row0, int B,
     for (slnlp_tf_plan* pl : ls->plans) {
         SLNLP_TRY(pl->prepare_planes(B, st));      // re-zero plane padding when B changes
         SLNLP_TRY(pl->ensure_wplanes(st));         // never part of a recorded program: the update kernel keeps the planes current
+        SLNLP_TRY(pl->ensure_wq(st));              // precision 8: re-quantised weights, likewise outside the program
     }
     const auto key = std::make_tuple(slot, B, train ? 1 : 0);
     auto it = ls->programs.find(key);

@@ -85,14 +85,31 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     bool ok = attn_init() == 0 && gemm_planes_init() == 0;
     p->use_planes = (cfg->E % 64 == 0) && (cfg->F % 64 == 0);
     if (const char* e = getenv("SLNLP_TF_SIDE_STREAMS")) p->side_mode = atoi(e);
-    for (int k = 0; ok && k < NSIDE; ++k)
-        ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int l = 0; ok && l < cfg->N; ++l) {
-        hipEvent_t e = nullptr;
-        ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        if (ok) p->ev_kv.push_back(e);
+    if (p->side_mode > 0) {      // side streams / events only exist for the experimental forked modes
+        for (int k = 0; ok && k < NSIDE; ++k)
+            ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int l = 0; ok && l < cfg->N; ++l) {
+            hipEvent_t e = nullptr;
+            ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (ok) p->ev_kv.push_back(e);
+        }
+    }
+    if (ok && cfg->precision == 8) {     // rows the fp8 forward products read: one {offset, K} entry each, uploaded once
+        std::vector<QuantRow> rows;
+        auto block = [&](long off, int nrows, int K) {
+            p->qrow0[off] = (long)rows.size();
+            for (int r = 0; r < nrows; ++r) rows.push_back(QuantRow{off + (long)r * K, K, 0});
+        };
+        const int E = cfg->E, F = cfg->F;
+        for (int i = 0; i < cfg->N; ++i) {
+            const EncP& q = p->L.enc[i];
+            block(q.in_w, 3 * E, E); block(q.out_w, E, E); block(q.l1_w, F, E); block(q.l2_w, E, F);
+        }
+        for (int i = 0; i < cfg->N; ++i) block(p->L.dec[i].cin_w + (long)E * E, 2 * E, E);
+        ok = (long)rows.size() == p->w.n_qrows &&
+             hipMemcpy(p->w.qrow_table, rows.data(), rows.size() * sizeof(QuantRow), hipMemcpyHostToDevice) == hipSuccess;
     }
     // LN (dgamma, dbeta) reduction table: one entry per LayerNorm, uploaded once.  nblk is the FULL
     // batch's block count; smaller batches launch the same number of LN-backward blocks (nblk_force),
@@ -167,6 +184,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     if (up) {   // weights as bf16 planes: current unless the arena changed outside the fused optimizer step
         SLNLP_TRY(prepare_planes(B, st));
         SLNLP_TRY(ensure_wplanes(st));
+        SLNLP_TRY(ensure_wq(st));
     }
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st,
                         up ? w.x0p.out() : PlaneOut{}, w.emb_keep));

@@ -115,7 +115,9 @@ static int check_cfg(const slnlp_tf_config* c) {
     SLNLP_CHECK_ARG(c->S > 0 && c->S <= 5000, "tf: seq_len %d outside 1..5000", c->S);
     SLNLP_CHECK_ARG((long)c->B * c->S <= 65536, "tf: batch %d x seq_len %d exceeds 65536 tokens per step", c->B, c->S);
     SLNLP_CHECK_ARG(c->dropout >= 0.f && c->dropout < 1.f, "tf: dropout %f", c->dropout);
-    SLNLP_CHECK_ARG(c->precision == 1 || c->precision == 3, "tf: precision %d", c->precision);
+    SLNLP_CHECK_ARG(c->precision == 1 || c->precision == 3 || c->precision == 8, "tf: precision %d (1, 3 or 8)", c->precision);
+    SLNLP_CHECK_ARG(c->precision != 8 || (c->E % 128 == 0 && c->F % 128 == 0),
+                    "tf: precision 8 (fp8 forward products) needs embedding_size and hidden_size to be multiples of 128");
     return 0;
 }
 
@@ -140,7 +142,8 @@ struct Bump {
 // zero-padded to a multiple of 64): written once by the producer, read by gemm_planes.hip
 struct PP {
     unsigned short *hi = nullptr, *lo = nullptr;
-    PlaneOut out() const { PlaneOut o; o.hi = hi; o.lo = lo; return o; }
+    unsigned char* q8 = nullptr;        // precision 8: forward operands also as an e4m3 plane
+    PlaneOut out() const { PlaneOut o; o.hi = hi; o.lo = lo; o.q8 = q8; return o; }
 };
 struct EncA {
     float *qkv, *probs, *ctx, *y1, *st1, *x1, *h, *y2, *st2, *x2, *lnp1, *lnp2;
@@ -160,6 +163,10 @@ struct Ws {
     void *emb_scratch_src, *emb_scratch_tgt;
     unsigned char* emb_keep;   // 4 keep bits per float4 of the source embedding's dropout (read by its backward)
     PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
+    unsigned char* wq;                  // precision 8: e4m3 plane of the arena (same offsets; only the GEMM weight rows are filled)
+    float* wscale;                      // [qrows] per-row scales
+    QuantRow* qrow_table;               // [qrows] device table for the quantiser
+    long n_qrows;
     char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
     float* opt_partials;
     float* attn_scratch;    // S > 64: dS of one self-attention backward ([B,H,S,S], shared by all layers)
@@ -266,17 +273,28 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
     // ---- bf16 operand planes (only used when E and F are multiples of 64)
     const size_t Mp = (M + 63) / 64 * 64;
-    auto pp = [&](size_t cols) { PP q; q.hi = b.take<unsigned short>(Mp * cols); q.lo = b.take<unsigned short>(Mp * cols); return q; };
+    const bool q8 = c.precision == 8;
+    auto pp = [&](size_t cols, bool fwd_operand = false) {
+        PP q;
+        q.hi = b.take<unsigned short>(Mp * cols);
+        q.lo = b.take<unsigned short>(Mp * cols);
+        if (q8 && fwd_operand) q.q8 = b.take<unsigned char>(Mp * cols);
+        return q;
+    };
     const size_t wtot = (size_t)build_layout(c).total + 64 * 3 * (E > F ? E : F);   // tail pad: tiles may over-read rows
     w.wp.hi = b.take<unsigned short>(wtot);
     w.wp.lo = b.take<unsigned short>(wtot);
+    w.n_qrows = (long)c.N * (3 * E + E + F + E) + (long)c.N * 2 * E;      // in_proj, out_proj, linear1, linear2 | decoder K|V rows
+    w.wq = q8 ? b.take<unsigned char>(wtot) : nullptr;
+    w.wscale = q8 ? b.take<float>(w.n_qrows) : nullptr;
+    w.qrow_table = q8 ? b.take<QuantRow>(w.n_qrows) : nullptr;
     b.cur = (b.cur + 255) & ~(size_t)255;
     w.planes_begin = b.base + b.cur;
-    w.x0p = pp(E);
-    w.memp = pp(E);
+    w.x0p = pp(E, true);
+    w.memp = pp(E, true);
     for (int i = 0; i < c.N; ++i) {
         EncA& a = w.enc[i];
-        a.ctxp = pp(E); a.x1p = pp(E); a.hp = pp(F); a.x2p = pp(E);
+        a.ctxp = pp(E, true); a.x1p = pp(E, true); a.hp = pp(F, true); a.x2p = pp(E, true);
         a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
         w.dec[i].gkvp = pp(2 * E);
     }
@@ -325,6 +343,20 @@ struct slnlp_tf_plan {
     float* ls_logp = nullptr;       // [rows of the epoch, Vt]
     float* ls_loss = nullptr;       // [batches of the epoch]
     const int* ls_dyn = nullptr;    // {first row of the batch, index of the batch}
+    // precision 8: the forward products run on the fp8 MFMA (e4m3 activations, scale 1; e4m3 weights with one scale per
+    // output row, re-quantised from the fp32 master weights whenever the arena has moved); the backward stays split-bf16
+    int prec3() const { return cfg.precision == 8 ? 3 : cfg.precision; }
+    unsigned long long wq_gen = 0;
+    std::map<long, long> qrow0;          // arena offset of a quantised weight block -> its first row in wscale
+    int ensure_wq(hipStream_t st) {
+        if (cfg.precision != 8) return 0;
+        unsigned long long g = params_generation(buf.params);
+        if (g != 0 && g == wq_gen) return 0;
+        SLNLP_TRY(quant_rows_fp8(buf.params, 0, (int)w.n_qrows, 0, w.wq, 0, w.wscale, w.qrow_table, st));
+        if (g == 0) g = bump_params_generation(buf.params);
+        wq_gen = g;
+        return 0;
+    }
     unsigned long long wplanes_gen = 0;   // generation of the parameter arena the weight planes were made from (0: never)
     // weights as bf16 planes: made by the optimizer kernel of the previous step, or here when the arena has changed since
     int ensure_wplanes(hipStream_t st) {
@@ -398,7 +430,7 @@ struct slnlp_tf_plan {
         a.bias = bias; a.relu = relu;
         a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
         a.resid = resid; a.ldr = ldy;
-        a.precision = cfg.precision;
+        a.precision = prec3();
         a.drop_head_dim = drop_head_dim;
         return gemm(a, st);
     }
@@ -412,7 +444,7 @@ struct slnlp_tf_plan {
         a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
         a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
         a.resid = resid; a.ldr = Kin;
-        a.precision = cfg.precision;
+        a.precision = prec3();
         return a;
     }
     int dgrad(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx, const float* gate,
@@ -427,7 +459,7 @@ struct slnlp_tf_plan {
         a.B = x; a.ldb = Kin; a.b_kmajor = 0;
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
-        a.precision = cfg.precision;
+        a.precision = prec3();
         return a;
     }
     int wgrad(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db,
@@ -444,6 +476,18 @@ struct slnlp_tf_plan {
                  int site, const float* resid, const PP* outp, hipStream_t st) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
+        if (cfg.precision == 8) {       // fp8 forward product: e4m3 planes, per-row weight scales
+            a.A_hi = reinterpret_cast<const uint16_t*>(x.q8); a.lda_p = K; a.a_kmajor = 1;
+            a.B_hi = reinterpret_cast<const uint16_t*>(w.wq + woff); a.ldb_p = K; a.b_kmajor = 1;
+            a.col_scale = w.wscale + qrow0.at(woff);
+            a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+            a.bias = bias; a.relu = relu;
+            a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
+            a.resid = resid; a.ldr = ldy;
+            if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.C_q8 = outp->q8; a.ldc_p = N; }
+            a.precision = 8;
+            return gemm(a, st);
+        }
         a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
         a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; a.b_kmajor = 1;
         a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
@@ -451,7 +495,7 @@ struct slnlp_tf_plan {
         a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
         a.resid = resid; a.ldr = ldy;
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
-        a.precision = cfg.precision;
+        a.precision = prec3();
         return gemm(a, st);
     }
     slnlp_gemm_args dgrad_p_args(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
@@ -464,7 +508,7 @@ struct slnlp_tf_plan {
         a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
         a.resid = resid; a.ldr = Kin;
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = Kin; }
-        a.precision = cfg.precision;
+        a.precision = prec3();
         return a;
     }
     int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
@@ -478,7 +522,7 @@ struct slnlp_tf_plan {
         a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
-        a.precision = cfg.precision;
+        a.precision = prec3();
         return a;
     }
     int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {

@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("resid", vp), ("ldr", i64),
                 ("rowsum_a", vp), ("precision", i32), ("gate_mode", i32),
                 ("A_hi", vp), ("A_lo", vp), ("lda_p", i64), ("B_hi", vp), ("B_lo", vp), ("ldb_p", i64),
-                ("C_hi", vp), ("C_lo", vp), ("ldc_p", i64), ("drop_head_dim", i32)]
+                ("C_hi", vp), ("C_lo", vp), ("ldc_p", i64), ("drop_head_dim", i32),
+                ("col_scale", vp), ("C_q8", vp)]
 
 
 class TfConfig(C.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "slnlp_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "slnlp_gemm_group_scratch_bytes": (i64, [C.POINTER(GemmArgs), C.POINTER(i32), i32]),
     "slnlp_gemm_group": (i32, [C.POINTER(GemmArgs), C.POINTER(i32), i32, vp, i64, vp]),
+    "slnlp_quant_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
     "slnlp_split_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp]),
     "slnlp_embed_fwd": (i32, [vp, i64, i32, i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, i64, vp]),
     "slnlp_embed_bwd_scratch_bytes": (i64, [i32, i32, i32]),

@@ -50,6 +50,39 @@ def split_planes(x, want_lo=True):
     return hi, lo
 
 
+def pad128(n):
+    return (n + 127) // 128 * 128
+
+
+def quant_rows_fp8(x):
+    """fp32 [R,K] -> (q uint8 [pad64(R), pad128(K)] OCP e4m3, scale fp32 [R]): q[r] = e4m3(x[r] / scale[r]), scale[r] = max|x[r]| / 448."""
+    _lib.require_gpu()
+    R, K = x.shape
+    q = torch.zeros(pad64(R), pad128(K), dtype=torch.uint8, device=x.device)
+    scale = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(load().slnlp_quant_rows_fp8(ptr(x), x.stride(0), R, K, ptr(q), q.stride(0), ptr(scale), stream_ptr()), "quant_rows_fp8")
+    return q, scale
+
+
+def gemm_fp8(Aq, Bq, *, M, N, K, col_scale=None, bias=None, relu=False, resid=None, out=None, want_q8=False):
+    """C = (A8 B8^T) * col_scale (+ bias, relu, resid) over e4m3 byte planes (both k-major) on the fp8 MFMA (precision 8)."""
+    _lib.require_gpu()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=Aq.device)
+    a = GemmArgs()
+    a.C, a.ldc, a.M, a.N, a.K = ptr(out), out.stride(0), M, N, K
+    a.a_kmajor, a.b_kmajor, a.precision = 1, 1, 8
+    a.A_hi, a.lda_p, a.B_hi, a.ldb_p = ptr(Aq), Aq.stride(0), ptr(Bq), Bq.stride(0)
+    a.col_scale, a.bias, a.relu = ptr(col_scale), ptr(bias), int(relu)
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    cq = None
+    if want_q8:
+        cq = torch.zeros(pad64(M), pad128(N), dtype=torch.uint8, device=out.device)
+        a.C_q8, a.ldc_p = ptr(cq), cq.stride(0)
+    check(load().slnlp_gemm(C.byref(a), stream_ptr()), "gemm_fp8")
+    return (out, cq) if want_q8 else out
+
+
 def plane_job(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, precision=3, rowsum_a=None, bias=None,
               relu=False, resid=None):
     """GemmArgs of one pre-split GEMM (for gemm_group); returns (args, out)."""
