@@ -86,6 +86,11 @@ typedef struct slnlp_gemm_args {
      * per-row scale of a quantised weight matrix.  C_q8 (optional): also emit the result as an e4m3 plane, row stride ldc_p. */
     const float* col_scale;
     uint8_t* C_q8;
+    /* batch > 1 (fp32-operand jobs of slnlp_gemm_group only): the job is `batch` GEMMs of this shape; GEMM z reads
+     * A + z * batch_stride_a, B + z * batch_stride_b and writes C + z * batch_stride_c (resid, when set, moves with C) --
+     * e.g. the per-head products of the decoder's cross-attention (attention_mem.hip).  0 or 1: a single GEMM. */
+    int32_t batch;
+    int64_t batch_stride_a, batch_stride_b, batch_stride_c;
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);

@@ -178,6 +178,13 @@ int attn_cross_fwd(const float* q, const float* kv, int64_t ld_kv, int B, int S,
 int attn_cross_bwd(const float* q, const float* kv, int64_t ld_kv, const float* probs, const float* dctx, int B,
                    int S, int H, int dh, float* dq, float* dkv, int64_t ld_dkv, float drop_p, int drop_site,
                    const unsigned long long* rng, hipStream_t st, PlaneOut po = {});
+// decoder cross-attention for a target of length 1 without K / V projections of the memory (attention_mem.hip); the
+// per-head weight products around these run as batched GEMM jobs (tf_plan.hip)
+int xmem_fwd(const float* qk, const float* mem, const float* bv, int B, int S, int H, int dh, float* mbar, float* psum, float* probs,
+             float* ctx0, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+int xmem_bwd(const float* mem, const float* bv, const float* probs, const float* psum, const float* qk, const float* dmbar,
+             const float* dctx, int B, int S, int H, int dh, float* dsc, float* dqk, float* dcp, float* dbv, float* dmem, int accumulate,
+             float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                   float* stats, hipStream_t st, PlaneOut po = {});
 int ln_bwd_blocks(int rows);

@@ -360,6 +360,14 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupParams P
         p = P.job[j]; variant = P.variant[j]; gx = P.gx[j]; gy = P.gy[j]; lid = blockIdx.x - P.block_begin[j];
     }
     launder(p.a);
+    if (p.a.batch > 1) {                    // `batch` GEMMs of one shape: this block belongs to GEMM z
+        const int z = lid / (gx * gy);
+        lid -= z * gx * gy;
+        p.a.A += (long)z * p.a.batch_stride_a;
+        p.a.B += (long)z * p.a.batch_stride_b;
+        p.a.C += (long)z * p.a.batch_stride_c;
+        if (p.a.resid) p.a.resid += (long)z * p.a.batch_stride_c;
+    }
     const int bx = lid % gx, by = lid / gx;
     switch (variant) {
         case 0: gemm_tile<NSPLIT, true, true, 64, true>(p, bx, by, gx, gy, smem); break;
@@ -457,14 +465,28 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
         P.gx[i] = ceil_div(a.N, narrow ? 16 : 64);
         P.gy[i] = ceil_div(a.M, BM);
         P.block_begin[i] = blocks;
-        blocks += P.gx[i] * P.gy[i];
+        const int nb = a.batch > 1 ? a.batch : 1;
+        SLNLP_CHECK_ARG(nb == 1 || (!a.bias && !a.gate && !a.rowsum_a && a.drop_p == 0.f), "gemm_group: a batched job takes a residual only");
+        SLNLP_CHECK_ARG(nb == 1 || (a.batch_stride_a % 4 == 0 && a.batch_stride_b % 4 == 0), "gemm_group: batch strides must keep 16-byte alignment");
+        blocks += P.gx[i] * P.gy[i] * nb;
     }
     if (recording()) {
         SLNLP_CHECK_ARG(fusable, "gemm_group: an operand that cannot take 16-byte loads cannot join a lockstep launch");
         return record_op(gemm_group_kernel_ptr(jobs[0].precision), dim3(blocks), dim3(256), 0, REC_GEMM_GROUP, &P, sizeof(P), "gemm_group");
     }
-    if (!fusable || njobs == 1) {
-        for (int i = 0; i < njobs; ++i) SLNLP_TRY(gemm(jobs[i], s));
+    bool batched = false;
+    for (int i = 0; i < njobs; ++i) batched = batched || jobs[i].batch > 1;
+    if (!fusable || (njobs == 1 && !batched)) {
+        for (int i = 0; i < njobs; ++i) {
+            const int nb = jobs[i].batch > 1 ? jobs[i].batch : 1;
+            for (int z = 0; z < nb; ++z) {                     // (operands without 16-byte alignment: one launch per GEMM)
+                slnlp_gemm_args a = jobs[i];
+                a.batch = 0;
+                a.A += (long)z * jobs[i].batch_stride_a; a.B += (long)z * jobs[i].batch_stride_b; a.C += (long)z * jobs[i].batch_stride_c;
+                if (a.resid) a.resid += (long)z * jobs[i].batch_stride_c;
+                SLNLP_TRY(gemm(a, s));
+            }
+        }
         return SLNLP_OK;
     }
     if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_group_kernel<3>, dim3(blocks), dim3(256), 0, s, P, (const GemmJob*)nullptr, (const int*)nullptr);

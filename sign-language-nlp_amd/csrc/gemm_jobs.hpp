@@ -37,6 +37,7 @@ struct PlaneJob {
     float drop_scale;
     int variant;        // 0: A,B k-major   1: A k-major, B m-major   2: A,B m-major
     int tiles_x, tiles_y, nks, block_begin;
+    int vec_out;        // epilogue may use 16-byte row pieces (N % 4 == 0, aligned C / residual / planes)
     float* part;        // [tile][nks][PTHREADS * 8]
     float* part_rs;     // [tile_y][nks][PT]     (row sums of A)
     int* counters;      // [tiles], zero outside a launch

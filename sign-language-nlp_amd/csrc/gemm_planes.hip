@@ -210,6 +210,65 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
 
     // ---- epilogue: +bias -> activation -> gate -> dropout -> +resid ; fp32 store (+ optional bf16 planes)
     const int crow = (lane >> 4) << 2, ccol = lane & 15;
+    if (job.vec_out) {
+        // Two phases.  (1) In the accumulator layout (a lane holds 4 rows x 1 column): bias, activation, gate and dropout -- the
+        // Philox call serves the lane's 4 rows -- and the value goes to an LDS image of the tile.  (2) Row-major: each thread
+        // takes 4 consecutive columns of a row, adds the residual and writes ONE 16-byte fp32 store and two 8-byte plane
+        // stores.  The accumulator layout alone needs 8 dword + 16 short stores per lane in 64- / 32-byte row segments;
+        // the element-wise arithmetic and its order are the same, so results are bit-identical.
+        constexpr int SLD = PT + 4;
+        float* stg = reinterpret_cast<float*>(smem);
+        __syncthreads();                                     // every thread is done with the K-loop stages / the split-K flag
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gm0 = bm0 + wm0 + crow, gn = bn0 + wn0 + j * 16 + ccol;
+            const bool live = gn < N && gm0 < M;
+            const float bias = (live && g.bias) ? g.bias[gn] : 0.f;
+            uint4 bits = make_uint4(0, 0, 0, 0);
+            if (live && g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = gm0 + r;
+                float v = acc[j][r] + bias;
+                if (g.relu == 1) v = fmaxf(v, 0.f);
+                else if (g.relu == 2) v = tanhf(v);
+                if (live && gm < M) {
+                    if (g.gate) {
+                        const float gt = g.gate[(long)gm * g.ldg + gn];
+                        v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
+                    }
+                    if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                }
+                stg[(wm0 + crow + r) * SLD + wn0 + j * 16 + ccol] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 32 + (tid >> 4), c4 = (tid & 15) << 2;
+            const int gm = bm0 + row, gn = bn0 + c4;
+            if (gm >= M || gn >= N) continue;                 // N % 4 == 0 (vec_out): a live piece is 4 live columns
+            float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+            if (g.resid) {
+                const float4 rr = *reinterpret_cast<const float4*>(g.resid + (long)gm * g.ldr + gn);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (g.C) *reinterpret_cast<float4*>(g.C + (long)gm * g.ldc + gn) = v;
+            if (g.C_hi) {
+                PlaneOut po;
+                po.hi = g.C_hi;
+                po.lo = g.C_lo;
+                if (g.C_lo) store_planes4(po, (long)gm * g.ldc_p + gn, v);
+                else {
+                    uint2 w;
+                    w.x = (__float_as_uint(v.x) >> 16) | (__float_as_uint(v.y) & 0xFFFF0000u);
+                    w.y = (__float_as_uint(v.z) >> 16) | (__float_as_uint(v.w) & 0xFFFF0000u);
+                    *reinterpret_cast<uint2*>(g.C_hi + (long)gm * g.ldc_p + gn) = w;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int gm0 = bm0 + wm0 + crow;
@@ -438,6 +497,10 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
         j.drop_thr = dropout_threshold(a.drop_p);
         j.drop_scale = 1.f / (1.f - a.drop_p);
         j.variant = a.precision == 8 ? 3 : (a.a_kmajor && a.b_kmajor) ? 0 : a.a_kmajor ? 1 : 2;
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        j.vec_out = a.N % 4 == 0 && (!a.C || (a.ldc % 4 == 0 && al16(a.C))) && (!a.resid || (a.ldr % 4 == 0 && al16(a.resid))) &&
+                    (!a.C_hi || (a.ldc_p % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C_hi) & 7) == 0 &&
+                                 (!a.C_lo || (reinterpret_cast<uintptr_t>(a.C_lo) & 7) == 0)));
         if (a.precision == 8) SLNLP_CHECK_ARG(!split_k || split_k[i] <= 1, "gemm_group: fp8 jobs do not split K");
         j.tiles_x = ceil_div(a.N, PT);
         j.tiles_y = ceil_div(a.M, PT);

@@ -176,7 +176,7 @@ static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& pr
                     GemmJob job;
                     job.p = P->job[j]; job.variant = P->variant[j]; job.gx = P->gx[j]; job.gy = P->gy[j];
                     job.block_begin = (int)map.size();
-                    map.insert(map.end(), job.gx * job.gy, (int)jobs.size());
+                    map.insert(map.end(), job.gx * job.gy * (job.p.a.batch > 1 ? job.p.a.batch : 1), (int)jobs.size());
                     jobs.push_back(job);
                 }
             }

@@ -64,7 +64,6 @@ void slnlp_tf_destroy(slnlp_tf_plan* plan) {
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
     }
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-    for (hipEvent_t e : plan->ev_kv) (void)hipEventDestroy(e);
     delete plan;
 }
 
@@ -90,11 +89,6 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
             ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int l = 0; ok && l < cfg->N; ++l) {
-            hipEvent_t e = nullptr;
-            ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            if (ok) p->ev_kv.push_back(e);
-        }
     }
     if (ok && cfg->precision == 8) {     // rows the fp8 forward products read: one {offset, K} entry each, uploaded once
         std::vector<QuantRow> rows;
@@ -107,7 +101,6 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
             const EncP& q = p->L.enc[i];
             block(q.in_w, 3 * E, E); block(q.out_w, E, E); block(q.l1_w, F, E); block(q.l2_w, E, F);
         }
-        for (int i = 0; i < cfg->N; ++i) block(p->L.dec[i].cin_w + (long)E * E, 2 * E, E);
         ok = (long)rows.size() == p->w.n_qrows &&
              hipMemcpy(p->w.qrow_table, rows.data(), rows.size() * sizeof(QuantRow), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -175,8 +168,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     // query projection: five B-row launches) depends on nothing the encoder computes: it runs on side[1] next to the
     // encoder and is joined right before layer 0's cross-attention.
     in_backward = false;
-    hipStream_t f0 = side_or(st, 0), f1 = side_or(st, 1);
-    const bool fwd_forks = forks_on();
+    hipStream_t f1 = side_or(st, 1);
     SLNLP_TRY(fork(st, 1));
     SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, f1));
     SLNLP_TRY(dec_self_block(0, w.t0, B, p, f1));
@@ -216,34 +208,23 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     }
     SLNLP_TRY(layernorm_fwd(x, pl->P(L.encn_w), pl->P(L.encn_b), M, E, 1e-5f, w.mem, w.st_mem, st, up ? w.memp.out() : PlaneOut{}));
 
-    // memory K|V projections of ALL decoder layers depend only on `mem`: run them on side[0]
-    // while the main stream walks the decoder's chain of small (B-row) kernels.
-    SLNLP_TRY(fork(st, 0));
-    for (int l = 0; l < c.N; ++l) {
-        const DecP& q = L.dec[l];
-        if (up)
-            SLNLP_TRY(pl->linear_p(w.memp, M, E, q.cin_w + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0, 0.f, 0,
-                                   nullptr, nullptr, f0));
-        else
-            SLNLP_TRY(pl->linear(w.mem, M, E, pl->P(q.cin_w) + (long)E * E, 2 * E, pl->P(q.cin_b) + E, w.dec[l].kv, 2 * E, 0,
-                                 0.f, 0, nullptr, f0));
-        if (fwd_forks && hipEventRecord(ev_kv[l], side[0]) != hipSuccess) {
-            set_error("tf_forward: event record failed");
-            return SLNLP_ERR_LAUNCH;
-        }
-    }
-
     const float* t = w.t0;
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
         if (l == 0) SLNLP_TRY(join(st, 1));                     // layer 0's block ran on side[1] (above)
         else SLNLP_TRY(dec_self_block(l, t, B, p, st));
-        if (fwd_forks && hipStreamWaitEvent(st, ev_kv[l], 0) != hipSuccess) {
-            set_error("tf_forward: wait for K/V projection failed");
-            return SLNLP_ERR_LAUNCH;
+        // cross-attention over the memory itself: with ONE query per sequence the K / V projections of the S memory rows
+        // re-associate into B-row products (attention_mem.hip) -- no [S*B, 2E] projection, no K|V gradient GEMMs:
+        // qk = Wk_h^T q_h (batched GEMM) -> scores / softmax / dropout / mbar (+ ctx0 = bv sum_s p_s) -> ctx = Wv_h mbar + ctx0
+        {
+            const float *Wk = pl->P(q.cin_w) + (long)E * E, *Wv = pl->P(q.cin_w) + 2L * E * E;
+            const slnlp_gemm_args j1 = pl->head_expand(a.q, Wk, a.qk, B, H, dh);
+            SLNLP_TRY(gemm_group(&j1, 1, st));
+            SLNLP_TRY(xmem_fwd(a.qk, w.mem, pl->P(q.cin_b) + 2 * E, B, S, H, dh, a.mbar, a.psum, a.xprobs, a.xctx, p, pl->dec_site(l, 2), rng, st));
+            const slnlp_gemm_args j2 = pl->head_reduce(a.mbar, Wv, a.xctx, a.xctx, B, H, dh);
+            SLNLP_TRY(gemm_group(&j2, 1, st));
         }
-        SLNLP_TRY(attn_cross_fwd(a.q, a.kv, 2 * E, B, S, H, dh, a.xctx, a.xprobs, p, pl->dec_site(l, 2), rng, st));
         SLNLP_TRY(pl->linear(a.xctx, B, E, pl->P(q.cout_w), E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, st));
         SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st));
         SLNLP_TRY(pl->linear(a.t2, B, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, st));
@@ -251,7 +232,6 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st));
         t = a.t3;
     }
-    side_dirty[0] = false;  // every ev_kv has been waited for: side[0] is joined
     SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
     SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
     // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70)
@@ -282,7 +262,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
     pl->in_backward = true;
-    hipStream_t s0 = pl->side_or(st, 0), s1 = pl->side_or(st, 1);
+    hipStream_t s1 = pl->side_or(st, 1);
     const slnlp_tf_config& c = pl->cfg;
     const Ws& w = pl->w;
     const Layout& L = pl->L;
@@ -293,9 +273,8 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     const bool up = pl->use_planes;
     int nb;
     // Everything runs on the main stream; the weight gradient of each dY shares a launch with its data gradient.
-    // Only the (large, independent) d memory / K|V weight-gradient groups go to side[0] and the target-embedding
-    // gradient to side[1]: graph replay places parallel branches on its own queues and every cross-queue edge
-    // costs 4-10 us, so fine-grained forks were measured slower than no forks.
+    // (side_mode > 0, experimental: layer 0's self-attention gradient tail and the target-embedding gradient may go to
+    // side[1]; the default runs every launch on the caller's stream -- tf_plan.hpp, side_mode.)
 
     // generator: logits = tfin lin_w^T + lin_b
     SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b)),
@@ -321,18 +300,19 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d2, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b)),
                                  pl->dgrad_args(d2, E, B, E, pl->P(q.cout_w), E, a.gxctx, nullptr, 0.f, nullptr), st));
-        SLNLP_TRY(attn_cross_bwd(a.q, a.kv, 2 * E, a.xprobs, a.gxctx, B, S, H, dh, a.gq, a.gkv, 2 * E, p, pl->dec_site(l, 2), rng, st,
-                                 up ? a.gkvp.out() : PlaneOut{}));
-        // d memory accumulates over the decoder layers in a fixed order on side[0], next to its weight gradient
-        SLNLP_TRY(pl->fork(st, 0));
-        if (up) {
-            SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gkvp, 2 * E, M, 2 * E, w.memp, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E),
-                                   pl->dgrad_p_args(a.gkvp, 2 * E, M, 2 * E, q.cin_w + (long)E * E, E, w.gmem, nullptr, 0.f,
-                                                    l == c.N - 1 ? nullptr : w.gmem, nullptr), 1, s0));
-        } else {
-            SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gkv, 2 * E, M, 2 * E, w.mem, E, pl->G(q.cin_w) + (long)E * E, pl->G(q.cin_b) + E),
-                                     pl->dgrad_args(a.gkv, 2 * E, M, 2 * E, pl->P(q.cin_w) + (long)E * E, E, w.gmem, nullptr, 0.f,
-                                                    l == c.N - 1 ? nullptr : w.gmem), s0));
+        // d ctx -> d mbar = Wv_h^T d ctx_h (batched GEMM) -> d scores, d qk, d memory (accumulated over the decoder layers in
+        // layer order), d bv -> ONE launch of three batched jobs: d q_h = Wk_h d qk, d Wk_h = q_h^T (x) d qk, d Wv_h = d ctx_h^T (x) mbar.
+        // d bk is exactly zero (a shift of all scores): nothing writes it, the gradient arena was zeroed at plan creation.
+        {
+            const float *Wk = pl->P(q.cin_w) + (long)E * E, *Wv = pl->P(q.cin_w) + 2L * E * E;
+            const slnlp_gemm_args j1 = pl->head_expand(a.gxctx, Wv, a.dmbar, B, H, dh);
+            SLNLP_TRY(gemm_group(&j1, 1, st));
+            SLNLP_TRY(xmem_bwd(w.mem, pl->P(q.cin_b) + 2 * E, a.xprobs, a.psum, a.qk, a.dmbar, a.gxctx, B, S, H, dh, a.dsc, a.dqk, a.dcp,
+                               pl->G(q.cin_b) + 2 * E, w.gmem, l == c.N - 1 ? 0 : 1, p, pl->dec_site(l, 2), rng, st));
+            const slnlp_gemm_args jobs[3] = {pl->head_reduce(a.dqk, Wk, a.gq, nullptr, B, H, dh),
+                                             pl->head_wgrad(a.q, a.dqk, pl->G(q.cin_w) + (long)E * E, B, H, dh),
+                                             pl->head_wgrad(a.gxctx, a.mbar, pl->G(q.cin_w) + 2L * E * E, B, H, dh)};
+            SLNLP_TRY(gemm_group(jobs, 3, st));
         }
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b)),
                                  pl->dgrad_args(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2), st));
@@ -360,7 +340,6 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s1));
 
     // encoder: needs the complete d memory
-    SLNLP_TRY(pl->join(st, 0));
     SLNLP_TRY(layernorm_bwd(w.gmem, w.enc[c.N - 1].x2, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.gxl, nullptr, 0.f, 0,
                             rng, w.lnp_mem, &nb, pl->nbE, st));
     const float* dx = w.gxl;
@@ -525,9 +504,9 @@ int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_byt
     for (int i = 0; i < cfg->N; ++i) {
         const DecA& a = w.dec[i];
         const std::string pre = "dec" + std::to_string(i) + ".";
-        F(pre, a, v); F(pre, a, y1); F(pre, a, st1); F(pre, a, t1); F(pre, a, q); F(pre, a, kv); F(pre, a, xprobs); F(pre, a, xctx); F(pre, a, y2);
+        F(pre, a, v); F(pre, a, y1); F(pre, a, st1); F(pre, a, t1); F(pre, a, q); F(pre, a, qk); F(pre, a, mbar); F(pre, a, psum); F(pre, a, xprobs); F(pre, a, xctx); F(pre, a, y2);
         F(pre, a, st2); F(pre, a, t2); F(pre, a, h); F(pre, a, y3); F(pre, a, st3); F(pre, a, t3); F(pre, a, lnp1); F(pre, a, lnp2); F(pre, a, lnp3);
-        F(pre, a, gA3); F(pre, a, gB3); F(pre, a, gh); F(pre, a, gt2); F(pre, a, gA2); F(pre, a, gB2); F(pre, a, gxctx); F(pre, a, gq); F(pre, a, gkv);
+        F(pre, a, gA3); F(pre, a, gB3); F(pre, a, gh); F(pre, a, gt2); F(pre, a, gA2); F(pre, a, gB2); F(pre, a, gxctx); F(pre, a, gq); F(pre, a, dmbar); F(pre, a, dsc); F(pre, a, dqk); F(pre, a, dcp);
         F(pre, a, gt1); F(pre, a, gA1); F(pre, a, gB1); F(pre, a, gv); F(pre, a, gt0);
     }
 #undef F

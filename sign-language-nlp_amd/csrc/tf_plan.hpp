@@ -151,9 +151,10 @@ struct EncA {
     PP ctxp, x1p, hp, x2p, d2p, ghp, d1p, gqkvp;
 };
 struct DecA {
-    float *v, *y1, *st1, *t1, *q, *kv, *xprobs, *xctx, *y2, *st2, *t2, *h, *y3, *st3, *t3, *lnp1, *lnp2, *lnp3;
-    float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gkv, *gt1, *gA1, *gB1, *gv, *gt0;
-    PP gkvp;
+    float *v, *y1, *st1, *t1, *q, *xprobs, *xctx, *y2, *st2, *t2, *h, *y3, *st3, *t3, *lnp1, *lnp2, *lnp3;
+    float *qk, *mbar, *psum;                 // cross-attention without K / V projections (attention_mem.hip): kept for the backward
+    float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gt1, *gA1, *gB1, *gv, *gt0;
+    float *dmbar, *dsc, *dqk, *dcp;          // its gradients: d mbar, d scores, d qk [B*H, .], d ctx * sum_s p_s [B, E]
 };
 struct Ws {
     float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp, *row_nll;
@@ -225,7 +226,9 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.st1 = b.take<float>(B * 2);
         a.t1 = b.take<float>(B * E);
         a.q = b.take<float>(B * E);
-        a.kv = b.take<float>(M * 2 * E);
+        a.qk = b.take<float>(B * H * E);
+        a.mbar = b.take<float>(B * H * E);
+        a.psum = b.take<float>(B * H);
         a.xprobs = b.take<float>(B * H * S);
         a.xctx = b.take<float>(B * E);
         a.y2 = b.take<float>(B * E);
@@ -246,7 +249,10 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.gB2 = b.take<float>(B * E);
         a.gxctx = b.take<float>(B * E);
         a.gq = b.take<float>(B * E);
-        a.gkv = b.take<float>(M * 2 * E);
+        a.dmbar = b.take<float>(B * H * E);
+        a.dsc = b.take<float>(B * H * S);
+        a.dqk = b.take<float>(B * H * E);
+        a.dcp = b.take<float>(B * E);
         a.gt1 = b.take<float>(B * E);
         a.gA1 = b.take<float>(B * E);
         a.gB1 = b.take<float>(B * E);
@@ -284,7 +290,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     const size_t wtot = (size_t)build_layout(c).total + 64 * 3 * (E > F ? E : F);   // tail pad: tiles may over-read rows
     w.wp.hi = b.take<unsigned short>(wtot);
     w.wp.lo = b.take<unsigned short>(wtot);
-    w.n_qrows = (long)c.N * (3 * E + E + F + E) + (long)c.N * 2 * E;      // in_proj, out_proj, linear1, linear2 | decoder K|V rows
+    w.n_qrows = (long)c.N * (3 * E + E + F + E);                          // encoder in_proj, out_proj, linear1, linear2
     w.wq = q8 ? b.take<unsigned char>(wtot) : nullptr;
     w.wscale = q8 ? b.take<float>(w.n_qrows) : nullptr;
     w.qrow_table = q8 ? b.take<QuantRow>(w.n_qrows) : nullptr;
@@ -296,7 +302,6 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         EncA& a = w.enc[i];
         a.ctxp = pp(E, true); a.x1p = pp(E, true); a.hp = pp(F, true); a.x2p = pp(E, true);
         a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
-        w.dec[i].gkvp = pp(2 * E);
     }
     {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
         const size_t tx = ((E > F ? E : F) + 63) / 64, ty = ((3 * E > F ? 3 * E : F) + 63) / 64;
@@ -336,7 +341,6 @@ struct slnlp_tf_plan {
     // capture the forks become parallel branches of the hipGraph.
     hipStream_t side[NSIDE] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev_kv;
     bool side_dirty[NSIDE] = {false, false};
     // Lockstep (lockstep.hip): where this fit's per-step outputs go while it advances as one of K fits -- an epoch-long
     // log-prob buffer and a per-batch loss history, indexed through two device scalars the driver updates per step
@@ -465,6 +469,38 @@ struct slnlp_tf_plan {
     int wgrad(const float* dy, long ldy, int T, int Nout, const float* x, int Kin, float* dW, float* db,
               hipStream_t st) const {
         return gemm(wgrad_args(dy, ldy, T, Nout, x, Kin, dW, db), st);
+    }
+    // `H` GEMMs of one shape in one job (gemm.hip, batched jobs): GEMM h reads A + h*sa, B + h*sb and writes C + h*sc
+    static slnlp_gemm_args batched(slnlp_gemm_args a, int H, long sa, long sb, long sc) {
+        a.batch = H; a.batch_stride_a = sa; a.batch_stride_b = sb; a.batch_stride_c = sc;
+        return a;
+    }
+    // per-head products of the decoder's cross-attention (attention_mem.hip); W = rows h*dh.. of a [E, E] block of in_proj
+    // x[B, H*dh] (columns h*dh..) -> out[B, H, E]:  out_h = x_h W_h      (qk = Wk_h^T q_h;  d mbar = Wv_h^T d ctx_h)
+    slnlp_gemm_args head_expand(const float* x, const float* W, float* out, int B, int H, int dh) const {
+        const int E = H * dh;
+        slnlp_gemm_args a = dgrad_args(x, E, B, dh, W, E, out, nullptr, 0.f, nullptr);
+        a.ldc = (long)H * E;
+        return batched(a, H, dh, (long)dh * E, E);
+    }
+    // x[B, H, E] -> out[B, H*dh] (columns h*dh..):  out_h = x_h W_h^T (+ resid in place)      (ctx_h = Wv_h mbar;  d q_h = Wk_h d qk)
+    slnlp_gemm_args head_reduce(const float* x, const float* W, float* out, const float* resid, int B, int H, int dh) const {
+        const int E = H * dh;
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A = x; a.lda = (long)H * E; a.a_kmajor = 1;
+        a.B = W; a.ldb = E; a.b_kmajor = 1;
+        a.C = out; a.ldc = E; a.M = B; a.N = dh; a.K = E;
+        a.resid = resid; a.ldr = E;
+        a.precision = prec3();
+        return batched(a, H, E, (long)dh * E, dh);
+    }
+    // dW_h[dh, E] = dy_h^T x_h:  dy[B, H*dh] (columns h*dh..), x[B, H, E], dW = rows h*dh.. of an [E, E] gradient block
+    slnlp_gemm_args head_wgrad(const float* dy, const float* x, float* dW, int B, int H, int dh) const {
+        const int E = H * dh;
+        slnlp_gemm_args a = wgrad_args(dy, E, B, dh, x, E, dW, nullptr);
+        a.ldb = (long)H * E;
+        return batched(a, H, dh, E, (long)dh * E);
     }
     // weight- and data-gradient of one dY (fp32 operands) in one launch
     int wd_group_f(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, hipStream_t st) const {
