@@ -27,6 +27,37 @@ namespace slnlp {
 // 450 KB of weight rows per workgroup through dependent loads -- the cfg2 step went from 3.21 to 4.07 ms.)  What stays
 // here touches only the memory rows: scores, softmax, dropout, the weighted sums over s, and their gradients.
 
+// dots of an LDS vector v[E] with memory rows s = wave, wave + 4, ... of sequence b: FOUR rows per trip, so their loads are
+// in flight together (one row per trip left each wave with a dependent load -> reduce chain per row: 19 us per kernel)
+// workgroups go round-robin over the 8 XCDs, each with its own L2: with bh = blockIdx.x the H heads of a sequence sit on H
+// different XCDs and every XCD streams ALL of mem (4.9 MB at cfg2, more than its 4 MB L2) -- 19 us per kernel.  Give XCD x the
+// contiguous range [x nb/8, (x+1) nb/8) instead: each L2 then holds only the ~B/8 sequences its workgroups share.
+__device__ __forceinline__ int xcd_local(int i, int nb) { return (nb & 7) == 0 ? (i & 7) * (nb >> 3) + (i >> 3) : i; }
+
+template <class F>
+__device__ __forceinline__ void row_dots(const float* __restrict__ v, const float* __restrict__ mem, int B, int b, int S, int E, int lane,
+                                         int wave, F&& put) {
+    for (int s0 = wave; s0 < S; s0 += 16) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < S) {
+                const float* mr = mem + ((long)s * B + b) * E;
+                for (int e = lane * 4; e < E; e += 256) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mr + e), q4 = *reinterpret_cast<const float4*>(v + e);
+                    a[u] += q4.x * m4.x + q4.y * m4.y + q4.z * m4.z + q4.w * m4.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float r = wave_sum(a[u]);
+            if (lane == 0 && s0 + 4 * u < S) put(s0 + 4 * u, r);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- forward ----
 // qk [B*H, E] (from the batched GEMM); mem rows m = s*B + b, [S*B, E]; outputs: mbar [B*H, E], psum [B*H],
 // probs [B*H, S] (pre-dropout), ctx0 [B, E] = bv * sum_s p_s (the batched GEMM Wv_h mbar adds onto it)
@@ -36,23 +67,14 @@ __device__ __forceinline__ void xmem_fwd_body(const float* __restrict__ qk, cons
                                               int drop_site, const unsigned long long* __restrict__ rng) {
     extern __shared__ __attribute__((aligned(16))) float xm_lds[];   // qk[E] | sc[S] | psum
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H, E = H * dh;
+    const int bh = xcd_local(blockIdx.x, gridDim.x), b = bh / H, h = bh % H, E = H * dh;
     float* qv = xm_lds;
     float* sc = qv + E;
     float* ps = sc + S;
     for (int e = tid * 4; e < E; e += 1024) *reinterpret_cast<float4*>(qv + e) = *reinterpret_cast<const float4*>(qk + (long)bh * E + e);
     __syncthreads();
     const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
-    for (int s = wave; s < S; s += 4) {                  // scores: one wave-wide dot product per memory row
-        const float* mr = mem + ((long)s * B + b) * E;
-        float a = 0.f;
-        for (int e = lane * 4; e < E; e += 256) {
-            const float4 m4 = *reinterpret_cast<const float4*>(mr + e), q4 = *reinterpret_cast<const float4*>(qv + e);
-            a += q4.x * m4.x + q4.y * m4.y + q4.z * m4.z + q4.w * m4.w;
-        }
-        a = wave_sum(a);
-        if (lane == 0) sc[s] = a * scale;
-    }
+    row_dots(qv, mem, B, b, S, E, lane, wave, [&](int s_, float r) { sc[s_] = r * scale; });   // scores: a wave-wide dot product per memory row
     __syncthreads();
     if (wave == 0) {
         float m = -INFINITY;
@@ -78,7 +100,7 @@ __device__ __forceinline__ void xmem_fwd_body(const float* __restrict__ qk, cons
     __syncthreads();
     for (int e = tid * 4; e < E; e += 1024) {            // mbar = sum_s p_s mem_s
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
+#pragma unroll 16
         for (int s = 0; s < S; ++s) {
             const float p = sc[s];
             const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s * B + b) * E + e);
@@ -102,7 +124,7 @@ __device__ __forceinline__ void xmem_bwd_body(const float* __restrict__ mem, con
                                               int drop_site, const unsigned long long* __restrict__ rng) {
     extern __shared__ __attribute__((aligned(16))) float xm_lds[];   // dmb[E] | t[S] | c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H, E = H * dh;
+    const int bh = xcd_local(blockIdx.x, gridDim.x), b = bh / H, h = bh % H, E = H * dh;
     float* dmb = xm_lds;
     float* t = dmb + E;
     float* cc = t + S;
@@ -119,16 +141,7 @@ __device__ __forceinline__ void xmem_bwd_body(const float* __restrict__ mem, con
         if (lane == 0) cc[0] = c;
     }
     __syncthreads();
-    for (int s = wave; s < S; s += 4) {                  // d p_s (after dropout) = d mbar . mem_s + d ctx_h . bv_h
-        const float* mr = mem + ((long)s * B + b) * E;
-        float a = 0.f;
-        for (int e = lane * 4; e < E; e += 256) {
-            const float4 m4 = *reinterpret_cast<const float4*>(mr + e), d4 = *reinterpret_cast<const float4*>(dmb + e);
-            a += d4.x * m4.x + d4.y * m4.y + d4.z * m4.z + d4.w * m4.w;
-        }
-        a = wave_sum(a);
-        if (lane == 0) t[s] = a + cc[0];
-    }
+    row_dots(dmb, mem, B, b, S, E, lane, wave, [&](int s_, float r) { t[s_] = r + cc[0]; });   // d p_s (after dropout) = d mbar . mem_s + d ctx_h . bv_h
     __syncthreads();
     const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
     if (wave == 0) {                                     // through the dropout mask and the softmax
@@ -149,7 +162,7 @@ __device__ __forceinline__ void xmem_bwd_body(const float* __restrict__ mem, con
     __syncthreads();
     for (int e = tid * 4; e < E; e += 1024) {            // d qk = sum_s d score_s mem_s
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
+#pragma unroll 16
         for (int s = 0; s < S; ++s) {
             const float w = t[s];
             const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s * B + b) * E + e);
@@ -166,15 +179,22 @@ __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, 
                                                const float* __restrict__ qk, int B, int S, int H, int E, float* __restrict__ dmem,
                                                int accumulate, float drop_p, unsigned drop_thr, int drop_site,
                                                const unsigned long long* __restrict__ rng) {
+    __shared__ float ph[64], dh_[64];                    // this row's p_s (after dropout) and d score_s per head: computed once
     const int m = blockIdx.x, s = m / B, b = m % B;
-    const float inv_keep = 1.f / (1.f - drop_p);
+    if (threadIdx.x < H) {
+        const long bh = (long)b * H + threadIdx.x;
+        float p = probs[bh * S + s];
+        if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)s, drop_thr) ? p / (1.f - drop_p) : 0.f;
+        ph[threadIdx.x] = p;
+        dh_[threadIdx.x] = dsc[bh * S + s];
+    }
+    __syncthreads();
     for (int e = threadIdx.x * 4; e < E; e += 1024) {
         float4 a = accumulate ? *reinterpret_cast<const float4*>(dmem + (long)m * E + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
         for (int h = 0; h < H; ++h) {
             const long bh = (long)b * H + h;
-            float p = probs[bh * S + s];
-            if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)s, drop_thr) ? p * inv_keep : 0.f;
-            const float d = dsc[bh * S + s];
+            const float p = ph[h], d = dh_[h];
             const float4 g = *reinterpret_cast<const float4*>(dmbar + bh * E + e), k = *reinterpret_cast<const float4*>(qk + bh * E + e);
             a.x += p * g.x + d * k.x; a.y += p * g.y + d * k.y; a.z += p * g.z + d * k.z; a.w += p * g.w + d * k.w;
         }

@@ -1,0 +1,13 @@
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_transformer_gpu.py tests/test_edge_shapes_gpu.py tests/test_lockstep_gpu.py -q -x > gpurun_out/r02_t7a.log 2>&1; rc=$?
+tail -5 gpurun_out/r02_t7a.log | cut -c1-300
+if [ $rc -ge 124 ]; then exit $rc; fi
+if [ $rc -ne 0 ]; then grep -E "^E " gpurun_out/r02_t7a.log | head -20 | cut -c1-300; exit $rc; fi
+timeout -k 10 300 python bench.py --steps 100 --warmup 20 --no-grid --no-cpu-baseline > gpurun_out/r02_b8.json 2> gpurun_out/r02_b8.err || exit 1
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r02_b8.json").read().strip().splitlines()[-1])
+print("cfg2:", d["value"], d["ms_per_step"], d["parity"])
+PY
+timeout -k 10 300 python tools/bench_lockstep.py --workload cfg2 --ks 1,4,8 2>/dev/null | tail -1 || exit 1
+bash tools/gpu_trace.sh
