@@ -181,3 +181,19 @@ def test_bench_spawns_one_fresh_process_per_rank(monkeypatch):
     assert [env["RANK"] for _, env in started] == ["0", "1"] and [env["LOCAL_RANK"] for _, env in started] == ["0", "1"]
     assert all(cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "2", "--steps", "3"] for cmd, _ in started)
     assert not torch.cuda.is_initialized()                          # the parent never touched the GPU
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the shipped package may import it (only tests/, __graft_entry__.smoke()
+    and bench.py's parity / cpu_baseline legs do)."""
+    import re
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sign-language-nlp_amd")
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    offenders = []
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                path = os.path.join(root, f)
+                if pat.search(open(path, encoding="utf-8").read()):
+                    offenders.append(path)
+    assert not offenders, offenders
