@@ -847,8 +847,10 @@ __global__ __launch_bounds__(256) void rnn_layer_fwd_kernel(const RnnLayerParams
 
 // one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
 int rnn_layer_init() {
-    static bool done = false;
-    if (done) return 0;
+    static bool done[64] = {};                  // hipFuncSetAttribute applies per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return 0;
     const int lim = 156 * 1024;
     const bool ok =
         hipFuncSetAttribute((const void*)rnn_layer_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess &&
@@ -859,7 +861,7 @@ int rnn_layer_init() {
         set_error("rnn_layer_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
-    done = true;
+    done[dev] = true;
     return 0;
 }
 
