@@ -459,6 +459,25 @@ int slnlp_rnn_graph_launch(slnlp_rnn_plan* plan, int B, void* stream);
 /* taps: "enc_out" [S*B,2Hd] (time-major), "enc_final" [N*B,2Hd], "alphas" [B,S], "context" [B,2Hd], "dec_out" [B,Hd], "logits" */
 int slnlp_rnn_tap(slnlp_rnn_plan* plan, const char* name, float* out, int64_t max_floats, int64_t* n_out, void* stream);
 
+/* Lockstep for K EncoderDecoder{LSTM,GRU}Attn fits of one shape -- the same contract as slnlp_tf_lockstep_* above
+ * (one launch per call site for all K fits, each fit bit-identical to its solo run; replaces the one-fit-at-a-time
+ * tasks of /root/reference/main.py:70-78).  The recurrence makes an RNN fit a chain of ~600 dependent small launches
+ * per step, so K fits cost little more than one.  A data slot also carries lengths[f] int64 [rows]
+ * (pack_padded_sequence semantics, bkp.py:110-114).  The persistent layer kernel must be off (it is by default). */
+typedef struct slnlp_rnn_lockstep slnlp_rnn_lockstep;
+int64_t slnlp_rnn_lockstep_workspace_bytes(const slnlp_rnn_config* cfg, int K);
+int slnlp_rnn_lockstep_create(slnlp_rnn_plan** plans, int K, void* workspace, int64_t workspace_bytes, void* stream,
+                              slnlp_rnn_lockstep** out);
+void slnlp_rnn_lockstep_destroy(slnlp_rnn_lockstep* group);
+int slnlp_rnn_lockstep_set_data(slnlp_rnn_lockstep* group, int slot, const int64_t* const* X, const int64_t* const* y,
+                                const int64_t* const* lengths, int64_t rows, float* const* logp, float* const* loss,
+                                void* stream);
+int slnlp_rnn_lockstep_step(slnlp_rnn_lockstep* group, int slot, int64_t row0, int B, int step_index, int train,
+                            float momentum, float max_norm, void* stream);
+int slnlp_rnn_lockstep_epoch(slnlp_rnn_lockstep* group, int slot, int batch, int train, float momentum, float max_norm,
+                             void* stream);
+int slnlp_rnn_lockstep_num_launches(slnlp_rnn_lockstep* group, int slot, int B, int train);
+
 #ifdef __cplusplus
 }
 #endif

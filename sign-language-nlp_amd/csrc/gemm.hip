@@ -508,7 +508,7 @@ const void* gemm_group_kernel_ptr(int precision) {
 // buffer than the one read (other workgroups still read h_{t-1}): the caller chains the per-timestep `hprev` slots.
 struct RnnStepParams {
     slnlp_rnn_step_dir d[2];
-    int B, Hd;
+    int B, Hd, ndir;
     const long* lengths;
     float fill;
     long ld_out;
@@ -520,17 +520,31 @@ struct RnnStepParams {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
+__device__ __forceinline__ slnlp_rnn_step_dir as_global(slnlp_rnn_step_dir d) {
+    d.h_in = as_global(d.h_in); d.h_out = as_global(d.h_out); d.w_hh = as_global(d.w_hh); d.b_hh = as_global(d.b_hh);
+    d.xproj = as_global(d.xproj); d.c = as_global(d.c); d.cprev_save = as_global(d.cprev_save); d.acts = as_global(d.acts);
+    d.hn_save = as_global(d.hn_save); d.out = as_global(d.out);
+    return d;
+}
+
+// grid (Hd / 16, ndir x row tiles, fit): `tab` != nullptr is a lockstep launch, fit z takes tab[z] (launch.hpp)
 template <int NSPLIT, bool LSTM, bool EDGE>
-__global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P) {
+__global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P0, const RnnStepParams* __restrict__ tab) {
+    RnnStepParams P;
+    if (tab) P = tab[blockIdx.z];
+    else P = P0;
+    P.lengths = as_global(P.lengths);
+    P.rng = as_global(P.rng);
     constexpr int G = LSTM ? 4 : 3;
     constexpr int NP = NSPLIT == 3 ? 2 : 1;
     using TA = TileIO<true, BM>;
     using TB = TileIO<true, 16>;
     __shared__ __attribute__((aligned(16))) unsigned short As[NP * TA::PLANE];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[G * NP * TB::PLANE];
-    const slnlp_rnn_step_dir& d = P.d[blockIdx.y];
+    const int dir = blockIdx.y % P.ndir;
+    const slnlp_rnn_step_dir d = as_global(dir == 0 ? P.d[0] : P.d[1]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = P.B, Hd = P.Hd, j0 = blockIdx.x * 16, bm0 = blockIdx.z * BM;
+    const int B = P.B, Hd = P.Hd, j0 = blockIdx.x * 16, bm0 = (blockIdx.y / P.ndir) * BM;
     const int K = Hd, ktiles = (K + BKT - 1) / BKT;
 
     f32x4 acc[G];
@@ -654,11 +668,17 @@ int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int 
         P.d[k] = d;
     }
     if (ndir == 1) P.d[1] = P.d[0];
-    P.B = B; P.Hd = Hd; P.lengths = (const long*)lengths; P.fill = fill; P.ld_out = ld_out;
+    P.B = B; P.Hd = Hd; P.ndir = ndir; P.lengths = (const long*)lengths; P.fill = fill; P.ld_out = ld_out;
     P.drop_p = drop_p; P.drop_thr = dropout_threshold(drop_p); P.drop_site = drop_site; P.rng = rng;
-    const dim3 grid(ceil_div(Hd, 16), ndir, ceil_div(B, BM));
+    const dim3 grid(ceil_div(Hd, 16), ndir * ceil_div(B, BM));
     const bool edge = (Hd % BKT) != 0;
-#define SLNLP_STEP(NS, L, E) hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E>), grid, dim3(256), 0, st, P)
+    const bool rec = recording();
+    int rrc = 0;
+#define SLNLP_STEP(NS, L, E)                                                                                                    \
+    do {                                                                                                                        \
+        if (rec) rrc = record_op((const void*)rnn_step_fwd_kernel<NS, L, E>, grid, dim3(256), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd"); \
+        else hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E>), grid, dim3(256), 0, st, P, (const RnnStepParams*)nullptr);      \
+    } while (0)
     if (precision == 3) {
         if (lstm) { if (edge) SLNLP_STEP(3, true, true); else SLNLP_STEP(3, true, false); }
         else { if (edge) SLNLP_STEP(3, false, true); else SLNLP_STEP(3, false, false); }
@@ -667,6 +687,7 @@ int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int 
         else { if (edge) SLNLP_STEP(1, false, true); else SLNLP_STEP(1, false, false); }
     }
 #undef SLNLP_STEP
+    if (rec) return rrc;
     SLNLP_CHECK_LAUNCH("rnn_step_fwd");
     return SLNLP_OK;
 }

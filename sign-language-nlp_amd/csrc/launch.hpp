@@ -60,6 +60,21 @@ __device__ __forceinline__ PlaneOut as_global(PlaneOut po) {
     return po;
 }
 
+// the per-direction argument structs travel inside kernel argument packs: their pointers get the same global
+// address-space treatment as bare pointer arguments (declared before PackOf so its calls see them)
+__device__ __forceinline__ slnlp_rnn_cell_dir as_global(slnlp_rnn_cell_dir d) {
+    d.xproj = as_global(d.xproj); d.hproj = as_global(d.hproj); d.h = as_global(d.h); d.c = as_global(d.c);
+    d.hprev_save = as_global(d.hprev_save); d.cprev_save = as_global(d.cprev_save); d.acts = as_global(d.acts);
+    d.hn_save = as_global(d.hn_save); d.out = as_global(d.out);
+    return d;
+}
+__device__ __forceinline__ slnlp_rnn_cell_bwd_dir as_global(slnlp_rnn_cell_bwd_dir d) {
+    d.dh_state = as_global(d.dh_state); d.dc_state = as_global(d.dc_state); d.dout = as_global(d.dout); d.acts = as_global(d.acts);
+    d.cprev_save = as_global(d.cprev_save); d.hprev_save = as_global(d.hprev_save); d.hn_save = as_global(d.hn_save);
+    d.dgx = as_global(d.dgx); d.dgh = as_global(d.dgh); d.carry = as_global(d.carry); d.dh_extra = as_global(d.dh_extra);
+    return d;
+}
+
 template <class F>
 struct PackOf;
 template <class... T>

@@ -1,4 +1,4 @@
-// lockstep.hip -- K Transformer fits of one shape advancing through ONE launch sequence.
+// lockstep.hip -- K fits of one shape (Transformer or LSTM / GRU encoder-decoder) advancing through ONE launch sequence.
 //
 // What it replaces: the reference runs its (candidate x fold) fits as independent dask tasks, one after another per
 // worker (/root/reference/main.py:70-78, helper.py:490-526).  A batch-50 fit cannot fill 256 CUs (its decoder stages
@@ -33,11 +33,21 @@ namespace slnlp {
 constexpr int LS_MAX_FITS = 64;
 constexpr int LS_SLOTS = 4;
 
+// hooks of the RNN plan (its struct is private to rnn_plan.hip)
+int rnn_ls_prepare(slnlp_rnn_plan* pl, int B, hipStream_t st);
+int rnn_ls_record(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum,
+                  float max_norm, hipStream_t st);
+void rnn_ls_outputs(slnlp_rnn_plan* pl, float* logp, float* loss, const int* dyn);
+void rnn_ls_replayed(slnlp_rnn_plan* pl, int B, int train);
+const slnlp_rnn_config* rnn_ls_cfg(slnlp_rnn_plan* pl);
+
 struct GatherArgs {
     const int64_t* const* X;     // [K] dataset pointers (device table)
     const int64_t* const* y;
+    const int64_t* const* len;   // RNN fits: lengths per sequence (nullptr for the Transformer, which reads the pad ids)
     int64_t* const* Xst;         // [K] staging pointers (device table)
     int64_t* const* yst;
+    int64_t* const* Lst;
     int* dyn;                    // {row0, batch index}
     int S, row0, B, step;
 };
@@ -52,6 +62,11 @@ __global__ __launch_bounds__(256) void ls_gather_kernel(const GatherArgs a) {
         const int64_t* y = a.y[f] + a.row0;
         int64_t* ys = a.yst[f];
         for (int i = threadIdx.x; i < a.B; i += 256) ys[i] = y[i];
+        if (a.len) {
+            const int64_t* l = a.len[f] + a.row0;
+            int64_t* ls = a.Lst[f];
+            for (int i = threadIdx.x; i < a.B; i += 256) ls[i] = l[i];
+        }
         if (f == 0 && threadIdx.x == 0) {
             a.dyn[0] = a.row0;
             a.dyn[1] = a.step;
@@ -77,20 +92,33 @@ struct Program {
 
 using namespace slnlp;
 
-struct slnlp_tf_lockstep {
-    std::vector<slnlp_tf_plan*> plans;
+// What the driver needs from one fit, whatever its plan type.
+struct LsFit {
+    void* plan;
+    int (*prepare)(void* plan, int B, hipStream_t st);      // work that must stay outside a recorded program (memsets, re-splits)
+    int (*record)(void* plan, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum, float max_norm,
+                  hipStream_t st);                          // the ordinary step code, run under a Recorder
+    void (*outputs)(void* plan, float* logp, float* loss, const int* dyn);
+    void (*replayed)(void* plan, int B, int train);         // host bookkeeping after the step's launches were issued
+};
+
+struct LockstepGroup {
+    std::vector<LsFit> fits;
+    bool has_len = false;
     int K = 0, S = 0, maxB = 0;
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_used = 0;
-    std::vector<int64_t*> Xst, yst;                 // per-fit staging (device)
+    std::vector<int64_t*> Xst, yst, Lst;            // per-fit staging (device)
     int64_t** d_Xst = nullptr;                      // device tables of the above
     int64_t** d_yst = nullptr;
+    int64_t** d_Lst = nullptr;
     int* dyn = nullptr;
     struct Slot {
         bool set = false;
         int64_t rows = 0;
         const int64_t** d_X = nullptr;              // device tables [K]
         const int64_t** d_y = nullptr;
+        const int64_t** d_len = nullptr;
         std::vector<float*> logp, loss;             // per-fit output buffers (device, caller-owned)
     } slot[LS_SLOTS];
     std::map<std::tuple<int, int, int>, Program> programs;   // (slot, B, train)
@@ -103,8 +131,10 @@ struct slnlp_tf_lockstep {
         return p;
     }
 };
+struct slnlp_tf_lockstep : LockstepGroup {};
+struct slnlp_rnn_lockstep : LockstepGroup {};
 
-static int upload(slnlp_tf_lockstep* ls, const void* host, size_t bytes, void** dev, hipStream_t st) {
+static int upload(LockstepGroup* ls, const void* host, size_t bytes, void** dev, hipStream_t st) {
     void* d = ls->take(bytes);
     SLNLP_CHECK_ARG(d, "lockstep: workspace exhausted (%zu of %zu bytes used, %zu more needed)", ls->ws_used, ls->ws_bytes, bytes);
     // synchronous with respect to the host buffer (pageable memory); ordered on `st` before the launches that read it
@@ -127,7 +157,7 @@ struct Blob {
     }
 };
 
-static int merge(slnlp_tf_lockstep* ls, std::vector<Recorder>& recs, Program& prog, hipStream_t st) {
+static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, hipStream_t st) {
     const int K = (int)recs.size();
     Blob blob;
     const size_t nops = recs[0].ops.size();
@@ -208,6 +238,142 @@ static int replay(const Program& prog, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ generic driver ----
+static int ls_init(LockstepGroup* ls, int B, int S, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    const int K = (int)ls->fits.size();
+    ls->K = K; ls->S = S; ls->maxB = B;
+    ls->ws = (char*)workspace; ls->ws_bytes = (size_t)workspace_bytes;
+    for (int f = 0; f < K; ++f) {
+        int64_t* x = (int64_t*)ls->take((size_t)B * S * sizeof(int64_t));
+        int64_t* y = (int64_t*)ls->take((size_t)B * sizeof(int64_t));
+        int64_t* l = ls->has_len ? (int64_t*)ls->take((size_t)B * sizeof(int64_t)) : nullptr;
+        SLNLP_CHECK_ARG(x && y && (l || !ls->has_len), "lockstep_create: workspace too small");
+        ls->Xst.push_back(x);
+        ls->yst.push_back(y);
+        ls->Lst.push_back(l);
+    }
+    ls->dyn = (int*)ls->take(64);
+    SLNLP_CHECK_ARG(ls->dyn, "lockstep_create: workspace too small");
+    SLNLP_TRY(upload(ls, ls->Xst.data(), K * sizeof(void*), (void**)&ls->d_Xst, st));
+    SLNLP_TRY(upload(ls, ls->yst.data(), K * sizeof(void*), (void**)&ls->d_yst, st));
+    if (ls->has_len) SLNLP_TRY(upload(ls, ls->Lst.data(), K * sizeof(void*), (void**)&ls->d_Lst, st));
+    return 0;
+}
+
+static void ls_destroy(LockstepGroup* ls) {
+    (void)hipDeviceSynchronize();      // tables live in caller memory that may be freed next
+    for (LsFit& f : ls->fits) f.outputs(f.plan, nullptr, nullptr, nullptr);
+}
+
+static int ls_set_data(LockstepGroup* ls, int slot, const int64_t* const* X, const int64_t* const* y, const int64_t* const* len,
+                       int64_t rows, float* const* logp, float* const* loss, hipStream_t st) {
+    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && X && y && logp && loss && rows > 0 && (len || !ls->has_len),
+                    "lockstep_set_data: bad arguments");
+    LockstepGroup::Slot& s = ls->slot[slot];
+    for (auto it = ls->programs.begin(); it != ls->programs.end();)     // programs of this slot baked the old output pointers
+        it = std::get<0>(it->first) == slot ? ls->programs.erase(it) : std::next(it);
+    s.rows = rows;
+    s.logp.assign(logp, logp + ls->K);
+    s.loss.assign(loss, loss + ls->K);
+    SLNLP_TRY(upload(ls, X, ls->K * sizeof(void*), (void**)&s.d_X, st));
+    SLNLP_TRY(upload(ls, y, ls->K * sizeof(void*), (void**)&s.d_y, st));
+    if (ls->has_len) SLNLP_TRY(upload(ls, len, ls->K * sizeof(void*), (void**)&s.d_len, st));
+    s.set = true;
+    return 0;
+}
+
+// One lockstep step of every fit on rows [row0, row0 + B) of slot `slot`: train != 0 -> forward + criterion + backward +
+// clip + SGD (what slnlp_{tf,rnn}_train_step does for one fit), else an eval-mode forward + criterion.
+static int ls_step(LockstepGroup* ls, int slot, int64_t row0, int B, int step_index, int train, float momentum, float max_norm,
+                   hipStream_t st) {
+    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && ls->slot[slot].set, "lockstep_step: slot %d has no data", slot);
+    LockstepGroup::Slot& s = ls->slot[slot];
+    SLNLP_CHECK_ARG(B > 0 && B <= ls->maxB && row0 >= 0 && row0 + B <= s.rows, "lockstep_step: rows [%ld, %ld) outside 0..%ld or batch > %d",
+                    (long)row0, (long)(row0 + B), (long)s.rows, ls->maxB);
+    for (LsFit& f : ls->fits) SLNLP_TRY(f.prepare(f.plan, B, st));
+    const auto key = std::make_tuple(slot, B, train ? 1 : 0);
+    auto it = ls->programs.find(key);
+    if (it == ls->programs.end()) {
+        std::vector<Recorder> recs(ls->K);
+        int rc = 0;
+        for (int f = 0; f < ls->K && !rc; ++f) {
+            LsFit& fit = ls->fits[f];
+            fit.outputs(fit.plan, s.logp[f], s.loss[f], ls->dyn);
+            set_recorder(&recs[f]);
+            rc = fit.record(fit.plan, ls->Xst[f], ls->yst[f], ls->Lst[f], B, train, momentum, max_norm, st);
+            set_recorder(nullptr);
+        }
+        if (rc) return rc;
+        Program prog;
+        SLNLP_TRY(merge(ls, recs, prog, st));
+        it = ls->programs.emplace(key, std::move(prog)).first;
+    }
+    GatherArgs g;
+    g.X = s.d_X; g.y = s.d_y; g.len = ls->has_len ? s.d_len : nullptr;
+    g.Xst = ls->d_Xst; g.yst = ls->d_yst; g.Lst = ls->d_Lst; g.dyn = ls->dyn;
+    g.S = ls->S; g.row0 = (int)row0; g.B = B; g.step = step_index;
+    int gx = (B * ls->S + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(ls_gather_kernel, dim3(gx, 1, ls->K), dim3(256), 0, st, g);
+    SLNLP_CHECK_LAUNCH("lockstep gather");
+    SLNLP_TRY(replay(it->second, st));
+    for (LsFit& f : ls->fits) f.replayed(f.plan, B, train);
+    return 0;
+}
+
+// One pass over slot `slot` in dataset order, batches of `batch` rows (the last one may be shorter).
+static int ls_epoch(LockstepGroup* ls, int slot, int batch, int train, float momentum, float max_norm, hipStream_t st) {
+    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && ls->slot[slot].set && batch > 0, "lockstep_epoch: bad arguments");
+    const int64_t rows = ls->slot[slot].rows;
+    int step = 0;
+    for (int64_t r = 0; r < rows; r += batch, ++step) {
+        const int B = (int)(rows - r < batch ? rows - r : batch);
+        SLNLP_TRY(ls_step(ls, slot, r, B, step, train, momentum, max_norm, st));
+    }
+    return 0;
+}
+
+static int ls_num_launches(LockstepGroup* ls, int slot, int B, int train) {
+    if (!ls) return -1;
+    auto it = ls->programs.find(std::make_tuple(slot, B, train ? 1 : 0));
+    return it == ls->programs.end() ? -1 : (int)it->second.ops.size() + 1;
+}
+
+// ---------------------------------------------------------------------------------------------- Transformer hooks ----
+static int tf_prepare(void* p, int B, hipStream_t st) {
+    slnlp_tf_plan* pl = (slnlp_tf_plan*)p;
+    SLNLP_TRY(pl->prepare_planes(B, st));      // re-zero plane padding when B changes
+    SLNLP_TRY(pl->ensure_wplanes(st));         // never part of a recorded program: the update kernel keeps the planes current
+    return pl->ensure_wq(st);                  // precision 8: re-quantised weights, likewise outside the program
+}
+static int tf_record(void* p, const int64_t* X, const int64_t* y, const int64_t*, int B, int train, float momentum, float max_norm,
+                     hipStream_t st) {
+    slnlp_tf_plan* pl = (slnlp_tf_plan*)p;
+    SLNLP_TRY(pl->forward_impl(X, y, B, train, nullptr, st, false));
+    if (!train) return 0;
+    SLNLP_TRY(slnlp_tf_backward(pl, st));
+    return slnlp_tf_optim(pl, momentum, max_norm, st);
+}
+static void tf_outputs(void* p, float* logp, float* loss, const int* dyn) {
+    slnlp_tf_plan* pl = (slnlp_tf_plan*)p;
+    pl->ls_logp = logp; pl->ls_loss = loss; pl->ls_dyn = dyn;
+}
+static void tf_replayed(void* p, int B, int train) {
+    slnlp_tf_plan* pl = (slnlp_tf_plan*)p;
+    pl->last_B = B;
+    pl->last_p = train ? pl->cfg.dropout : 0.f;
+    if (train) pl->params_stepped();
+}
+
+// ------------------------------------------------------------------------------------------------------ RNN hooks ----
+static int rnn_prepare(void* p, int B, hipStream_t st) { return rnn_ls_prepare((slnlp_rnn_plan*)p, B, st); }
+static int rnn_record(void* p, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum, float max_norm,
+                      hipStream_t st) {
+    return rnn_ls_record((slnlp_rnn_plan*)p, X, y, len, B, train, momentum, max_norm, st);
+}
+static void rnn_outputs(void* p, float* logp, float* loss, const int* dyn) { rnn_ls_outputs((slnlp_rnn_plan*)p, logp, loss, dyn); }
+static void rnn_replayed(void* p, int B, int train) { rnn_ls_replayed((slnlp_rnn_plan*)p, B, train); }
+
 extern "C" {
 
 int64_t slnlp_tf_lockstep_workspace_bytes(const slnlp_tf_config* cfg, int K) {
@@ -235,22 +401,8 @@ int slnlp_tf_lockstep_create(slnlp_tf_plan** plans, int K, void* workspace, int6
         for (int g = 0; g < f; ++g) SLNLP_CHECK_ARG(plans[g] != plans[f], "lockstep_create: plan %d listed twice", f);
     }
     slnlp_tf_lockstep* ls = new slnlp_tf_lockstep();
-    ls->plans.assign(plans, plans + K);
-    ls->K = K; ls->S = c0.S; ls->maxB = c0.B;
-    ls->ws = (char*)workspace; ls->ws_bytes = (size_t)workspace_bytes;
-    hipStream_t st = (hipStream_t)stream;
-    int rc = 0;
-    for (int f = 0; f < K && !rc; ++f) {
-        int64_t* x = (int64_t*)ls->take((size_t)c0.B * c0.S * sizeof(int64_t));
-        int64_t* y = (int64_t*)ls->take((size_t)c0.B * sizeof(int64_t));
-        if (!x || !y) { set_error("lockstep_create: workspace too small"); rc = SLNLP_ERR_INVALID_ARG; break; }
-        ls->Xst.push_back(x);
-        ls->yst.push_back(y);
-    }
-    ls->dyn = rc ? nullptr : (int*)ls->take(64);
-    if (!rc && !ls->dyn) { set_error("lockstep_create: workspace too small"); rc = SLNLP_ERR_INVALID_ARG; }
-    if (!rc) rc = upload(ls, ls->Xst.data(), K * sizeof(void*), (void**)&ls->d_Xst, st);
-    if (!rc) rc = upload(ls, ls->yst.data(), K * sizeof(void*), (void**)&ls->d_yst, st);
+    for (int f = 0; f < K; ++f) ls->fits.push_back(LsFit{plans[f], tf_prepare, tf_record, tf_outputs, tf_replayed});
+    const int rc = ls_init(ls, c0.B, c0.S, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc) { delete ls; return rc; }
     *out = ls;
     return 0;
@@ -258,8 +410,7 @@ int slnlp_tf_lockstep_create(slnlp_tf_plan** plans, int K, void* workspace, int6
 
 void slnlp_tf_lockstep_destroy(slnlp_tf_lockstep* ls) {
     if (!ls) return;
-    (void)hipDeviceSynchronize();      // tables live in caller memory that may be freed next
-    for (slnlp_tf_plan* p : ls->plans) { p->ls_logp = nullptr; p->ls_loss = nullptr; p->ls_dyn = nullptr; }
+    ls_destroy(ls);
     delete ls;
 }
 
@@ -267,83 +418,69 @@ void slnlp_tf_lockstep_destroy(slnlp_tf_lockstep* ls) {
 // [rows, Vt] (log-probs of every batch of a pass) and loss[f] float [ceil(rows / batch)] (loss per batch).
 int slnlp_tf_lockstep_set_data(slnlp_tf_lockstep* ls, int slot, const int64_t* const* X, const int64_t* const* y, int64_t rows,
                                float* const* logp, float* const* loss, void* stream) {
-    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && X && y && logp && loss && rows > 0, "lockstep_set_data: bad arguments");
-    slnlp_tf_lockstep::Slot& s = ls->slot[slot];
-    for (auto it = ls->programs.begin(); it != ls->programs.end();)     // programs of this slot baked the old output pointers
-        it = std::get<0>(it->first) == slot ? ls->programs.erase(it) : std::next(it);
-    s.rows = rows;
-    s.logp.assign(logp, logp + ls->K);
-    s.loss.assign(loss, loss + ls->K);
-    SLNLP_TRY(upload(ls, X, ls->K * sizeof(void*), (void**)&s.d_X, (hipStream_t)stream));
-    SLNLP_TRY(upload(ls, y, ls->K * sizeof(void*), (void**)&s.d_y, (hipStream_t)stream));
-    s.set = true;
-    return 0;
+    return ls_set_data(ls, slot, X, y, nullptr, rows, logp, loss, (hipStream_t)stream);
 }
-
-// One lockstep step of every fit on rows [row0, row0 + B) of slot `slot`: train != 0 -> forward + criterion + backward +
-// clip + SGD (what slnlp_tf_train_step does for one fit), else an eval-mode forward + criterion.
 int slnlp_tf_lockstep_step(slnlp_tf_lockstep* ls, int slot, int64_t row0, int B, int step_index, int train, float momentum,
                            float max_norm, void* stream) {
-    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && ls->slot[slot].set, "lockstep_step: slot %d has no data", slot);
-    slnlp_tf_lockstep::Slot& s = ls->slot[slot];
-    SLNLP_CHECK_ARG(B > 0 && B <= ls->maxB && row0 >= 0 && row0 + B <= s.rows, "lockstep_step: rows [%ld, %ld) outside 0..%ld or batch > %d",
-                    (long)row0, (long)(row0 + B), (long)s.rows, ls->maxB);
-    hipStream_t st = (hipStream_t)stream;
-    for (slnlp_tf_plan* pl : ls->plans) {
-        SLNLP_TRY(pl->prepare_planes(B, st));      // re-zero plane padding when B changes
-        SLNLP_TRY(pl->ensure_wplanes(st));         // never part of a recorded program: the update kernel keeps the planes current
-        SLNLP_TRY(pl->ensure_wq(st));              // precision 8: re-quantised weights, likewise outside the program
-    }
-    const auto key = std::make_tuple(slot, B, train ? 1 : 0);
-    auto it = ls->programs.find(key);
-    if (it == ls->programs.end()) {
-        std::vector<Recorder> recs(ls->K);
-        int rc = 0;
-        for (int f = 0; f < ls->K && !rc; ++f) {
-            slnlp_tf_plan* pl = ls->plans[f];
-            pl->ls_logp = s.logp[f]; pl->ls_loss = s.loss[f]; pl->ls_dyn = ls->dyn;
-            set_recorder(&recs[f]);
-            rc = pl->forward_impl(ls->Xst[f], ls->yst[f], B, train, nullptr, st, false);
-            if (!rc && train) rc = slnlp_tf_backward(pl, st);
-            if (!rc && train) rc = slnlp_tf_optim(pl, momentum, max_norm, st);
-            set_recorder(nullptr);
-        }
-        if (rc) return rc;
-        Program prog;
-        SLNLP_TRY(merge(ls, recs, prog, st));
-        it = ls->programs.emplace(key, std::move(prog)).first;
-    } else {
-        for (slnlp_tf_plan* pl : ls->plans) { pl->last_B = B; pl->last_p = train ? pl->cfg.dropout : 0.f; }
-    }
-    GatherArgs g;
-    g.X = s.d_X; g.y = s.d_y; g.Xst = ls->d_Xst; g.yst = ls->d_yst; g.dyn = ls->dyn;
-    g.S = ls->S; g.row0 = (int)row0; g.B = B; g.step = step_index;
-    int gx = (B * ls->S + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(ls_gather_kernel, dim3(gx, 1, ls->K), dim3(256), 0, st, g);
-    SLNLP_CHECK_LAUNCH("lockstep gather");
-    SLNLP_TRY(replay(it->second, st));
-    if (train)
-        for (slnlp_tf_plan* pl : ls->plans) pl->params_stepped();
-    return 0;
+    return ls_step(ls, slot, row0, B, step_index, train, momentum, max_norm, (hipStream_t)stream);
 }
-
-// One pass over slot `slot` in dataset order, batches of `batch` rows (the last one may be shorter).
 int slnlp_tf_lockstep_epoch(slnlp_tf_lockstep* ls, int slot, int batch, int train, float momentum, float max_norm, void* stream) {
-    SLNLP_CHECK_ARG(ls && slot >= 0 && slot < LS_SLOTS && ls->slot[slot].set && batch > 0, "lockstep_epoch: bad arguments");
-    const int64_t rows = ls->slot[slot].rows;
-    int step = 0;
-    for (int64_t r = 0; r < rows; r += batch, ++step) {
-        const int B = (int)(rows - r < batch ? rows - r : batch);
-        SLNLP_TRY(slnlp_tf_lockstep_step(ls, slot, r, B, step, train, momentum, max_norm, stream));
+    return ls_epoch(ls, slot, batch, train, momentum, max_norm, (hipStream_t)stream);
+}
+int slnlp_tf_lockstep_num_launches(slnlp_tf_lockstep* ls, int slot, int B, int train) { return ls_num_launches(ls, slot, B, train); }
+
+// ---- the same for K EncoderDecoder{LSTM,GRU}Attn fits (rnn_plan.hip); a slot also carries the sequence lengths
+int64_t slnlp_rnn_lockstep_workspace_bytes(const slnlp_rnn_config* cfg, int K) {
+    if (!cfg || K < 1 || K > LS_MAX_FITS) return -1;
+    // call sites: one fused step per timestep forward, a cell + a grouped recurrent dgrad per timestep backward, ~24 more per
+    // layer and ~64 around them.  Table bytes per site and fit: a z-pack is <= 320 B, the recurrent dgrad group up to 8 jobs
+    // of ~400 B + a block map: budget 6 KiB on average, for 6 programs (train / eval x full / tail batch, test).
+    const size_t staging = (size_t)K * ((size_t)cfg->B * cfg->S + 2 * cfg->B + 64) * sizeof(int64_t);
+    const size_t sites = 64 + (size_t)cfg->N * (3 * (size_t)cfg->S + 24);
+    return (int64_t)(staging + 65536 + 6 * sites * (size_t)K * 6144);
+}
+
+int slnlp_rnn_lockstep_create(slnlp_rnn_plan** plans, int K, void* workspace, int64_t workspace_bytes, void* stream,
+                              slnlp_rnn_lockstep** out) {
+    SLNLP_CHECK_ARG(plans && out && K >= 1 && K <= LS_MAX_FITS, "rnn_lockstep_create: 1..%d plans", LS_MAX_FITS);
+    SLNLP_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "rnn_lockstep_create: workspace must be 256-byte aligned");
+    for (int f = 0; f < K; ++f) SLNLP_CHECK_ARG(plans[f], "rnn_lockstep_create: null plan %d", f);
+    const slnlp_rnn_config& c0 = *rnn_ls_cfg(plans[0]);
+    for (int f = 0; f < K; ++f) {
+        const slnlp_rnn_config& c = *rnn_ls_cfg(plans[f]);
+        SLNLP_CHECK_ARG(c.lstm == c0.lstm && c.E == c0.E && c.Hd == c0.Hd && c.N == c0.N && c.Vs == c0.Vs && c.Vt == c0.Vt && c.B == c0.B &&
+                            c.S == c0.S && c.precision == c0.precision && (c.dropout > 0.f) == (c0.dropout > 0.f),
+                        "rnn_lockstep_create: plan %d does not have the shape of plan 0 (lr, dropout rate and seed may differ; "
+                        "dropout on/off may not)", f);
+        for (int g = 0; g < f; ++g) SLNLP_CHECK_ARG(plans[g] != plans[f], "rnn_lockstep_create: plan %d listed twice", f);
     }
+    slnlp_rnn_lockstep* ls = new slnlp_rnn_lockstep();
+    ls->has_len = true;
+    for (int f = 0; f < K; ++f) ls->fits.push_back(LsFit{plans[f], rnn_prepare, rnn_record, rnn_outputs, rnn_replayed});
+    const int rc = ls_init(ls, c0.B, c0.S, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc) { delete ls; return rc; }
+    *out = ls;
     return 0;
 }
 
-int slnlp_tf_lockstep_num_launches(slnlp_tf_lockstep* ls, int slot, int B, int train) {
-    if (!ls) return -1;
-    auto it = ls->programs.find(std::make_tuple(slot, B, train ? 1 : 0));
-    return it == ls->programs.end() ? -1 : (int)it->second.ops.size() + 1;
+void slnlp_rnn_lockstep_destroy(slnlp_rnn_lockstep* ls) {
+    if (!ls) return;
+    ls_destroy(ls);
+    delete ls;
 }
+
+int slnlp_rnn_lockstep_set_data(slnlp_rnn_lockstep* ls, int slot, const int64_t* const* X, const int64_t* const* y,
+                                const int64_t* const* lengths, int64_t rows, float* const* logp, float* const* loss, void* stream) {
+    SLNLP_CHECK_ARG(lengths, "rnn_lockstep_set_data: lengths are required");
+    return ls_set_data(ls, slot, X, y, lengths, rows, logp, loss, (hipStream_t)stream);
+}
+int slnlp_rnn_lockstep_step(slnlp_rnn_lockstep* ls, int slot, int64_t row0, int B, int step_index, int train, float momentum,
+                            float max_norm, void* stream) {
+    return ls_step(ls, slot, row0, B, step_index, train, momentum, max_norm, (hipStream_t)stream);
+}
+int slnlp_rnn_lockstep_epoch(slnlp_rnn_lockstep* ls, int slot, int batch, int train, float momentum, float max_norm, void* stream) {
+    return ls_epoch(ls, slot, batch, train, momentum, max_norm, (hipStream_t)stream);
+}
+int slnlp_rnn_lockstep_num_launches(slnlp_rnn_lockstep* ls, int slot, int B, int train) { return ls_num_launches(ls, slot, B, train); }
 
 }  // extern "C"

@@ -6,7 +6,7 @@
 // every dgrad / wgrad) run on the MFMA GEMM (gemm.hip); these kernels are the fp32 glue between
 // them.  Gate order follows torch.nn.LSTM (i,f,g,o) / torch.nn.GRU (r,z,n), which the reference
 // instantiates at bkp.py:95-100,186-190.
-#include "common.hpp"
+#include "launch.hpp"
 
 namespace slnlp {
 
@@ -17,10 +17,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // t < lengths[b] (pack_padded_sequence, bkp.py:110-114): otherwise state is carried and the layer
 // output is `fill` (pad_packed_sequence(padding_value=pad_idx), bkp.py:120-123).
 template <bool LSTM>
-__global__ __launch_bounds__(256) void rnn_cell_fwd_kernel(slnlp_rnn_cell_dir d0, slnlp_rnn_cell_dir d1, int B, int Hd,
-                                                           const long* __restrict__ lengths, float fill, long ld_out,
-                                                           float drop_p, unsigned drop_thr, int drop_site,
-                                                           const unsigned long long* __restrict__ rng) {
+__device__ __forceinline__ void rnn_cell_fwd_body(slnlp_rnn_cell_dir d0, slnlp_rnn_cell_dir d1, int B, int Hd,
+                                                  const long* __restrict__ lengths, float fill, long ld_out, float drop_p,
+                                                  unsigned drop_thr, int drop_site, const unsigned long long* __restrict__ rng) {
     const slnlp_rnn_cell_dir d = blockIdx.y == 0 ? d0 : d1;
     const int G = LSTM ? 4 : 3;
     const long n = (long)B * Hd;
@@ -65,15 +64,27 @@ __global__ __launch_bounds__(256) void rnn_cell_fwd_kernel(slnlp_rnn_cell_dir d0
     }
 }
 
+__device__ __forceinline__ void rnn_cell_fwd_lstm_body(slnlp_rnn_cell_dir d0, slnlp_rnn_cell_dir d1, int B, int Hd, const long* lengths,
+                                                       float fill, long ld_out, float drop_p, unsigned drop_thr, int drop_site,
+                                                       const unsigned long long* rng) {
+    rnn_cell_fwd_body<true>(d0, d1, B, Hd, lengths, fill, ld_out, drop_p, drop_thr, drop_site, rng);
+}
+__device__ __forceinline__ void rnn_cell_fwd_gru_body(slnlp_rnn_cell_dir d0, slnlp_rnn_cell_dir d1, int B, int Hd, const long* lengths,
+                                                      float fill, long ld_out, float drop_p, unsigned drop_thr, int drop_site,
+                                                      const unsigned long long* rng) {
+    rnn_cell_fwd_body<false>(d0, d1, B, Hd, lengths, fill, ld_out, drop_p, drop_thr, drop_site, rng);
+}
+SLNLP_ZKERNEL(rnn_cell_fwd_lstm_kernel, 256, rnn_cell_fwd_lstm_body)
+SLNLP_ZKERNEL(rnn_cell_fwd_gru_kernel, 256, rnn_cell_fwd_gru_body)
+
 // ------------------------------------------------------------------ backward
 // dh_state / dc_state are the running gradients w.r.t. the state AFTER step t; the kernel emits the
 // gate gradients of step t and the part of dh that bypasses the recurrent matmul (`carry`); the
 // caller then forms dh_state(t-1) = dgh_t W_hh + carry with one GEMM.
 template <bool LSTM>
-__global__ __launch_bounds__(256) void rnn_cell_bwd_kernel(slnlp_rnn_cell_bwd_dir d0, slnlp_rnn_cell_bwd_dir d1, int B,
-                                                           int Hd, const long* __restrict__ lengths, long ld_dout,
-                                                           float drop_p, unsigned drop_thr, int drop_site,
-                                                           const unsigned long long* __restrict__ rng) {
+__device__ __forceinline__ void rnn_cell_bwd_body(slnlp_rnn_cell_bwd_dir d0, slnlp_rnn_cell_bwd_dir d1, int B, int Hd,
+                                                  const long* __restrict__ lengths, long ld_dout, float drop_p, unsigned drop_thr,
+                                                  int drop_site, const unsigned long long* __restrict__ rng) {
     const slnlp_rnn_cell_bwd_dir d = blockIdx.y == 0 ? d0 : d1;
     const int G = LSTM ? 4 : 3;
     const long n = (long)B * Hd;
@@ -125,17 +136,29 @@ __global__ __launch_bounds__(256) void rnn_cell_bwd_kernel(slnlp_rnn_cell_bwd_di
     }
 }
 
+__device__ __forceinline__ void rnn_cell_bwd_lstm_body(slnlp_rnn_cell_bwd_dir d0, slnlp_rnn_cell_bwd_dir d1, int B, int Hd,
+                                                       const long* lengths, long ld_dout, float drop_p, unsigned drop_thr, int drop_site,
+                                                       const unsigned long long* rng) {
+    rnn_cell_bwd_body<true>(d0, d1, B, Hd, lengths, ld_dout, drop_p, drop_thr, drop_site, rng);
+}
+__device__ __forceinline__ void rnn_cell_bwd_gru_body(slnlp_rnn_cell_bwd_dir d0, slnlp_rnn_cell_bwd_dir d1, int B, int Hd,
+                                                      const long* lengths, long ld_dout, float drop_p, unsigned drop_thr, int drop_site,
+                                                      const unsigned long long* rng) {
+    rnn_cell_bwd_body<false>(d0, d1, B, Hd, lengths, ld_dout, drop_p, drop_thr, drop_site, rng);
+}
+SLNLP_ZKERNEL(rnn_cell_bwd_lstm_kernel, 256, rnn_cell_bwd_lstm_body)
+SLNLP_ZKERNEL(rnn_cell_bwd_gru_kernel, 256, rnn_cell_bwd_gru_body)
+
 // ------------------------------------------------------------------ Bahdanau
 // bkp.py:304-327 with one query per sequence: scores[s] = w_e . tanh(q + proj_key[s]); positions
 // where the source token is <pad> are masked (bkp.py:404-406); softmax; context = alphas . value.
 // One workgroup per sequence b; rows of proj_key / value are time-major (m = s*B + b).
 constexpr int BAH_MAXS = 2048;   // source positions per sequence held in LDS (the softmax walks them 64 at a time)
 
-__global__ __launch_bounds__(256) void bahdanau_fwd_kernel(const float* __restrict__ q, const float* __restrict__ pk,
-                                                           const float* __restrict__ val, const float* __restrict__ we,
-                                                           const long* __restrict__ ids, long ld_ids, long pad, int B,
-                                                           int S, int Hd, float* __restrict__ alphas,
-                                                           float* __restrict__ ctx) {
+__device__ __forceinline__ void bahdanau_fwd_body(const float* __restrict__ q, const float* __restrict__ pk,
+                                                  const float* __restrict__ val, const float* __restrict__ we,
+                                                  const long* __restrict__ ids, long ld_ids, long pad, int B, int S, int Hd,
+                                                  float* __restrict__ alphas, float* __restrict__ ctx) {
     __shared__ float sc[BAH_MAXS];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int s = wave; s < S; s += 4) {
@@ -169,13 +192,14 @@ __global__ __launch_bounds__(256) void bahdanau_fwd_kernel(const float* __restri
     }
 }
 
+SLNLP_ZKERNEL(bahdanau_fwd_kernel, 256, bahdanau_fwd_body)
+
 // dctx [B,2Hd] -> dq [B,Hd], dpk [S*B,Hd], dval [S*B,2Hd] (written, not accumulated), dwe_part [B,Hd]
-__global__ __launch_bounds__(256) void bahdanau_bwd_kernel(const float* __restrict__ q, const float* __restrict__ pk,
-                                                           const float* __restrict__ val, const float* __restrict__ we,
-                                                           const float* __restrict__ alphas,
-                                                           const float* __restrict__ dctx, int B, int S, int Hd,
-                                                           float* __restrict__ dq, float* __restrict__ dpk,
-                                                           float* __restrict__ dval, float* __restrict__ dwe_part) {
+__device__ __forceinline__ void bahdanau_bwd_body(const float* __restrict__ q, const float* __restrict__ pk,
+                                                  const float* __restrict__ val, const float* __restrict__ we,
+                                                  const float* __restrict__ alphas, const float* __restrict__ dctx, int B, int S,
+                                                  int Hd, float* __restrict__ dq, float* __restrict__ dpk,
+                                                  float* __restrict__ dval, float* __restrict__ dwe_part) {
     __shared__ float al[BAH_MAXS], dsc[BAH_MAXS];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, V2 = 2 * Hd;
     for (int s = threadIdx.x; s < S; s += 256) al[s] = alphas[(long)b * S + s];
@@ -217,8 +241,10 @@ __global__ __launch_bounds__(256) void bahdanau_bwd_kernel(const float* __restri
     }
 }
 
+SLNLP_ZKERNEL(bahdanau_bwd_kernel, 256, bahdanau_bwd_body)
+
 // out[c] = sum_r in[r, c]   (fixed order; tiny)
-__global__ void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+__device__ __forceinline__ void colsum_body(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float a = 0.f;
@@ -226,9 +252,11 @@ __global__ void colsum_kernel(const float* __restrict__ in, int R, int C, float*
     out[c] = a;
 }
 
+SLNLP_ZKERNEL(colsum_kernel, 256, colsum_body)
+
 // out[r, :] (+)= in[r, :] for strided row blocks (final-state gather, gradient adds)
-__global__ void add_rows_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out, int R,
-                                int C, int accumulate) {
+__device__ __forceinline__ void add_rows_body(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out, int R,
+                                              int C, int accumulate) {
     const long n = (long)R * C;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int r = (int)(i / C), c = (int)(i % C);
@@ -238,18 +266,19 @@ __global__ void add_rows_kernel(const float* __restrict__ in, long ld_in, float*
     }
 }
 
+SLNLP_ZKERNEL(add_rows_kernel, 256, add_rows_body)
+
 // out = dy * (1 - y^2)   (backward of y = tanh(z); the bridge, bkp.py:268-280)
-__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long n) {
+__device__ __forceinline__ void tanh_bwd_body(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = dy[i] * (1.f - y[i] * y[i]);
 }
+SLNLP_ZKERNEL(tanh_bwd_kernel, 256, tanh_bwd_body)
 
 int tanh_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t st) {
     SLNLP_CHECK_ARG(dy && y && out && n > 0, "tanh_bwd: bad args");
     int gx = ceil_div(n, 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(gx), dim3(256), 0, st, dy, y, out, (long)n);
-    SLNLP_CHECK_LAUNCH("tanh_bwd");
-    return 0;
+    return zlaunch(tanh_bwd_kernel, dim3(gx), 256, 0, st, "tanh_bwd", dy, y, out, (long)n);
 }
 
 int rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, float fill,
@@ -263,14 +292,8 @@ int rnn_cell_fwd(int lstm, const slnlp_rnn_cell_dir* dirs, int ndir, int B, int 
     int gx = ceil_div((long)B * Hd, 256);
     if (gx > 1024) gx = 1024;
     const slnlp_rnn_cell_dir d1 = dirs[ndir - 1];
-    if (lstm)
-        hipLaunchKernelGGL(rnn_cell_fwd_kernel<true>, dim3(gx, ndir), dim3(256), 0, st, dirs[0], d1, B, Hd,
-                           (const long*)lengths, fill, (long)ld_out, drop_p, dropout_threshold(drop_p), drop_site, rng);
-    else
-        hipLaunchKernelGGL(rnn_cell_fwd_kernel<false>, dim3(gx, ndir), dim3(256), 0, st, dirs[0], d1, B, Hd,
-                           (const long*)lengths, fill, (long)ld_out, drop_p, dropout_threshold(drop_p), drop_site, rng);
-    SLNLP_CHECK_LAUNCH("rnn_cell_fwd");
-    return 0;
+    return zlaunch(lstm ? rnn_cell_fwd_lstm_kernel : rnn_cell_fwd_gru_kernel, dim3(gx, ndir), 256, 0, st, "rnn_cell_fwd", dirs[0], d1, B, Hd,
+                   (const long*)lengths, fill, (long)ld_out, drop_p, dropout_threshold(drop_p), drop_site, rng);
 }
 
 int rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
@@ -285,24 +308,16 @@ int rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, 
     int gx = ceil_div((long)B * Hd, 256);
     if (gx > 1024) gx = 1024;
     const slnlp_rnn_cell_bwd_dir d1 = dirs[ndir - 1];
-    if (lstm)
-        hipLaunchKernelGGL(rnn_cell_bwd_kernel<true>, dim3(gx, ndir), dim3(256), 0, st, dirs[0], d1, B, Hd,
-                           (const long*)lengths, (long)ld_dout, drop_p, dropout_threshold(drop_p), drop_site, rng);
-    else
-        hipLaunchKernelGGL(rnn_cell_bwd_kernel<false>, dim3(gx, ndir), dim3(256), 0, st, dirs[0], d1, B, Hd,
-                           (const long*)lengths, (long)ld_dout, drop_p, dropout_threshold(drop_p), drop_site, rng);
-    SLNLP_CHECK_LAUNCH("rnn_cell_bwd");
-    return 0;
+    return zlaunch(lstm ? rnn_cell_bwd_lstm_kernel : rnn_cell_bwd_gru_kernel, dim3(gx, ndir), 256, 0, st, "rnn_cell_bwd", dirs[0], d1, B, Hd,
+                   (const long*)lengths, (long)ld_dout, drop_p, dropout_threshold(drop_p), drop_site, rng);
 }
 
 int bahdanau_fwd(const float* q, const float* pk, const float* val, const float* we, const int64_t* ids,
                  int64_t ld_ids, int64_t pad, int B, int S, int Hd, float* alphas, float* ctx, hipStream_t st) {
     SLNLP_CHECK_ARG(q && pk && val && we && ids && alphas && ctx, "bahdanau_fwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && S <= BAH_MAXS && Hd > 0, "bahdanau_fwd: S=%d outside 1..%d", S, BAH_MAXS);
-    hipLaunchKernelGGL(bahdanau_fwd_kernel, dim3(B), dim3(256), 0, st, q, pk, val, we, (const long*)ids, (long)ld_ids,
-                       (long)pad, B, S, Hd, alphas, ctx);
-    SLNLP_CHECK_LAUNCH("bahdanau_fwd");
-    return 0;
+    return zlaunch(bahdanau_fwd_kernel, dim3(B), 256, 0, st, "bahdanau_fwd", q, pk, val, we, (const long*)ids, (long)ld_ids, (long)pad, B, S,
+                   Hd, alphas, ctx);
 }
 
 int bahdanau_bwd(const float* q, const float* pk, const float* val, const float* we, const float* alphas,
@@ -311,21 +326,15 @@ int bahdanau_bwd(const float* q, const float* pk, const float* val, const float*
     SLNLP_CHECK_ARG(q && pk && val && we && alphas && dctx && dq && dpk && dval && dwe_part && dwe,
                     "bahdanau_bwd: null pointer");
     SLNLP_CHECK_ARG(B > 0 && S > 0 && S <= BAH_MAXS && Hd > 0, "bahdanau_bwd: S=%d outside 1..%d", S, BAH_MAXS);
-    hipLaunchKernelGGL(bahdanau_bwd_kernel, dim3(B), dim3(256), 0, st, q, pk, val, we, alphas, dctx, B, S, Hd, dq, dpk,
-                       dval, dwe_part);
-    SLNLP_CHECK_LAUNCH("bahdanau_bwd");
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(Hd, 256)), dim3(256), 0, st, dwe_part, B, Hd, dwe);
-    SLNLP_CHECK_LAUNCH("colsum");
-    return 0;
+    SLNLP_TRY(zlaunch(bahdanau_bwd_kernel, dim3(B), 256, 0, st, "bahdanau_bwd", q, pk, val, we, alphas, dctx, B, S, Hd, dq, dpk, dval, dwe_part));
+    return zlaunch(colsum_kernel, dim3(ceil_div(Hd, 256)), 256, 0, st, "colsum", (const float*)dwe_part, B, Hd, dwe);
 }
 
 int add_rows(const float* in, int64_t ld_in, float* out, int64_t ld_out, int R, int C, int accumulate, hipStream_t st) {
     SLNLP_CHECK_ARG(in && out && R > 0 && C > 0, "add_rows: bad args");
     int gx = ceil_div((long)R * C, 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(add_rows_kernel, dim3(gx), dim3(256), 0, st, in, (long)ld_in, out, (long)ld_out, R, C, accumulate);
-    SLNLP_CHECK_LAUNCH("add_rows");
-    return 0;
+    return zlaunch(add_rows_kernel, dim3(gx), 256, 0, st, "add_rows", in, (long)ld_in, out, (long)ld_out, R, C, accumulate);
 }
 
 }  // namespace slnlp

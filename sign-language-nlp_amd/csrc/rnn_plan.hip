@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "launch.hpp"
 
 namespace slnlp {
 
@@ -254,6 +255,10 @@ struct slnlp_rnn_plan {
     bool use_planes = false;  // E, Hd multiples of 64: the M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
     int planes_B = -1;        // batch size the activation planes' zero padding is valid for
     bool persistent = false;  // opt-in: all timesteps of an encoder layer in one launch (not yet faster; needs one fit per GPU)
+    // lockstep (lockstep.hip): where lsm_nll also puts the batch's log-probs / loss (device row and batch index in ls_dyn)
+    float* ls_logp = nullptr;
+    float* ls_loss = nullptr;
+    const int* ls_dyn = nullptr;
 
     float* P(long off) const { return buf.params + off; }
     float* Gd(long off) const { return buf.grads + off; }
@@ -347,10 +352,6 @@ struct slnlp_rnn_plan {
     }
 };
 
-static int fail_memset() {
-    set_error("rnn: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
-    return SLNLP_ERR_LAUNCH;
-}
 
 extern "C" {
 
@@ -428,12 +429,12 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
     // src_embed (nn.Embedding(padding_idx), no scale, no positional term)  bkp.py:48-50
     const bool up = pl->use_planes;
     if (up) {   // the encoder's RNN weights as bf16 planes, once per forward (they changed in the optimizer step / load_state)
-        SLNLP_TRY(pl->prepare_planes(B, st));
+        if (!recording()) SLNLP_TRY(pl->prepare_planes(B, st));   // a memset: the lockstep driver runs it before it records
         SLNLP_TRY(split_planes(pl->buf.params, L.key_w, 1, (int)L.key_w, w.wp.hi, w.wp.lo, L.key_w, st));
     }
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), nullptr, w.emb, 1.f, 0.f, 0, rng, -1, st,
                         up ? w.enc[0].xinp.out() : PlaneOut{}));
-    if (hipMemsetAsync(w.zero_fwd, 0, (size_t)2 * N * c.B * Hd * sizeof(float), st) != hipSuccess) return fail_memset();   // every c_0
+    SLNLP_TRY(fill_zero(w.zero_fwd, (size_t)2 * N * c.B * Hd * sizeof(float), st));   // every c_0
     const float* x_in = w.emb;
     for (int l = 0; l < N; ++l) {
         const EncLayerA& a = w.enc[l];
@@ -449,8 +450,7 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
             if (!up) SLNLP_TRY(pl->lin(x_in, in, M, in, pl->P(q.w_ih), in, GH, pl->P(q.b_ih), a.d[d].xproj, GH, 0, nullptr, st));
             // the state chain lives in the per-timestep `hprev` slots: slot of the first processed timestep = h_0 = 0
             const int t0 = d == 0 ? 0 : S - 1;
-            if (hipMemsetAsync(a.d[d].hprev + (long)t0 * B * Hd, 0, (size_t)B * Hd * sizeof(float), st) != hipSuccess)
-                return fail_memset();
+            SLNLP_TRY(fill_zero(a.d[d].hprev + (long)t0 * B * Hd, (size_t)B * Hd * sizeof(float), st));
         }
         const bool last = l == N - 1;
         // inter-layer dropout (not after the last layer); padded outputs of the LAST layer = float(pad_idx)
@@ -528,7 +528,8 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
     // generator on the decoder state (bkp.py:40-46,69-76) + criterion
     SLNLP_TRY(pl->lin(x_prev, Hd, B, Hd, pl->P(L.gen_w), Hd, c.Vt, nullptr, w.logits, Vp, 0, nullptr, st));
     SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp,
-                      w.row_nll, st, nullptr));
+                      w.row_nll, st, nullptr, logp_out ? nullptr : pl->ls_logp, logp_out ? nullptr : pl->ls_dyn,
+                      logp_out ? nullptr : pl->ls_loss, (!logp_out && pl->ls_dyn) ? pl->ls_dyn + 1 : nullptr));
     if (logp_out &&
         hipMemcpyAsync(logp_out, w.logp, (size_t)B * c.Vt * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
         set_error("rnn_forward: copy of log-probs failed");
@@ -578,7 +579,7 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
     const int64_t *X = pl->last_X, *lengths = pl->last_len;
     const float* enc_out = w.enc[N - 1].out;
 
-    if (hipMemsetAsync(w.zero_bwd, 0, (size_t)4 * N * c.B * Hd * sizeof(float), st) != hipSuccess) return fail_memset();   // dc / dh seeds
+    SLNLP_TRY(fill_zero(w.zero_bwd, (size_t)4 * N * c.B * Hd * sizeof(float), st));   // dc / dh seeds
     // generator (no bias)
     const float* dec_out = w.dec[N - 1].out;
     SLNLP_TRY(pl->wgr(w.dlogits, Vp, B, c.Vt, dec_out, Hd, Hd, pl->Gd(L.gen_w), Hd, nullptr, st));
@@ -779,3 +780,24 @@ int slnlp_rnn_tap(slnlp_rnn_plan* pl, const char* name, float* out, int64_t max_
 }
 
 }  // extern "C"
+
+// ---- hooks of the lockstep driver (lockstep.hip): the plan struct stays private to this file
+namespace slnlp {
+int rnn_ls_prepare(slnlp_rnn_plan* pl, int B, hipStream_t st) { return pl->prepare_planes(B, st); }
+int rnn_ls_record(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum,
+                  float max_norm, hipStream_t st) {
+    SLNLP_CHECK_ARG(!pl->persistent, "lockstep: the persistent RNN layer kernel needs the GPU to itself -- switch it off");
+    SLNLP_TRY(slnlp_rnn_forward(pl, X, y, len, B, train, nullptr, st));
+    if (!train) return 0;
+    SLNLP_TRY(slnlp_rnn_backward(pl, st));
+    return slnlp_rnn_optim(pl, momentum, max_norm, st);
+}
+void rnn_ls_outputs(slnlp_rnn_plan* pl, float* logp, float* loss, const int* dyn) {
+    pl->ls_logp = logp; pl->ls_loss = loss; pl->ls_dyn = dyn;
+}
+void rnn_ls_replayed(slnlp_rnn_plan* pl, int B, int train) {
+    pl->last_B = B;
+    pl->last_p = train ? pl->cfg.dropout : 0.f;
+}
+const slnlp_rnn_config* rnn_ls_cfg(slnlp_rnn_plan* pl) { return &pl->cfg; }
+}  // namespace slnlp

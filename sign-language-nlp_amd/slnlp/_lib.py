@@ -147,6 +147,13 @@ SIGNATURES = {
     "slnlp_tf_lockstep_step": (i32, [vp, i32, i64, i32, i32, i32, C.c_float, C.c_float, vp]),
     "slnlp_tf_lockstep_epoch": (i32, [vp, i32, i32, i32, C.c_float, C.c_float, vp]),
     "slnlp_tf_lockstep_num_launches": (i32, [vp, i32, i32, i32]),
+    "slnlp_rnn_lockstep_workspace_bytes": (i64, [vp, i32]),
+    "slnlp_rnn_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),
+    "slnlp_rnn_lockstep_destroy": (None, [vp]),
+    "slnlp_rnn_lockstep_set_data": (i32, [vp, i32, vp, vp, vp, i64, vp, vp, vp]),
+    "slnlp_rnn_lockstep_step": (i32, [vp, i32, i64, i32, i32, i32, C.c_float, C.c_float, vp]),
+    "slnlp_rnn_lockstep_epoch": (i32, [vp, i32, i32, i32, C.c_float, C.c_float, vp]),
+    "slnlp_rnn_lockstep_num_launches": (i32, [vp, i32, i32, i32]),
 }
 
 _lib = None

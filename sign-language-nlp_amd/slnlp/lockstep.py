@@ -1,4 +1,5 @@
-"""K fits of one shape advancing in lockstep through ONE launch sequence (libslnlp ``slnlp_tf_lockstep_*``).
+"""K fits of one shape advancing in lockstep through ONE launch sequence (libslnlp ``slnlp_tf_lockstep_*`` /
+``slnlp_rnn_lockstep_*``).
 
 The reference runs the (candidate x fold) fits of its grid one at a time per worker
 (/root/reference/main.py:70-78, helper.py:490-526).  One batch-50 fit cannot fill an MI355X -- its decoder stages
@@ -27,59 +28,71 @@ def _ptr_array(tensors):
 
 
 class LockstepGroup:
-    """The fits' TransformerEngines (same configuration up to the dropout rate) stepping together."""
+    """The fits' engines -- all TransformerEngines or all RnnEngines, same configuration up to the dropout rate -- stepping
+    together."""
 
     def __init__(self, engines):
         cfg = engines[0].cfg
         self.engines, self.K, self.device = list(engines), len(engines), engines[0].device
-        nbytes = int(load().slnlp_tf_lockstep_workspace_bytes(C.byref(cfg), self.K))
+        self.kind = "rnn" if type(engines[0]).__name__ == "RnnEngine" else "tf"
+        assert all(type(e) is type(engines[0]) for e in engines), "lockstep: one engine type per group"
+        self._fn = lambda name: getattr(load(), f"slnlp_{self.kind}_lockstep_{name}")
+        nbytes = int(self._fn("workspace_bytes")(C.byref(cfg), self.K))
         if nbytes < 0:
             raise RuntimeError("lockstep: bad configuration")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         handles = (C.c_void_p * self.K)(*[e.handle for e in self.engines])
         out = C.c_void_p()
-        check(load().slnlp_tf_lockstep_create(handles, self.K, ptr(self.workspace), nbytes, stream_ptr(), C.byref(out)),
-              "tf_lockstep_create")
+        check(self._fn("create")(handles, self.K, ptr(self.workspace), nbytes, stream_ptr(), C.byref(out)), f"{self.kind}_lockstep_create")
         self.handle = out
         self.data, self.logp, self.loss, self.rows = {}, {}, {}, {}
 
     def close(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:
-            load().slnlp_tf_lockstep_destroy(h)
+            self._fn("destroy")(h)
 
     __del__ = close
 
-    def set_data(self, slot, Xs, ys, batch):
-        """Per-fit datasets of one slot (device int64 [rows, S] / [rows], the same number of rows for every fit).  Allocates
-        the slot's output buffers: ``logp[slot][f]`` [rows, Vt] and ``loss[slot][f]`` [ceil(rows / batch)]."""
+    def set_data(self, slot, Xs, ys, batch, lengths=None):
+        """Per-fit datasets of one slot (device int64 [rows, S] / [rows], the same number of rows for every fit; RNN fits also
+        pass the sequence lengths [rows]).  Allocates the slot's output buffers: ``logp[slot][f]`` [rows, Vt] and
+        ``loss[slot][f]`` [ceil(rows / batch)]."""
         rows = int(Xs[0].shape[0])
         assert len(Xs) == len(ys) == self.K and all(x.shape[0] == rows and x.is_contiguous() for x in Xs)
         Vt = self.engines[0].cfg.Vt
         nb = (rows + batch - 1) // batch
-        self.data[slot] = (list(Xs), list(ys))           # keep the tensors alive: the C side holds raw pointers
         self.logp[slot] = [torch.empty(rows, Vt, dtype=torch.float32, device=self.device) for _ in range(self.K)]
         self.loss[slot] = [torch.zeros(nb, dtype=torch.float32, device=self.device) for _ in range(self.K)]
         self.rows[slot] = rows
-        check(load().slnlp_tf_lockstep_set_data(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), rows,
-                                                _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), stream_ptr()),
-              "tf_lockstep_set_data")
+        if self.kind == "rnn":
+            assert lengths is not None and len(lengths) == self.K, "lockstep: RNN fits need the sequence lengths"
+            lengths = [l.contiguous() for l in lengths]
+            self.data[slot] = (list(Xs), list(ys), lengths)   # keep the tensors alive: the C side holds raw pointers
+            check(self._fn("set_data")(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), _ptr_array(lengths), rows,
+                                       _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), stream_ptr()), "rnn_lockstep_set_data")
+        else:
+            self.data[slot] = (list(Xs), list(ys))
+            check(self._fn("set_data")(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), rows,
+                                       _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), stream_ptr()), "tf_lockstep_set_data")
+
+    def _sync_versions(self):
+        for e in self.engines:                           # Transformer: weight planes follow outside writes to the fp32 arena
+            if hasattr(e, "sync_params_version"):
+                e.sync_params_version()
 
     def step(self, slot, row0, B, step_index, train, momentum=0.9, max_norm=0.5):
-        for e in self.engines:
-            e.sync_params_version()
-        check(load().slnlp_tf_lockstep_step(self.handle, slot, row0, B, step_index, int(train), momentum, max_norm, stream_ptr()),
-              "tf_lockstep_step")
+        self._sync_versions()
+        check(self._fn("step")(self.handle, slot, row0, B, step_index, int(train), momentum, max_norm, stream_ptr()),
+              f"{self.kind}_lockstep_step")
 
     def epoch(self, slot, batch, train, momentum=0.9, max_norm=0.5):
         """One pass over the slot in dataset order; no host synchronisation.  Results: ``logp[slot]``, ``loss[slot]``."""
-        for e in self.engines:
-            e.sync_params_version()
-        check(load().slnlp_tf_lockstep_epoch(self.handle, slot, batch, int(train), momentum, max_norm, stream_ptr()),
-              "tf_lockstep_epoch")
+        self._sync_versions()
+        check(self._fn("epoch")(self.handle, slot, batch, int(train), momentum, max_norm, stream_ptr()), f"{self.kind}_lockstep_epoch")
 
     def num_launches(self, slot, B, train):
-        return int(load().slnlp_tf_lockstep_num_launches(self.handle, slot, B, int(train)))
+        return int(self._fn("num_launches")(self.handle, slot, B, int(train)))
 
     def results(self, slot, f, batch):
         """What ``NeuralNetClassifier._run_epoch`` returns for fit ``f``: (batch-size weighted mean loss, log-probs [rows, Vt],
@@ -92,9 +105,12 @@ class LockstepGroup:
         return mean, self.logp[slot][f], list(zip(per_batch.tolist(), sizes))
 
 
+LOCKSTEP_MODULES = ("Transformer", "EncoderDecoderLSTMAttn", "EncoderDecoderGRUAttn")
+
+
 def lockstep_supported(net):
-    """Fused SGD + CrossEntropyLoss on a Transformer module: what the lockstep launch sequence implements."""
-    return getattr(net, "_fused_kind", None) == "sgd" and type(net.module_).__name__ == "Transformer"
+    """Fused SGD + CrossEntropyLoss on one of the path's three modules: what the lockstep launch sequences implement."""
+    return getattr(net, "_fused_kind", None) == "sgd" and type(net.module_).__name__ in LOCKSTEP_MODULES
 
 
 def fit_lockstep(nets, datasets):
@@ -105,7 +121,8 @@ def fit_lockstep(nets, datasets):
     K = len(nets)
     runs = [_FitRun(n, d) for n, d in zip(nets, datasets)]
     r0 = runs[0]
-    assert all(lockstep_supported(n) for n in nets), "lockstep: fused SGD + CrossEntropyLoss on model.Transformer only"
+    assert all(lockstep_supported(n) for n in nets), "lockstep: fused SGD + CrossEntropyLoss on the model.* modules only"
+    assert len({type(n.module_) for n in nets}) == 1, "lockstep: one module class per group"
     assert all((r.bs, r.momentum, r.max_norm, len(r.tr), (len(r.va) if r.va is not None else 0)) ==
                (r0.bs, r0.momentum, r0.max_norm, len(r0.tr), (len(r0.va) if r0.va is not None else 0)) for r in runs), \
         "lockstep: the fits of a group share batch size, momentum, clipping and split sizes"
@@ -121,9 +138,11 @@ def fit_lockstep(nets, datasets):
                     torch.cuda.synchronize()
                     group.close()
                 group = LockstepGroup([engines[i] for i in active])
-                group.set_data(TRAIN, [runs[i].Xtr for i in active], [runs[i].ytr for i in active], r0.bs)
+                group.set_data(TRAIN, [runs[i].Xtr for i in active], [runs[i].ytr for i in active], r0.bs,
+                               [runs[i].Ltr for i in active])
                 if r0.va is not None:
-                    group.set_data(VALID, [runs[i].Xva for i in active], [runs[i].yva for i in active], r0.bs)
+                    group.set_data(VALID, [runs[i].Xva for i in active], [runs[i].yva for i in active], r0.bs,
+                                   [runs[i].Lva for i in active])
                 members = list(active)
             for i in active:
                 engines[i].set_lr(nets[i].lr_)
@@ -157,7 +176,7 @@ def predict_proba_lockstep(nets, datasets):
         for n in nets:
             n.module_.eval()
         group = LockstepGroup(engines)
-        group.set_data(TEST, [d[0] for d in dev], [d[2] for d in dev], bs)
+        group.set_data(TEST, [d[0] for d in dev], [d[2] for d in dev], bs, [d[1] for d in dev])
         group.epoch(TEST, bs, False)
         out = [torch.softmax(lp, dim=-1) if n.predict_nonlinearity == "auto" else lp for n, lp in zip(nets, group.logp[TEST])]
         torch.cuda.synchronize()
@@ -183,7 +202,8 @@ def fit_and_score_group(estimator_factory, params_list, trains, tests, scoring="
                 torch.manual_seed(seed)
             net.initialize()
         nets.append(net)
-    if not all(lockstep_supported(n) for n in nets) or len({len(t) for t in trains}) != 1 or len({len(t) for t in tests}) != 1:
+    if not all(lockstep_supported(n) for n in nets) or len({type(n.module_) for n in nets}) != 1 or \
+            len({len(t) for t in trains}) != 1 or len({len(t) for t in tests}) != 1:
         del nets
         return [default_fit_and_score(estimator_factory, p, tr, te, scoring, seed=s)
                 for p, tr, te, s in zip(params_list, trains, tests, seeds)]
