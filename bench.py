@@ -160,7 +160,7 @@ def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
     """Aggregate train seq/s of K independent fits of this workload sharing the GPU by advancing in LOCKSTEP through one
     launch sequence (slnlp/lockstep.py: own weights, lr, seed and data per fit; bit-identical to solo fits) -- how
     ShardedGridSearchCV(lockstep=k) runs a work unit.  A single batch-50 fit leaves most CUs idle in its decoder stages."""
-    from slnlp import synth, tf_engine as te
+    from slnlp import synth, tf_engine as te, rnn_engine as re_
     from slnlp.lockstep import LockstepGroup
     B, S = c["B"], c["S"]
     rows = steps * B
@@ -170,15 +170,15 @@ def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
         engs, data = [], []
         for i in range(k):
             cfg, sd = build_sd(c, seed=101 + i)
-            e = te.TransformerEngine(cfg, device=dev, seed=101 + i)
+            e = (re_.RnnEngine if "rnn" in c else te.TransformerEngine)(cfg, device=dev, seed=101 + i)
             e.load_state(sd)
             e.set_lr(LR)
-            Xn, _, yn = synth.make_batch(rows, S, c["Vs"], c["Vt"], seed=101 + i)
+            Xn, Ln, yn = synth.make_batch(rows, S, c["Vs"], c["Vt"], seed=101 + i)
             engs.append(e)
-            data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev)))
+            data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev), torch.from_numpy(Ln).to(dev)))
         with torch.cuda.stream(st):
             grp = LockstepGroup(engs)
-            grp.set_data(0, [d[0] for d in data], [d[1] for d in data], B)
+            grp.set_data(0, [d[0] for d in data], [d[1] for d in data], B, [d[2] for d in data])
             grp.epoch(0, B, True, MOMENTUM, MAX_NORM)          # records the launch program
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--precision", type=int, default=3)
     args = ap.parse_args()
-    from slnlp import synth, tf_engine as te
+    from slnlp import synth, tf_engine as te, rnn_engine as re_
     from slnlp.lockstep import LockstepGroup
     dev = torch.device("cuda", 0)
     c = dict(bench.WORKLOADS[args.workload], precision=args.precision)
@@ -37,15 +37,15 @@ def main():
         engs, data = [], []
         for f in range(K):
             cfg, sd = bench.build_sd(c, seed=1 + f)
-            e = te.TransformerEngine(cfg, device=dev, seed=1 + f)
+            e = (re_.RnnEngine if "rnn" in c else te.TransformerEngine)(cfg, device=dev, seed=1 + f)
             e.load_state(sd)
             e.set_lr(0.01)
-            Xn, _, yn = synth.make_batch(rows, S, c["Vs"], c["Vt"], seed=1 + f)
+            Xn, Ln, yn = synth.make_batch(rows, S, c["Vs"], c["Vt"], seed=1 + f)
             engs.append(e)
-            data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev)))
+            data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev), torch.from_numpy(Ln).to(dev)))
         with torch.cuda.stream(st):
             grp = LockstepGroup(engs)
-            grp.set_data(0, [d[0] for d in data], [d[1] for d in data], B)
+            grp.set_data(0, [d[0] for d in data], [d[1] for d in data], B, [d[2] for d in data])
             grp.epoch(0, B, True, 0.9, 0.5)              # warm-up pass (records the program)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
