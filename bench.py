@@ -522,9 +522,8 @@ def main():
                     out["roofline_fp8"] = fp8_kernel_roofline(c, dev)
             if dk:
                 out["roofline"] = dk
-            if world == 1 and not args.no_cpu_baseline:
-                if args.precision != 8:
-                    out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
+        if world == 1 and not args.no_cpu_baseline and args.precision != 8:
+            out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
         out.setdefault("roofline", dict(out["roofline_step"]))   # RNN workloads: no single dominant GEMM, the step is the unit
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(c, sd0, torch.from_numpy(Xn), torch.from_numpy(yn), torch.from_numpy(Ln))
