@@ -52,12 +52,53 @@ class ArenaModule(nn.Module):
 
     _dead_params = frozenset()
 
-    def _setup_arena(self, entries, total, init_values):
+    def _setup_arena(self, entries, total, init_values, recipe=None, recipe_seed=0):
+        """init_values: {name: tensor} drawn by the caller (the reference-identical CPU stream), or None with a `recipe`
+        {name: (kind, scale[, zero_row])}: the same distributions drawn by ``_materialize`` on whatever device the arena lands
+        on, from a generator seeded with `recipe_seed` -- no CPU modules are built and no global RNG is consumed."""
         self._entries = entries
         self._param_names = [n for n, _, _ in entries]
         self._engines = {}
         self._opt_state = None      # (grads, momentum, rng, lr) on the device: ONE set per module, shared by every plan
-        self._build(torch.zeros(total, dtype=torch.float32), init_values)
+        self._pending_recipe = None
+        if init_values is None:
+            assert recipe is not None, "either initial values or an init recipe"
+            self._pending_recipe = (dict(recipe), int(recipe_seed))
+            self._build(torch.empty(total, dtype=torch.float32))      # untouched pages until it is materialised
+        else:
+            self._build(torch.zeros(total, dtype=torch.float32), init_values)
+
+    def _materialize(self):
+        """Draw the pending init recipe into the arena, on the arena's device (one generator, tensors in layout order)."""
+        pend = getattr(self, "_pending_recipe", None)
+        if pend is None:
+            return
+        recipe, seed = pend
+        self._pending_recipe = None
+        arena = self._arena
+        g = torch.Generator(device=arena.device)
+        g.manual_seed(seed)
+        with torch.no_grad():
+            for name, shape, off in self._entries:
+                n = 1
+                for d in shape:
+                    n *= d
+                v = arena[off:off + n].view(*shape)
+                kind, scale, *rest = recipe[name]
+                if kind == "normal":
+                    v.normal_(0.0, scale, generator=g)
+                elif kind == "uniform":
+                    v.uniform_(-scale, scale, generator=g)
+                elif kind == "const":
+                    v.fill_(scale)
+                else:
+                    raise ValueError(f"init recipe: unknown kind {kind!r} for {name}")
+                if rest and rest[0] is not None:
+                    v[rest[0]].zero_()                   # nn.Embedding(padding_idx=...) keeps that row at zero
+
+    def state_dict(self, *args, **kwargs):
+        self._materialize()
+        return super().state_dict(*args, **kwargs)
 
     def _shared_state(self):
         """Gradient / momentum arenas, dropout rng {seed, step} and lr live on the module, not on a plan: training with
@@ -109,12 +150,16 @@ class ArenaModule(nn.Module):
         if device != self._arena.device:
             grads = {n: p.grad for n, p in self.named_parameters() if p.grad is not None}
             self._move_buffers(device)
-            self._build(self._arena.detach().to(device))
+            if getattr(self, "_pending_recipe", None) is not None:      # nothing drawn yet: allocate there, draw there
+                self._build(torch.empty(self._arena.numel(), dtype=torch.float32, device=device))
+            else:
+                self._build(self._arena.detach().to(device))
             for n, p in self.named_parameters():
                 if n in grads:
                     p.grad = grads[n].to(device)
             self._engines = {}
         self.device = device
+        self._materialize()
         return self
 
     def _move_buffers(self, device):
@@ -131,6 +176,7 @@ class ArenaModule(nn.Module):
         if not self._arena.is_cuda:
             raise RuntimeError("%s: the module is on %s -- the HIP path is the only compute path "
                                "(no CPU fallback); call .to('cuda') first" % (type(self).__name__, self._arena.device))
+        self._materialize()
         eng = self._engines.get(S)
         if eng is None or eng.cfg.B < B:
             old = eng
@@ -153,6 +199,7 @@ class ArenaModule(nn.Module):
     # and pickle restore every tensor separately, so the parameters would stop aliasing ``_arena`` (the memory the HIP
     # plans compute from): ``__setstate__`` re-creates them as views of the restored arena.
     def __getstate__(self):
+        self._materialize()
         d = self.__dict__.copy()
         d["_engines"] = {}
         d["_opt_state"] = None

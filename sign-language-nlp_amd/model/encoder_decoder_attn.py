@@ -9,6 +9,8 @@ log-probs [B, V]``, same ``state_dict()`` keys (``model.encoder.rnn.weight_ih_l0
 ``model.generator.proj.weight``).  Quirks kept on purpose: the decoder is
 unrolled for exactly one step fed ``<bos>`` (index 0 on a torchtext-0.6 target vocab), so the
 output does not depend on ``y``; padded encoder outputs hold float(pad_idx)."""
+import math
+
 import torch
 import torch.nn as nn
 
@@ -44,6 +46,24 @@ def _reference_init(rnn_type, E, Hd, N, dropout, Vs, Vt, pad_src, pad_tgt):
                "model.decoder.pre_output_layer.weight": pre.weight, "model.src_embed.weight": src.weight,
                "model.trg_embed.weight": trg.weight, "model.generator.proj.weight": gen.weight})
     return {k: v.detach() for k, v in sd.items()}
+
+
+def _init_recipe(entries, E, Hd, pad_src, pad_tgt):
+    """The distributions ``_reference_init`` draws (torch defaults: nn.LSTM / nn.GRU U(+-1/sqrt(Hd)) for every tensor,
+    nn.Linear U(+-1/sqrt(fan_in)), embeddings N(0, 1) with a zero padding row) without building the torch modules."""
+    rec = {}
+    for name, shape, _ in entries:
+        if ".rnn." in name:
+            rec[name] = ("uniform", 1.0 / math.sqrt(Hd))
+        elif name == "model.src_embed.weight":
+            rec[name] = ("normal", 1.0, pad_src)
+        elif name == "model.trg_embed.weight":
+            rec[name] = ("normal", 1.0, pad_tgt)
+        elif name == "model.decoder.bridge.bias":
+            rec[name] = ("uniform", 1.0 / math.sqrt(2 * Hd))
+        else:                                                       # bias-free Linear weights [out, in]
+            rec[name] = ("uniform", 1.0 / math.sqrt(shape[1]))
+    return rec
 
 
 class EncoderDecoderAttnBase(ArenaModule):
@@ -83,9 +103,14 @@ class EncoderDecoderAttnBase(ArenaModule):
                               bos_idx=util.get_bos_idx(tgt_vocab),      # 0 when '<bos>' is not in the vocab
                               dropout=self.dropout_p if num_layers > 1 else 0.0, precision=self.precision)
         entries, total = re_.layout(re_.make_config(B=1, S=1, **self._cfg_args))
-        init = _reference_init(rnn_type, embedding_size, hidden_size, num_layers, self.dropout_p,
-                               len(src_vocab), len(tgt_vocab), pad_src, pad_tgt)
-        self._setup_arena(entries, total, init)
+        self.init = kwargs.get("init", "reference")             # see model/transformer.py
+        assert self.init in ("reference", "recipe"), "init must be 'reference' or 'recipe'"
+        if self.init == "recipe":
+            self._setup_arena(entries, total, None, _init_recipe(entries, embedding_size, hidden_size, pad_src, pad_tgt), torch.initial_seed())
+        else:
+            init = _reference_init(rnn_type, embedding_size, hidden_size, num_layers, self.dropout_p,
+                                   len(src_vocab), len(tgt_vocab), pad_src, pad_tgt)
+            self._setup_arena(entries, total, init)
 
     def _state_order(self, views):
         return [(n, views[n], True) for n in self._param_names]

@@ -14,6 +14,8 @@ raises.  Autograd integration: in training mode ``forward`` is a
 each parameter its gradient, so stock ``torch.optim`` / skorch loops work;
 ``slnlp.net.NeuralNetClassifier`` uses the fused clip+SGD step instead.
 """
+import math
+
 import torch
 import torch.nn as nn
 
@@ -37,6 +39,30 @@ def _reference_init(E, H, N, F, dropout, Vs, Vt):
     for k, v in tr.state_dict().items():
         sd["transformer." + k] = v
     return {k: v.detach() for k, v in sd.items()}
+
+
+def _init_recipe(entries, E, F):
+    """The distributions ``_reference_init`` draws, per tensor, without building the torch modules: embeddings N(0, 1);
+    every matrix inside nn.Transformer xavier-uniform (its _reset_parameters); attention biases 0, LayerNorm (1, 0); the FFN
+    biases and the output Linear keep nn.Linear's default U(+-1/sqrt(fan_in)).  Same distributions, NOT the same stream."""
+    rec = {}
+    for name, shape, _ in entries:
+        leaf = name.rsplit(".", 1)[-1]
+        if name in ("src_embedding.weight", "tgt_embedding.weight"):
+            rec[name] = ("normal", 1.0)
+        elif name == "linear.weight" or name == "linear.bias":
+            rec[name] = ("uniform", 1.0 / math.sqrt(E))
+        elif len(shape) > 1:
+            rec[name] = ("uniform", math.sqrt(6.0 / (shape[0] + shape[1])))
+        elif "norm" in name:
+            rec[name] = ("const", 1.0 if leaf == "weight" else 0.0)
+        elif name.endswith("linear1.bias"):
+            rec[name] = ("uniform", 1.0 / math.sqrt(E))
+        elif name.endswith("linear2.bias"):
+            rec[name] = ("uniform", 1.0 / math.sqrt(F))
+        else:                                                       # in_proj_bias, out_proj.bias
+            rec[name] = ("const", 0.0)
+    return rec
 
 
 class Transformer(ArenaModule):
@@ -72,9 +98,18 @@ class Transformer(ArenaModule):
                               dropout=self.dropout_p, precision=self.precision)
         entries, total = te.layout(te.make_config(B=1, S=1, **self._cfg_args))   # host query of the arena layout
         self._pe = te.positional_table(5000, embedding_size).unsqueeze(1)        # [5000, 1, E] like the reference buffer
-        init = _reference_init(embedding_size, num_heads, num_layers, hidden_size, self.dropout_p,
-                               len(src_vocab), len(tgt_vocab))
-        self._setup_arena(entries, total, init)
+        # init="reference" (default): bit-identical to the reference's modules under the same torch seed (builds them on the
+        # CPU: 0.2 s at E512 N6, 0.4 s at E1024 N6, all of it under the global RNG).  init="recipe": the same distributions
+        # drawn on the device from a generator seeded with torch.initial_seed() -- what grid-search fits use, whose initial
+        # weights the reference does not define either (they depend on which dask worker runs the fit).
+        self.init = kwargs.get("init", "reference")
+        assert self.init in ("reference", "recipe"), "init must be 'reference' or 'recipe'"
+        if self.init == "recipe":
+            self._setup_arena(entries, total, None, _init_recipe(entries, embedding_size, hidden_size), torch.initial_seed())
+        else:
+            init = _reference_init(embedding_size, num_heads, num_layers, hidden_size, self.dropout_p,
+                                   len(src_vocab), len(tgt_vocab))
+            self._setup_arena(entries, total, init)
 
     # registration order = the reference's state_dict order (pe buffers sit after each embedding)
     def _state_order(self, views):

@@ -197,3 +197,48 @@ def test_product_package_never_imports_the_oracle():
                 if pat.search(open(path, encoding="utf-8").read()):
                     offenders.append(path)
     assert not offenders, offenders
+
+
+@pytest.mark.parametrize("cls_name,kw", [("Transformer", dict(embedding_size=64, num_heads=4, num_layers=2, hidden_size=96)),
+                                         ("EncoderDecoderLSTMAttn", dict(embedding_size=32, hidden_size=48, num_layers=2)),
+                                         ("EncoderDecoderGRUAttn", dict(embedding_size=32, hidden_size=48, num_layers=2))])
+def test_recipe_init_draws_the_reference_distributions(cls_name, kw):
+    """init="recipe" (what the grid's CV fits use): no torch modules are built and the global RNG is not consumed; every
+    tensor has the distribution the reference-identical init gives it (same zeros / ones, same spread and range), the draw is
+    a pure function of the torch seed, and the parameters still alias the arena."""
+    import model
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(50, seq_len=12, src_vocab=64, n_labels=6, seed=5, min_len=3)
+    cls = getattr(model, cls_name)
+    mk = lambda **extra: cls(src_vocab=ds.vocab_X, tgt_vocab=ds.vocab_y, batch_first=True, dropout=0.1, **kw, **extra)
+    torch.manual_seed(3)
+    ref = mk().state_dict()
+    torch.manual_seed(3)
+    before = torch.random.get_rng_state()
+    rec_mod = mk(init="recipe")
+    assert torch.equal(torch.random.get_rng_state(), before), "recipe init must not consume the global CPU stream"
+    rec = rec_mod.state_dict()                                        # materialises the draw (here: on the CPU)
+    assert list(ref) == list(rec)
+    for k, a in ref.items():
+        b = rec[k]
+        assert a.shape == b.shape, k
+        if k.endswith(".pe"):
+            continue
+        a, b = a.float(), b.float()
+        const = float(a.std()) == 0.0 if a.numel() > 1 else True
+        if const and a.numel() > 1:
+            assert torch.equal(a, b), k                               # biases at 0, LayerNorm at (1, 0)
+        elif a.numel() >= 256:
+            assert abs(float(a.std()) - float(b.std())) <= 0.12 * float(a.std()), (k, float(a.std()), float(b.std()))
+            assert abs(float(b.mean())) <= 4 * float(a.std()) / a.numel() ** 0.5 + 1e-3, k
+            if "embed" not in k:                                      # uniform tensors: same bound
+                assert float(b.abs().max()) <= float(a.abs().max()) * 1.1, k
+        assert torch.equal(a == 0, b == 0) or not k.endswith("embed.weight"), k      # the zero padding rows
+    torch.manual_seed(3)
+    again = mk(init="recipe").state_dict()
+    assert all(torch.equal(rec[k], again[k]) for k in rec)
+    torch.manual_seed(4)
+    other = mk(init="recipe").state_dict()
+    assert any(not torch.equal(rec[k], other[k]) for k in rec)
+    p0 = next(rec_mod.parameters())
+    assert p0.untyped_storage().data_ptr() == rec_mod._arena.untyped_storage().data_ptr()

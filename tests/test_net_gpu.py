@@ -355,3 +355,27 @@ def test_fused_adam_equals_torch_adam():
             # agree to ~1e-3 of their mean size (measured 9e-4 on the embedding), the losses above to 1e-5
             assert a.shape == b.shape and float((a - b).abs().mean()) <= 5e-3 * max(1e-6, float(b.abs().mean())) + 1e-12, (i, key)
     torch.optim.Adam(nets[1].module_.parameters(), lr=1.0).load_state_dict(got)         # the stock optimizer accepts it
+
+
+def test_recipe_init_on_the_device_trains_and_is_reproducible():
+    """module__init="recipe": the weights are drawn on the GPU (no CPU modules, no host-to-device copy of the arena), the same
+    torch seed gives the same weights, a fit on them descends, and ShardedGridSearchCV uses it for the CV fits only (the
+    refit keeps the reference-identical stream)."""
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV
+    ds = synthetic_dataset(120, seq_len=12, src_vocab=64, n_labels=6, seed=5, min_len=3)
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(21)
+        nets.append(make_net(ds, max_epochs=4, dropout=0.1, module__init="recipe").initialize())
+    a, b = nets[0].module_.state_dict(), nets[1].module_.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a) and nets[0].module_._arena.is_cuda
+    w = a["transformer.encoder.layers.0.linear1.weight"]
+    bound = (6.0 / (w.shape[0] + w.shape[1])) ** 0.5
+    assert float(w.abs().max()) <= bound and float(w.std()) > 0.5 * bound              # xavier-uniform, drawn
+    assert float(a["transformer.encoder.layers.0.norm1.weight"].min()) == 1.0
+    nets[0].partial_fit(ds)
+    h = nets[0].history
+    assert h[-1]["train_loss"] < h[0]["train_loss"]
+    gs = ShardedGridSearchCV(lambda: make_net(ds, max_epochs=1, dropout=0.1), {"lr": [0.1, 0.01]}, cv=2, refit=True, device="cuda").fit(ds)
+    assert gs.recipe_init and gs.best_estimator_.module_.init == "reference" and np.isfinite(gs.best_score_)
