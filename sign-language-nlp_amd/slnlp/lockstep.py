@@ -36,7 +36,6 @@ class LockstepGroup:
         self.engines, self.K, self.device = list(engines), len(engines), engines[0].device
         self.kind = "rnn" if type(engines[0]).__name__ == "RnnEngine" else "tf"
         assert all(type(e) is type(engines[0]) for e in engines), "lockstep: one engine type per group"
-        self._fn = lambda name: getattr(load(), f"slnlp_{self.kind}_lockstep_{name}")
         nbytes = int(self._fn("workspace_bytes")(C.byref(cfg), self.K))
         if nbytes < 0:
             raise RuntimeError("lockstep: bad configuration")
@@ -46,6 +45,9 @@ class LockstepGroup:
         check(self._fn("create")(handles, self.K, ptr(self.workspace), nbytes, stream_ptr(), C.byref(out)), f"{self.kind}_lockstep_create")
         self.handle = out
         self.data, self.logp, self.loss, self.rows = {}, {}, {}, {}
+
+    def _fn(self, name):                                 # a method, not a closure over self: no reference cycle
+        return getattr(load(), f"slnlp_{self.kind}_lockstep_{name}")
 
     def close(self):
         h, self.handle = getattr(self, "handle", None), None
