@@ -403,7 +403,9 @@ int slnlp_rnn_create(const slnlp_rnn_config* cfg, const slnlp_tf_buffers* buf, s
     std::vector<int64_t> bos(cfg->B, (int64_t)cfg->bos_idx);
     if (hipMemcpy(p->w.bos_ids, bos.data(), bos.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess ||   // pre_output_layer + pads stay 0
-        hipMemset(p->w.sync, 0, 64 * sizeof(unsigned)) != hipSuccess || rnn_layer_init() != 0 || gemm_planes_init() != 0) {
+        hipMemset(p->w.sync, 0, 64 * sizeof(unsigned)) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess ||      // null-stream memsets must not land inside the caller's first step
+        rnn_layer_init() != 0 || gemm_planes_init() != 0) {
         set_error("rnn_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
         delete p;
         return SLNLP_ERR_LAUNCH;

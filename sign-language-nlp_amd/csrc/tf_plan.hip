@@ -126,7 +126,11 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     }
     ent(p->w.lnp_fin, p->L.decn_w, p->L.decn_b, nbD);
     ok = ok && hipMemcpy(p->w.ln_table, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(buf->grads, 0, p->L.total * sizeof(float)) == hipSuccess;
+         hipMemset(buf->grads, 0, p->L.total * sizeof(float)) == hipSuccess &&
+         // the memset runs on the null stream, which does NOT order itself against the caller's non-blocking stream: without
+         // this wait it can land after the first backward has written gradients (seen with several host threads, whose
+         // initialisation kernels queue up on the null stream: grid scores differed from run to run)
+         hipStreamSynchronize(nullptr) == hipSuccess;
     if (!ok) {
         set_error("tf_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
         slnlp_tf_destroy(p);

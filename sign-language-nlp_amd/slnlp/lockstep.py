@@ -119,9 +119,13 @@ def fit_lockstep(nets, datasets):
     """``net.partial_fit(ds)`` for every (net, ds) pair, all fits advancing together.  The nets must be initialised,
     of one shape (lr and dropout rate may differ) and their datasets of one size; fits that stop early (EarlyStopping)
     leave the group, the others go on."""
-    from .net import _FitRun
+    from .net import _FitRun, stream_sync
     K = len(nets)
-    runs = [_FitRun(n, d) for n, d in zip(nets, datasets)]
+    stream = nets[0]._stream
+    assert all(n._stream is stream for n in nets), "lockstep: the fits of a group share the device's stream"
+    nets[0]._enter_stream()                             # the stream waits for whatever this thread queued elsewhere so far
+    with torch.cuda.stream(stream):
+        runs = [_FitRun(n, d) for n, d in zip(nets, datasets)]
     r0 = runs[0]
     assert all(lockstep_supported(n) for n in nets), "lockstep: fused SGD + CrossEntropyLoss on the model.* modules only"
     assert len({type(n.module_) for n in nets}) == 1, "lockstep: one module class per group"
@@ -129,15 +133,15 @@ def fit_lockstep(nets, datasets):
                (r0.bs, r0.momentum, r0.max_norm, len(r0.tr), (len(r0.va) if r0.va is not None else 0)) for r in runs), \
         "lockstep: the fits of a group share batch size, momentum, clipping and split sizes"
     S = r0.Xtr.shape[1]
-    engines = [n.module_.engine(r0.bs, S) for n in nets]
-    stream = nets[0]._stream
+    with torch.cuda.stream(stream):
+        engines = [n.module_.engine(r0.bs, S) for n in nets]
     active, group = [i for i in range(K) if not runs[i].done], None
     members = None
     with torch.cuda.stream(stream):
         while active:
             if members != active:                       # a fit left (or first epoch): regroup the ones still training
                 if group is not None:
-                    torch.cuda.synchronize()
+                    stream_sync(stream)
                     group.close()
                 group = LockstepGroup([engines[i] for i in active])
                 group.set_data(TRAIN, [runs[i].Xtr for i in active], [runs[i].ytr for i in active], r0.bs,
@@ -153,7 +157,7 @@ def fit_lockstep(nets, datasets):
             group.epoch(TRAIN, r0.bs, True, r0.momentum, r0.max_norm)
             if r0.va is not None:
                 group.epoch(VALID, r0.bs, False, r0.momentum, r0.max_norm)
-            torch.cuda.synchronize()                    # one host sync per epoch for all K fits
+            stream_sync(stream)                         # one host sync per epoch for all K fits
             nxt = []
             for j, i in enumerate(active):
                 tr = group.results(TRAIN, j, r0.bs)
@@ -161,7 +165,7 @@ def fit_lockstep(nets, datasets):
                 if not runs[i].end_epoch(tr, va):
                     nxt.append(i)
             active = nxt
-    torch.cuda.synchronize()
+    stream_sync(stream)
     if group is not None:
         group.close()
     return nets
@@ -170,18 +174,20 @@ def fit_lockstep(nets, datasets):
 def predict_proba_lockstep(nets, datasets):
     """``net.predict_proba(ds)`` for every pair through one launch sequence (eval-mode forward, softmax of the log-probs as
     skorch's predict_nonlinearity='auto' does)."""
+    from .net import stream_sync
     bs = int(nets[0].batch_size)
-    dev = [n._device_data(d) for n, d in zip(nets, datasets)]
-    S = dev[0][0].shape[1]
-    engines = [n.module_.engine(bs, S) for n in nets]
+    nets[0]._enter_stream()
     with torch.cuda.stream(nets[0]._stream):
+        dev = [n._device_data(d) for n, d in zip(nets, datasets)]
+        S = dev[0][0].shape[1]
+        engines = [n.module_.engine(bs, S) for n in nets]
         for n in nets:
             n.module_.eval()
         group = LockstepGroup(engines)
         group.set_data(TEST, [d[0] for d in dev], [d[2] for d in dev], bs, [d[1] for d in dev])
         group.epoch(TEST, bs, False)
         out = [torch.softmax(lp, dim=-1) if n.predict_nonlinearity == "auto" else lp for n, lp in zip(nets, group.logp[TEST])]
-        torch.cuda.synchronize()
+        stream_sync(nets[0]._stream)
         out = [o.cpu().numpy() for o in out]
         group.close()
     return out

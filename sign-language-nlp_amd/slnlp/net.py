@@ -35,6 +35,34 @@ from .data import TokenDataset
 # module construction consumes torch's global CPU generator (initial weights): concurrent fits take turns
 INIT_LOCK = threading.RLock()
 
+# ONE stream per device for every estimator of the process.  Measured on MI355X / ROCm 7.2 (tools/probe_concurrent*.py): when
+# kernels of this library run on several hardware queues at once -- three fits on three streams -- a consumer kernel can read
+# 64-byte pieces of its producer kernel's output stale (whole LayerNorm-backward rows changed with bit-identical inputs in the
+# final workspace), so fits influenced each other and grid scores changed from run to run.  With one stream (or
+# GPU_MAX_HW_QUEUES=1) every result is bit-identical to the fit running alone.  Fits that share a GPU therefore share a stream:
+# host threads still overlap their host work (initialisation, epoch metrics, Python), the GPU runs one kernel sequence.
+_DEVICE_STREAMS = {}
+_DEVICE_STREAMS_LOCK = threading.Lock()
+
+
+def stream_sync(stream):
+    """Wait for what THIS thread has queued on the shared stream so far -- not for the whole device: with several host
+    threads feeding one stream, torch.cuda.synchronize() would also wait for everything the others queue in the meantime."""
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    ev.synchronize()
+
+
+def device_stream(dev):
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    with _DEVICE_STREAMS_LOCK:
+        st = _DEVICE_STREAMS.get(dev.index)
+        if st is None:
+            st = _DEVICE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        return st
+
 
 _RESOLVED = {}
 
@@ -299,7 +327,9 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             raise RuntimeError("slnlp.net: device %r -- the HIP path is the only compute path (no CPU fallback)" % (self.device,))
         kw = self._sub("module")
         kw.setdefault("device", dev)
-        self.module_ = _resolve(self.module)(**kw).to(dev)
+        self._stream = device_stream(dev)
+        with torch.cuda.stream(self._stream):            # the weight draw / upload too: nothing of a fit runs on another queue
+            self.module_ = _resolve(self.module)(**kw).to(dev)
         self.criterion_ = _resolve(self.criterion)(**self._sub("criterion"))
         self._opt_cls = _resolve(self.optimizer)
         ok = self._opt_kwargs = self._sub("optimizer")
@@ -317,8 +347,12 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         self.lr_ = float(self.lr)
         self.history = []
         self.initialized_ = True
-        self._stream = torch.cuda.Stream(device=dev)
         return self
+
+    def _enter_stream(self):
+        """Order the fit's stream behind what this thread queued on the ambient stream so far (the weight draw / upload of
+        ``initialize``, the dataset upload): ``self._stream`` is a non-blocking stream, nothing else makes it wait."""
+        self._stream.wait_stream(torch.cuda.current_stream(self._stream.device))
 
     # ------------------------------------------------------------------ data
     @staticmethod
@@ -343,8 +377,9 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
     def partial_fit(self, X, y=None, **fit_params):
         if not self.initialized_:
             self.initialize()
-        run = _FitRun(self, self._as_dataset(X, y))
+        self._enter_stream()
         with torch.cuda.stream(self._stream):
+            run = _FitRun(self, self._as_dataset(X, y))
             for _ in range(int(self.max_epochs)):
                 run.begin_epoch()
                 self.module_.train()
@@ -355,7 +390,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                     va = self._run_epoch(run.Xva, run.Lva, run.yva, run.bs, False, run.momentum, run.max_norm)
                 if run.end_epoch(tr, va):
                     break
-        torch.cuda.synchronize()
+        stream_sync(self._stream)
         return self
 
     def _train_split(self, ds):
@@ -423,15 +458,17 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         if not self.initialized_:
             raise RuntimeError("This NeuralNetClassifier instance is not initialized yet.")
         ds = self._as_dataset(X)
-        Xd, Ld, yd = self._device_data(ds)
         self.module_.eval()
         outs = []
+        self._enter_stream()
         with torch.cuda.stream(self._stream), torch.no_grad():
+            Xd, Ld, yd = self._device_data(ds)
             for i in range(0, len(ds), int(self.batch_size)):
                 lp = self.module_(X=Xd[i:i + self.batch_size], y=yd[i:i + self.batch_size], lengths=Ld[i:i + self.batch_size])
                 outs.append(torch.softmax(lp, dim=-1) if self.predict_nonlinearity == "auto" else lp)
-        torch.cuda.synchronize()
-        return torch.cat(outs).cpu().numpy()
+            out = torch.cat(outs)
+        stream_sync(self._stream)
+        return out.cpu().numpy()
 
     def predict(self, X):
         return self.classes_[self.predict_proba(X).argmax(-1)]

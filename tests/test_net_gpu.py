@@ -379,3 +379,29 @@ def test_recipe_init_on_the_device_trains_and_is_reproducible():
     assert h[-1]["train_loss"] < h[0]["train_loss"]
     gs = ShardedGridSearchCV(lambda: make_net(ds, max_epochs=1, dropout=0.1), {"lr": [0.1, 0.01]}, cv=2, refit=True, device="cuda").fit(ds)
     assert gs.recipe_init and gs.best_estimator_.module_.init == "reference" and np.isfinite(gs.best_score_)
+
+
+def test_concurrent_fits_at_working_sizes_do_not_influence_each_other():
+    """fits_per_gpu=3 at E 512 / batch 50 / len 48 -- sizes at which kernels of three fits on three hardware queues used to
+    read their own producer kernels' output stale (tools/probe_concurrent3.py: backward results changed from
+    run to run; the tiny shapes of test_sharded_grid_concurrent_fits_equal_sequential never showed it).  All estimators of a
+    device now share one stream (slnlp.net.device_stream): three host threads, one kernel sequence, scores identical to one
+    thread and from run to run."""
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV
+    from slnlp.net import NeuralNetClassifier, device_stream
+    ds = synthetic_dataset(300, seq_len=48, src_vocab=3000, n_labels=50, seed=2, min_len=8)
+    factory = lambda: NeuralNetClassifier(
+        module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
+        module__embedding_size=512, module__num_heads=8, module__num_layers=2, module__hidden_size=512, module__dropout=0.1,
+        criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.1, max_epochs=2, batch_size=50,
+        device="cuda", gradient_clipping={"gradient_clip_value": 0.5}, scoring=["neg_log_loss"])
+    grid = {"lr": [0.1, 0.03, 0.01]}
+    runs = []
+    for k, ls in ((1, 1), (3, 1), (3, 1), (3, 3)):
+        gs = ShardedGridSearchCV(factory, grid, cv=3, refit=False, device="cuda", fits_per_gpu=k, lockstep=ls).fit(ds)
+        runs.append(np.stack([gs.cv_results_[f"split{i}_test_score"] for i in range(3)]))
+    for r in runs[1:]:
+        assert np.array_equal(runs[0], r), (runs[0], r)
+    a, b = factory().initialize(), factory().initialize()
+    assert a._stream is b._stream is device_stream("cuda")
