@@ -389,6 +389,12 @@ int slnlp_tf_params_changed(slnlp_tf_plan* plan);
 /* test / debug helper: "name byte_offset" lines of the workspace's activation and gradient buffers, in layout order */
 int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_bytes);
 
+/* slnlp_*_destroy wait for the device (hipDeviceSynchronize) before they return: the plan's buffers are the caller's and
+ * may be freed next.  on = 0 drops that wait, process-wide -- only for callers whose buffers come from a stream-ordered
+ * allocator on the stream the plans ran on (torch's caching allocator), where the device-wide wait stalls every other host
+ * thread's queued work each time a fit ends. */
+int slnlp_set_destroy_sync(int on);
+
 /* ---------------------------------------------------------------- lockstep --
  * K Transformer fits of ONE shape (own weights, lr, dropout rate, seed and data) advancing through one launch
  * sequence: every call site of the step is launched once for all K fits, so a 50-row decoder stage becomes a

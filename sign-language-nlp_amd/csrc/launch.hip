@@ -1,4 +1,5 @@
 // launch.hip -- the thread-local launch recorder behind zlaunch() and a recordable zero-fill (see launch.hpp).
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -17,6 +18,11 @@ unsigned long long params_generation(const float* params) {
 unsigned long long bump_params_generation(const float* params) {
     std::lock_guard<std::mutex> lk(gen_mutex);
     return ++gen_table[params];
+}
+
+static std::atomic<int> g_destroy_sync{1};
+void destroy_sync() {
+    if (g_destroy_sync.load(std::memory_order_relaxed)) (void)hipDeviceSynchronize();
 }
 
 static thread_local Recorder* tl_recorder = nullptr;
@@ -54,3 +60,8 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
 }
 
 }  // namespace slnlp
+
+extern "C" int slnlp_set_destroy_sync(int on) {
+    slnlp::g_destroy_sync.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}

@@ -148,6 +148,12 @@ int zlaunch(void (*kern)(P, const P*), dim3 grid, int threads, size_t lds, hipSt
     return 0;
 }
 
+// What a destroy call does about work still in flight.  Default: hipDeviceSynchronize() -- the plan's buffers belong to the
+// caller, who may free them next.  slnlp_set_destroy_sync(0): nothing -- for callers whose buffers come from a STREAM-ORDERED
+// allocator on the stream the plan ran on (torch's caching allocator: a freed block is only handed to later work of that
+// stream), where the device-wide wait would stall every other host thread's queued work behind each plan that goes away.
+void destroy_sync();
+
 // zero `bytes` (a multiple of 16, 16-B aligned) with a kernel of ours: recordable, unlike hipMemsetAsync
 int fill_zero(void* p, size_t bytes, hipStream_t st);
 

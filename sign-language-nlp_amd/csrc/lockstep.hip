@@ -261,7 +261,7 @@ static int ls_init(LockstepGroup* ls, int B, int S, void* workspace, int64_t wor
 }
 
 static void ls_destroy(LockstepGroup* ls) {
-    (void)hipDeviceSynchronize();      // tables live in caller memory that may be freed next
+    destroy_sync();                    // tables live in caller memory that may be freed next
     for (LsFit& f : ls->fits) f.outputs(f.plan, nullptr, nullptr, nullptr);
 }
 

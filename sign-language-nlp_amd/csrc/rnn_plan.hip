@@ -381,7 +381,7 @@ int64_t slnlp_rnn_workspace_bytes(const slnlp_rnn_config* cfg) {
 
 void slnlp_rnn_destroy(slnlp_rnn_plan* plan) {
     if (!plan) return;
-    (void)hipDeviceSynchronize();
+    destroy_sync();
     for (auto& kv : plan->graphs) (void)hipGraphExecDestroy(kv.second);
     delete plan;
 }

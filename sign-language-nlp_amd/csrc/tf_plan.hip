@@ -57,7 +57,8 @@ int64_t slnlp_tf_workspace_bytes(const slnlp_tf_config* cfg) {
 
 void slnlp_tf_destroy(slnlp_tf_plan* plan) {
     if (!plan) return;
-    (void)hipDeviceSynchronize();             // nothing of this plan may still be in flight
+    if (!plan->graphs.empty() || plan->side_mode > 0) (void)hipDeviceSynchronize();   // graph execs / side streams are torn down below
+    else destroy_sync();                      // nothing of this plan may still be in flight when its buffers go
     for (auto& kv : plan->graphs) (void)hipGraphExecDestroy(kv.second);
     for (int k = 0; k < NSIDE; ++k) {
         if (plan->side[k]) (void)hipStreamDestroy(plan->side[k]);

@@ -39,19 +39,27 @@ class LockstepGroup:
         nbytes = int(self._fn("workspace_bytes")(C.byref(cfg), self.K))
         if nbytes < 0:
             raise RuntimeError("lockstep: bad configuration")
+        self._alloc_stream = self._last_stream = torch.cuda.current_stream(self.device)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         handles = (C.c_void_p * self.K)(*[e.handle for e in self.engines])
         out = C.c_void_p()
-        check(self._fn("create")(handles, self.K, ptr(self.workspace), nbytes, stream_ptr(), C.byref(out)), f"{self.kind}_lockstep_create")
+        check(self._fn("create")(handles, self.K, ptr(self.workspace), nbytes, self._sp(), C.byref(out)), f"{self.kind}_lockstep_create")
         self.handle = out
         self.data, self.logp, self.loss, self.rows = {}, {}, {}, {}
 
     def _fn(self, name):                                 # a method, not a closure over self: no reference cycle
         return getattr(load(), f"slnlp_{self.kind}_lockstep_{name}")
 
+    def _sp(self):
+        st = self._last_stream = torch.cuda.current_stream(self.device)
+        return st.cuda_stream
+
     def close(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:
+            ls, al = getattr(self, "_last_stream", None), getattr(self, "_alloc_stream", None)
+            if ls is not None and al is not None and ls != al:
+                ls.synchronize()                         # the tables go back to another stream's pool (tf_engine.__del__)
             self._fn("destroy")(h)
 
     __del__ = close
@@ -72,11 +80,11 @@ class LockstepGroup:
             lengths = [l.contiguous() for l in lengths]
             self.data[slot] = (list(Xs), list(ys), lengths)   # keep the tensors alive: the C side holds raw pointers
             check(self._fn("set_data")(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), _ptr_array(lengths), rows,
-                                       _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), stream_ptr()), "rnn_lockstep_set_data")
+                                       _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), self._sp()), "rnn_lockstep_set_data")
         else:
             self.data[slot] = (list(Xs), list(ys))
             check(self._fn("set_data")(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), rows,
-                                       _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), stream_ptr()), "tf_lockstep_set_data")
+                                       _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), self._sp()), "tf_lockstep_set_data")
 
     def _sync_versions(self):
         for e in self.engines:                           # Transformer: weight planes follow outside writes to the fp32 arena
@@ -85,13 +93,13 @@ class LockstepGroup:
 
     def step(self, slot, row0, B, step_index, train, momentum=0.9, max_norm=0.5):
         self._sync_versions()
-        check(self._fn("step")(self.handle, slot, row0, B, step_index, int(train), momentum, max_norm, stream_ptr()),
+        check(self._fn("step")(self.handle, slot, row0, B, step_index, int(train), momentum, max_norm, self._sp()),
               f"{self.kind}_lockstep_step")
 
     def epoch(self, slot, batch, train, momentum=0.9, max_norm=0.5):
         """One pass over the slot in dataset order; no host synchronisation.  Results: ``logp[slot]``, ``loss[slot]``."""
         self._sync_versions()
-        check(self._fn("epoch")(self.handle, slot, batch, int(train), momentum, max_norm, stream_ptr()), f"{self.kind}_lockstep_epoch")
+        check(self._fn("epoch")(self.handle, slot, batch, int(train), momentum, max_norm, self._sp()), f"{self.kind}_lockstep_epoch")
 
     def num_launches(self, slot, B, train):
         return int(self._fn("num_launches")(self.handle, slot, B, int(train)))

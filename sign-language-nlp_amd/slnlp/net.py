@@ -61,6 +61,10 @@ def device_stream(dev):
         st = _DEVICE_STREAMS.get(dev.index)
         if st is None:
             st = _DEVICE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+            # every buffer of an estimator's plans is a torch tensor allocated and used on this stream, so a plan that goes away
+            # needs no device-wide wait (which would stall the other host threads' queued work each time a fit ends)
+            from ._lib import load
+            load().slnlp_set_destroy_sync(0)
         return st
 
 

@@ -34,6 +34,7 @@ def layout(cfg):
 class RnnEngine:
     def __init__(self, cfg, device="cuda", seed=0, params=None, grads=None, momentum=None, rng=None, lr=None, scalars=None):
         _lib.require_gpu()
+        self._alloc_stream = self._last_stream = torch.cuda.current_stream(torch.device(device))   # whose pool the buffers come from
         self.cfg, self.device = cfg, torch.device(device)
         self.entries, self.arena_floats = layout(cfg)
         dev = self.device
@@ -57,10 +58,20 @@ class RnnEngine:
         self._launch = LaunchPolicy()
         self._xbuf = self._ybuf = self._lbuf = None
 
+    def _sp(self):
+        """Pointer of the stream this call runs on; remembered for the destructor."""
+        st = self._last_stream = torch.cuda.current_stream(self.device)
+        return st.cuda_stream
+
     def __del__(self):
         h = getattr(self, "handle", None)
         if h:
             try:
+                # the buffers return to the pool of the stream they were allocated on: if the plan last ran on another
+                # stream, that work must be over first (same stream: the allocator's stream order covers it)
+                ls, al = getattr(self, "_last_stream", None), getattr(self, "_alloc_stream", None)
+                if ls is not None and al is not None and ls != al:
+                    ls.synchronize()
                 load().slnlp_rnn_destroy(h)
             except Exception:
                 pass
@@ -87,25 +98,25 @@ class RnnEngine:
         B = X.shape[0]
         self._keep = (X.contiguous(), y.contiguous(), lengths.contiguous())
         X, y, L = self._keep
-        check(load().slnlp_rnn_forward(self.handle, ptr(X), ptr(y), ptr(L), B, int(train), ptr(self.logp), stream_ptr()),
+        check(load().slnlp_rnn_forward(self.handle, ptr(X), ptr(y), ptr(L), B, int(train), ptr(self.logp), self._sp()),
               "rnn_forward")
         return self.logp[:B]
 
     def seed_dlogp(self, dlogp):
-        check(load().slnlp_rnn_seed_dlogp(self.handle, ptr(dlogp.contiguous()), stream_ptr()), "rnn_seed_dlogp")
+        check(load().slnlp_rnn_seed_dlogp(self.handle, ptr(dlogp.contiguous()), self._sp()), "rnn_seed_dlogp")
 
     def backward(self):
-        check(load().slnlp_rnn_backward(self.handle, stream_ptr()), "rnn_backward")
+        check(load().slnlp_rnn_backward(self.handle, self._sp()), "rnn_backward")
 
     def optim(self, momentum=0.9, max_norm=0.5):
-        check(load().slnlp_rnn_optim(self.handle, momentum, max_norm, stream_ptr()), "rnn_optim")
+        check(load().slnlp_rnn_optim(self.handle, momentum, max_norm, self._sp()), "rnn_optim")
 
     def train_step(self, X, y, lengths, momentum=0.9, max_norm=0.5):
         B = X.shape[0]
         self._keep = (X.contiguous(), y.contiguous(), lengths.contiguous())
         X, y, L = self._keep
         check(load().slnlp_rnn_train_step(self.handle, ptr(X), ptr(y), ptr(L), B, momentum, max_norm, ptr(self.logp),
-                                          stream_ptr()), "rnn_train_step")
+                                          self._sp()), "rnn_train_step")
         return self.logp[:B]
 
     def train_step_graph(self, X, y, lengths, momentum=0.9, max_norm=0.5):
@@ -118,7 +129,7 @@ class RnnEngine:
             self._lbuf = torch.empty(self.cfg.B, dtype=torch.int64, device=dev)
         xb, yb, lb = self._xbuf[:B], self._ybuf[:B], self._lbuf[:B]
         xb.copy_(X); yb.copy_(y); lb.copy_(lengths)
-        st = stream_ptr()
+        st = self._sp()
         if st == 0:
             raise RuntimeError("train_step_graph needs a non-default stream (use torch.cuda.stream(...))")
         if self._graph_keys.get(B) != key:
@@ -131,7 +142,7 @@ class RnnEngine:
     def tap(self, name, rows, cols):
         out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
         n = C.c_int64(0)
-        check(load().slnlp_rnn_tap(self.handle, name.encode(), ptr(out), out.numel(), C.byref(n), stream_ptr()), "rnn_tap")
+        check(load().slnlp_rnn_tap(self.handle, name.encode(), ptr(out), out.numel(), C.byref(n), self._sp()), "rnn_tap")
         assert n.value == rows * cols, (name, n.value, rows, cols)
         return out
 
@@ -155,7 +166,7 @@ class RnnEngine:
 
     def step(self, X, y, lengths, momentum=0.9, max_norm=0.5, graph="auto"):
         """Uniform fused-step entry (estimator).  graph: True / False / "auto" (see launch.py)."""
-        if graph == "auto" and stream_ptr() == 0:
+        if graph == "auto" and self._sp() == 0:
             graph = False                    # graph capture needs a non-default stream
         if graph == "auto":
             return self._launch.run((X.shape[0], float(momentum), float(max_norm)),

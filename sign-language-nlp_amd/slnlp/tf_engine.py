@@ -55,6 +55,7 @@ class TransformerEngine:
         """``params`` / ``grads`` / ``momentum`` / ``pe``: adopt arenas owned by the caller (the
         drop-in ``model.Transformer`` keeps its nn.Parameters as views of ``params``)."""
         _lib.require_gpu()
+        self._alloc_stream = self._last_stream = torch.cuda.current_stream(torch.device(device))   # whose pool the buffers come from
         self.cfg = cfg
         self.device = torch.device(device)
         self.entries, self.arena_floats = layout(cfg)
@@ -91,10 +92,20 @@ class TransformerEngine:
             check(load().slnlp_tf_params_changed(self.handle), "tf_params_changed")
             self._pv = v
 
+    def _sp(self):
+        """Pointer of the stream this call runs on; remembered for the destructor."""
+        st = self._last_stream = torch.cuda.current_stream(self.device)
+        return st.cuda_stream
+
     def __del__(self):
         h = getattr(self, "handle", None)
         if h:
             try:
+                # the buffers return to the pool of the stream they were allocated on: if the plan last ran on another
+                # stream, that work must be over first (same stream: the allocator's stream order covers it)
+                ls, al = getattr(self, "_last_stream", None), getattr(self, "_alloc_stream", None)
+                if ls is not None and al is not None and ls != al:
+                    ls.synchronize()
                 load().slnlp_tf_destroy(h)
             except Exception:
                 pass
@@ -129,23 +140,23 @@ class TransformerEngine:
         X = X.contiguous()
         y = y.contiguous()
         self._keep = (X, y)  # backward reads the ids again
-        check(load().slnlp_tf_forward(self.handle, ptr(X), ptr(y), B, int(train), ptr(self.logp), stream_ptr()),
+        check(load().slnlp_tf_forward(self.handle, ptr(X), ptr(y), B, int(train), ptr(self.logp), self._sp()),
               "tf_forward")
         return self.logp[:B]
 
     def seed_dlogp(self, dlogp):
-        check(load().slnlp_tf_seed_dlogp(self.handle, ptr(dlogp.contiguous()), stream_ptr()), "tf_seed_dlogp")
+        check(load().slnlp_tf_seed_dlogp(self.handle, ptr(dlogp.contiguous()), self._sp()), "tf_seed_dlogp")
 
     def backward(self):
-        check(load().slnlp_tf_backward(self.handle, stream_ptr()), "tf_backward")
+        check(load().slnlp_tf_backward(self.handle, self._sp()), "tf_backward")
 
     def optim(self, momentum=0.9, max_norm=0.5):
-        check(load().slnlp_tf_optim(self.handle, momentum, max_norm, stream_ptr()), "tf_optim")
+        check(load().slnlp_tf_optim(self.handle, momentum, max_norm, self._sp()), "tf_optim")
 
     def optim_adam(self, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
         """clip_grad_norm_ + torch.optim.Adam fused (exp_avg = the momentum arena, exp_avg_sq = ``exp_avg_sq``, step count in
         ``scalars[2]``)."""
-        check(load().slnlp_tf_optim_adam(self.handle, ptr(exp_avg_sq), betas[0], betas[1], eps, weight_decay, max_norm, stream_ptr()),
+        check(load().slnlp_tf_optim_adam(self.handle, ptr(exp_avg_sq), betas[0], betas[1], eps, weight_decay, max_norm, self._sp()),
               "tf_optim_adam")
 
     def train_step_adam(self, X, y, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
@@ -163,7 +174,7 @@ class TransformerEngine:
         y = y.contiguous()
         self._keep = (X, y)
         check(load().slnlp_tf_train_step(self.handle, ptr(X), ptr(y), B, momentum, max_norm, ptr(self.logp),
-                                         stream_ptr()), "tf_train_step")
+                                         self._sp()), "tf_train_step")
         return self.logp[:B]
 
     def train_step_graph(self, X, y, momentum=0.9, max_norm=0.5):
@@ -178,7 +189,7 @@ class TransformerEngine:
         xb, yb = self._xbuf[:B], self._ybuf[:B]
         xb.copy_(X)
         yb.copy_(y)
-        st = stream_ptr()
+        st = self._sp()
         if st == 0:
             raise RuntimeError("train_step_graph needs a non-default stream (use torch.cuda.stream(...))")
         if self._graph_keys.get(B) != key:       # one captured graph per batch size, kept by the plan
@@ -191,7 +202,7 @@ class TransformerEngine:
     def tap(self, name, rows, cols):
         out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
         n = C.c_int64(0)
-        check(load().slnlp_tf_tap(self.handle, name.encode(), ptr(out), out.numel(), C.byref(n), stream_ptr()),
+        check(load().slnlp_tf_tap(self.handle, name.encode(), ptr(out), out.numel(), C.byref(n), self._sp()),
               "tf_tap")
         assert n.value == rows * cols, (name, n.value, rows, cols)
         return out
@@ -207,7 +218,7 @@ class TransformerEngine:
     def step(self, X, y, lengths=None, momentum=0.9, max_norm=0.5, graph="auto"):
         """Uniform fused-step entry (estimator): the Transformer ignores ``lengths`` (transformer.py:60).
         graph: True (hipGraph replay) / False (eager launches) / "auto" (time both, keep the faster; launch.py)."""
-        if graph == "auto" and stream_ptr() == 0:
+        if graph == "auto" and self._sp() == 0:
             graph = False                    # graph capture needs a non-default stream
         if graph == "auto":
             return self._launch.run((X.shape[0], float(momentum), float(max_norm)),
