@@ -196,13 +196,13 @@ def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
 
 
 # 48 of config-transformer.yaml's 324 candidates: every lr and dropout, two embedding sizes, two hidden sizes and both head
-# counts at num_layers 2 -> 8 shapes x 30 (candidate, fold) fits.  With lockstep 5 that is 48 work units: 24 at
-# embedding_size 512 and 24 cheap ones at 128 that fill the gaps of the longest-first schedule, so the strong-scaling leg
-# divides evenly over 1 / 2 / 4 / 8 GPUs (6 units per GPU at N = 8).
+# counts at num_layers 2 -> 8 shapes x 30 (candidate, fold) fits.  With lockstep 15 (the 3 learning rates x 5 folds of a
+# (shape, dropout) pair advance together) that is 16 work units: 8 at embedding_size 512 and 8 cheap ones at 128, so the
+# strong-scaling leg divides evenly over 1 / 2 / 4 / 8 GPUs (one large + one small unit per GPU at N = 8).
 GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__embedding_size": [512, 128],
                "module__hidden_size": [512, 256], "module__num_heads": [8, 4]}
 GRID_FIXED = {"module__num_layers": 2}
-GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 6, 2000
+GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 8, 4000
 
 
 def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
@@ -215,14 +215,15 @@ def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
         scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
 
 
-def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=5):
+def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=15):
     """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
-    on a bounded sample of config-transformer.yaml's grid -- 48 candidates x cv 5 = 240 fits of 6 epochs over 2000
+    on a bounded sample of config-transformer.yaml's grid -- 48 candidates x cv 5 = 240 fits of 8 epochs over 4000
     synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
     ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling).  Work unit =
     `lockstep` shape-compatible fits advancing through one launch sequence; `fits_per_gpu` host threads per rank each run
-    one unit at a time, so one unit's host work (estimator construction, epoch metrics, scoring) hides under another's kernels
-    (measured on the 24-unit predecessor of this sample: 8.5 k folds/hr with 1 thread, 18.1 k with 2, 19.9 k with 3, 20.6 k with 4)."""
+    one unit at a time ON ONE STREAM (slnlp.net.device_stream: kernels of several fits on several hardware queues are not
+    safe on this stack), so one unit's host work (estimator construction, epoch metrics, scoring) hides under another's
+    kernels while the GPU runs a single kernel sequence."""
     import warnings
     from slnlp.data import synthetic_dataset
     from slnlp.grid import ShardedGridSearchCV
@@ -377,7 +378,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true", help="skip the folds/hr leg")
     ap.add_argument("--fits-per-gpu", type=int, default=3, help="host threads per GPU in the grid leg (each runs work units)")
-    ap.add_argument("--lockstep", type=int, default=5, help="fits per work unit, advanced through one launch sequence, in the grid leg")
+    ap.add_argument("--lockstep", type=int, default=15, help="fits per work unit, advanced through one launch sequence, in the grid leg")
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")
     ap.add_argument("--eager", action="store_true", help="same as --launch eager")
