@@ -70,10 +70,38 @@ def build_tasks(param_grid, y, cv, seq_len=48, defaults=None):
 SHAPE_KEYS_EXCLUDED = ("lr", "module__dropout")
 
 
-def build_units(cands, folds, tasks, order, lockstep=1):
+def estimate_fit_bytes(params, seq_len, defaults=None):
+    """Device bytes one resident fit of this candidate needs (plan workspace + parameter / gradient / momentum arenas), asked
+    from the library's host-side size queries; None when the module is not one of this package's."""
+    d = dict(defaults or {})
+    d.update(params)
+    try:
+        import ctypes as C
+        from ._lib import load
+        from .net import _resolve
+        name = getattr(_resolve(d.get("module")), "__name__", "")
+        Vs, Vt, B = len(d["module__src_vocab"]), len(d["module__tgt_vocab"]), int(d.get("batch_size", 50))
+        E, F, N = int(d["module__embedding_size"]), int(d["module__hidden_size"]), int(d["module__num_layers"])
+        if name == "Transformer":
+            from . import tf_engine as te
+            cfg = te.make_config(E, int(d["module__num_heads"]), N, F, Vs, Vt, B, int(seq_len), 1, 1, 0.1, 3)
+            ws, arena = int(load().slnlp_tf_workspace_bytes(C.byref(cfg))), te.layout(cfg)[1]
+        elif name.startswith("EncoderDecoder"):
+            from . import rnn_engine as re_
+            cfg = re_.make_config("lstm" if "LSTM" in name else "gru", E, F, N, Vs, Vt, B, int(seq_len), 1, 1, 0, 0.1, 3)
+            ws, arena = int(load().slnlp_rnn_workspace_bytes(C.byref(cfg))), re_.layout(cfg)[1]
+        else:
+            return None
+        return ws + 3 * 4 * int(arena) if ws > 0 else None
+    except Exception:
+        return None
+
+
+def build_units(cands, folds, tasks, order, lockstep=1, cap=None):
     """Pack the cost-ordered task list into work units of up to ``lockstep`` tasks that can advance through one
     launch sequence: same candidate shapes (every parameter except lr / dropout rate) and the same train-fold
-    size (=> the same number and sizes of batches).  ``lockstep <= 1``: one task per unit."""
+    size (=> the same number and sizes of batches).  ``lockstep <= 1``: one task per unit.  ``cap(candidate index)``: an upper
+    bound on the unit size for that candidate (device memory), or None."""
     if lockstep <= 1:
         return [[t] for t in order]
     units, open_units = [], {}
@@ -88,7 +116,8 @@ def build_units(cands, folds, tasks, order, lockstep=1):
             u = open_units[key] = []
             units.append(u)                      # a unit keeps the position of its first (most expensive) task
         u.append(t)
-        if len(u) == lockstep:
+        limit = lockstep if cap is None else max(1, min(lockstep, cap(ci)))
+        if len(u) >= limit:
             del open_units[key]
     return units
 
@@ -210,9 +239,10 @@ def _recipe_init_factory(factory):
 class ShardedGridSearchCV:
     def __init__(self, estimator_factory, param_grid, cv=5, scoring="neg_log_loss", refit=True, fit_and_score=None,
                  device="cpu", verbose=0, fits_per_gpu=1, seed=1, schedule="dynamic", lockstep=1,
-                 fit_and_score_group=None, force_collectives=False, recipe_init=True):
+                 fit_and_score_group=None, force_collectives=False, recipe_init=True, memory_fraction=0.4):
         self.estimator_factory, self.param_grid, self.cv = estimator_factory, param_grid, cv
         self.recipe_init = bool(recipe_init)
+        self.memory_fraction = float(memory_fraction)     # of the device's memory that resident fits may take (unit size cap)
         self._task_factory = _recipe_init_factory(estimator_factory) if recipe_init else estimator_factory
         self.scoring, self.refit, self.verbose, self.device = scoring, refit, verbose, device
         self.fit_and_score = fit_and_score or default_fit_and_score
@@ -236,7 +266,19 @@ class ShardedGridSearchCV:
         group_fn = self.fit_and_score_group
         if self.lockstep > 1 and group_fn is None:
             from .lockstep import fit_and_score_group as group_fn
-        units = build_units(cands, folds, tasks, order, self.lockstep if group_fn else 1)
+        cap = None
+        if group_fn and self.lockstep > 1 and str(self.device).startswith("cuda") and torch.cuda.is_available():
+            # fits_per_gpu units of up to `lockstep` fits are resident at a time: keep them inside a fraction of the device's
+            # memory (E 1024 / 6 layers is 3.7 GB per fit: 45 of them are 166 GB).  Same arithmetic on every rank.
+            budget = self.memory_fraction * torch.cuda.get_device_properties(torch.device(self.device)).total_memory
+            defaults, S, per = self._defaults(), ds.ids.shape[1], {}
+
+            def cap(ci):
+                if ci not in per:
+                    b = estimate_fit_bytes(cands[ci], S, defaults)
+                    per[ci] = self.lockstep if not b else int(budget // (max(1, self.fits_per_gpu) * b))
+                return per[ci]
+        units = build_units(cands, folds, tasks, order, self.lockstep if group_fn else 1, cap)
         call = next(_FIT_CALLS)
         counter = WorkCounter(f"slnlp/grid/{call}/next", static=self.schedule == "static")
         rows = torch.full((len(tasks), 3), float("nan"), dtype=torch.float64)      # score, seconds, error flag

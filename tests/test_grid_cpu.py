@@ -167,6 +167,20 @@ def test_build_units_packs_shape_compatible_tasks():
     assert len(units) < len(tasks) / 2
 
 
+def test_build_units_respects_a_per_candidate_cap():
+    """cap(candidate) bounds a unit's size (device memory): large candidates get narrower units, nothing is lost or repeated."""
+    cands = [{"lr": lr, "module__embedding_size": E} for E in (1024, 128) for lr in (0.1, 0.01, 0.001)]
+    folds = [(np.arange(80), np.arange(20))] * 5
+    tasks = [(ci, fi) for ci in range(len(cands)) for fi in range(5)]
+    order = list(range(len(tasks)))
+    units = grid.build_units(cands, folds, tasks, order, lockstep=15, cap=lambda ci: 4 if cands[ci]["module__embedding_size"] == 1024 else 99)
+    assert sorted(t for u in units for t in u) == order
+    big = [u for u in units if cands[tasks[u[0]][0]]["module__embedding_size"] == 1024]
+    small = [u for u in units if cands[tasks[u[0]][0]]["module__embedding_size"] == 128]
+    assert [len(u) for u in big] == [4, 4, 4, 3] and [len(u) for u in small] == [15]
+    assert all(len({cands[tasks[t][0]]["module__embedding_size"] for t in u}) == 1 for u in units)
+
+
 def test_fits_per_gpu_threads_same_results_and_seed_passed():
     """fits_per_gpu=k: the rank's tasks run k at a time on host threads; scores, ranking and the per-task seeds
     are the same as with k = 1."""
