@@ -156,7 +156,7 @@ def fp8_kernel_roofline(c, dev):
             "note": "e4m3 operand planes (1 B/element) read once + fp32 result; plain fp8 MFMA (bf16 issue rate), priced against the 5 PF dense fp8 peak"}
 
 
-def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
+def concurrent_fits(c, precision, dev, ks=(4, 8, 16), steps=30):
     """Aggregate train seq/s of K independent fits of this workload sharing the GPU by advancing in LOCKSTEP through one
     launch sequence (slnlp/lockstep.py: own weights, lr, seed and data per fit; bit-identical to solo fits) -- how
     ShardedGridSearchCV(lockstep=k) runs a work unit.  A single batch-50 fit leaves most CUs idle in its decoder stages."""
@@ -166,8 +166,11 @@ def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
     rows = steps * B
     out = []
     st = torch.cuda.Stream(device=dev)
+    total = torch.cuda.get_device_properties(dev).total_memory
     for k in ks:
         engs, data = [], []
+        if out and k * per_fit_bytes > 0.35 * total:      # keep the resident fits well inside the device's memory
+            continue
         for i in range(k):
             cfg, sd = build_sd(c, seed=101 + i)
             e = (re_.RnnEngine if "rnn" in c else te.TransformerEngine)(cfg, device=dev, seed=101 + i)
@@ -176,6 +179,7 @@ def concurrent_fits(c, precision, dev, ks=(4, 8), steps=30):
             Xn, Ln, yn = synth.make_batch(rows, S, c["Vs"], c["Vt"], seed=101 + i)
             engs.append(e)
             data.append((torch.from_numpy(Xn).to(dev), torch.from_numpy(yn).to(dev), torch.from_numpy(Ln).to(dev)))
+        per_fit_bytes = engs[0].workspace.numel() + 3 * 4 * engs[0].params.numel()
         with torch.cuda.stream(st):
             grp = LockstepGroup(engs)
             grp.set_data(0, [d[0] for d in data], [d[1] for d in data], B, [d[2] for d in data])

@@ -35,7 +35,7 @@ from .data import TokenDataset
 # module construction consumes torch's global CPU generator (initial weights): concurrent fits take turns
 INIT_LOCK = threading.RLock()
 
-# ONE stream per device for every estimator of the process.  Measured on MI355X / ROCm 7.2 (tools/probe_concurrent*.py): when
+# ONE stream per device for every estimator of the process.  Measured on MI355X / ROCm 7.2 (tools/probes/probe_concurrent*.py): when
 # kernels of this library run on several hardware queues at once -- three fits on three streams -- a consumer kernel can read
 # 64-byte pieces of its producer kernel's output stale (whole LayerNorm-backward rows changed with bit-identical inputs in the
 # final workspace), so fits influenced each other and grid scores changed from run to run.  With one stream (or

@@ -383,7 +383,7 @@ def test_recipe_init_on_the_device_trains_and_is_reproducible():
 
 def test_concurrent_fits_at_working_sizes_do_not_influence_each_other():
     """fits_per_gpu=3 at E 512 / batch 50 / len 48 -- sizes at which kernels of three fits on three hardware queues used to
-    read their own producer kernels' output stale (tools/probe_concurrent3.py: backward results changed from
+    read their own producer kernels' output stale (tools/probes/probe_concurrent3.py: backward results changed from
     run to run; the tiny shapes of test_sharded_grid_concurrent_fits_equal_sequential never showed it).  All estimators of a
     device now share one stream (slnlp.net.device_stream): three host threads, one kernel sequence, scores identical to one
     thread and from run to run."""

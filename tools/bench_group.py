@@ -2,7 +2,8 @@
 import sys, torch
 sys.path.insert(0, "sign-language-nlp_amd")
 from slnlp import ops
-Mtok, Nout, Kin = 2400, int(sys.argv[1]) if len(sys.argv) > 1 else 512, 512
+Mtok, Nout = 2400, int(sys.argv[1]) if len(sys.argv) > 1 else 512
+Kin = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 g = torch.Generator().manual_seed(0)
 dY, X, W = [torch.randn(*s, generator=g) for s in ((Mtok, Nout), (Mtok, Kin), (Nout, Kin))]
 dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
@@ -20,7 +21,9 @@ def timeit(fn, n=200):
     return e0.elapsed_time(e1) / n * 1e3
 print(f"shapes: dY[{Mtok},{Nout}] X[{Mtok},{Kin}] W[{Nout},{Kin}]")
 print(f"dgrad alone            {timeit(lambda: ops.gemm_group([jd], [1], scr)):7.1f} us")
-for n in (1, 2, 3, 4, 6, 8):
+quick = len(sys.argv) > 3
+for n in ((3,) if quick else (1, 2, 3, 4, 6, 8)):
     print(f"wgrad alone split {n}    {timeit(lambda: ops.gemm_group([jw], [n], scr)):7.1f} us")
-for n in (1, 2, 3, 4, 6, 8):
-    print(f"group       split {n}    {timeit(lambda: ops.gemm_group([jw, jd], [n, 1], scr)):7.1f} us")
+for n in ((3,) if quick else (1, 2, 3, 4, 6, 8)):
+    t = timeit(lambda: ops.gemm_group([jw, jd], [n, 1], scr))
+    print(f"group       split {n}    {t:7.1f} us   {2 * 2 * Mtok * Nout * Kin / t / 1e6:7.1f} TFLOP/s")

@@ -1,5 +1,5 @@
 # round-2 profiles: kernel trace of the bench command, HBM traffic PMC passes, SQ counters of the roofline kernel, lockstep trace
-# usage (GPU box): bash tools/gpu_profile_r02.sh      -> summaries under gpurun_out/prof/ (copy the keepers into profiles/)
+# usage (GPU box): bash tools/gpu/profile_r02.sh      -> summaries under gpurun_out/prof/ (copy the keepers into profiles/)
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

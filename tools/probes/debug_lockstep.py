@@ -1,6 +1,6 @@
 """Determinism probe: the same first train step from identical fresh engines, solo (multi-stream plan) and lockstep."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

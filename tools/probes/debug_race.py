@@ -1,6 +1,6 @@
 """Locate the first differing workspace buffer between identical solo train steps (multi-stream plan)."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

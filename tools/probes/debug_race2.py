@@ -1,6 +1,6 @@
 """How often does a solo (multi-stream) train step differ from the deterministic single-stream (lockstep K=1) result?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

@@ -1,6 +1,6 @@
 """Does a fit's result depend on OTHER fits running concurrently on other streams / host threads?  Engine level."""
 import os, sys, threading, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 warnings.filterwarnings("ignore")

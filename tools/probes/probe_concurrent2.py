@@ -1,7 +1,7 @@
 """Which part of ONE train step changes when another stream keeps the GPU busy?  Same engine, same batch, same weights:
 step once alone, reset, step once next to a load generator; compare log-probs and every gradient tensor bit for bit."""
 import os, sys, threading, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 warnings.filterwarnings("ignore")

@@ -1,6 +1,6 @@
 """Narrow down: 3 engines of this library in 3 threads -- what is the smallest piece whose result depends on the others?"""
 import os, sys, threading, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 warnings.filterwarnings("ignore")

@@ -1,6 +1,6 @@
 """3 engines concurrently, ONE forward + backward each: which named workspace buffers differ from the solo run?"""
 import bisect, ctypes as C, os, sys, threading, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 warnings.filterwarnings("ignore")

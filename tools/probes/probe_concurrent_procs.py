@@ -1,7 +1,7 @@
 """Same question as probe_concurrent3.py, but the three fits live in three PROCESSES (one stream each): does a fit's backward
 still depend on the others?  Separates 'several hardware queues at once' from 'several streams inside one HIP process'."""
 import hashlib, os, subprocess, sys, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
         sys.path.insert(0, p)

@@ -1,11 +1,10 @@
 """Are grid results reproducible run to run (same process, fresh estimators), with 1 and 3 host threads?"""
 import os, sys, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 warnings.filterwarnings("ignore")
 import numpy as np, torch
-import tools.full_grid as fg  # noqa
 from slnlp.data import synthetic_dataset
 from slnlp.grid import ShardedGridSearchCV
 from slnlp.net import NeuralNetClassifier

@@ -1,7 +1,7 @@
 """How much of the grid leg's wall time is the serialized reference-style weight init?  Runs bench.grid_folds_per_hour twice:
 as is, and with model.transformer._reference_init memoised per shape (NOT a valid mode -- an upper bound for a faster init)."""
 import functools, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 import torch

@@ -1,6 +1,6 @@
 """Does an estimator's GPU memory come back by reference counting alone (no gc.collect) after a lockstep unit?"""
 import gc, os, sys, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
     sys.path.insert(0, p)
 warnings.filterwarnings("ignore")
