@@ -5,11 +5,13 @@ The reference (/root/reference/helper.py:355-388) chains imblearn's ``RandomUnde
 
     under:  n_c -> min(n_c, round(u + ln n_c))          over (on the result):  n_c -> max(n_c, round(u + ln n_c))
 
-This module computes the same targets and draws the samples the way imbalanced-learn 0.8 does (one
-``numpy.random.RandomState(seed)`` per sampler; classes visited in sorted order; under-sampling draws without
-replacement inside each class and keeps class blocks in sorted-class order; over-sampling appends, per class, draws
-with replacement after all original rows).  imbalanced-learn is not installed in the build image, so the sample-level
-agreement is by construction from its published algorithm, not pinned by a test against it.
+This module computes the same targets and draws the samples the way imbalanced-learn 0.8 does with DICT sampling
+strategies (which is what the reference passes: every class is a key): one ``numpy.random.RandomState(seed)`` per sampler;
+classes visited in sorted order; the under-sampler calls ``choice(range(n_c), size=target_c, replace=False)`` for EVERY
+class -- also one that keeps all its rows, whose rows come back permuted -- and concatenates the class blocks in sorted-class
+order; the over-sampler appends, per class, ``choice(rows of c, size=needed_c, replace=True)`` (the same stream as
+``randint(0, n_c, needed_c)``) after all rows of the under-sampled set.  imbalanced-learn is not installed in the build
+image: tests/test_pipeline_cpu.py pins the order with indices worked out from that published algorithm by hand.
 """
 import collections
 import math
@@ -35,8 +37,7 @@ def balance_indices(y, seed):
     keep = []
     for c in np.unique(y):
         members = np.flatnonzero(y == c)
-        pick = rs.choice(range(len(members)), size=under[c], replace=False) if under[c] < len(members) else slice(None)
-        keep.append(members[pick])
+        keep.append(members[rs.choice(range(len(members)), size=under[c], replace=False)])   # every class is in the dict
     idx = np.concatenate(keep)
     y_u = y[idx]
     rs = np.random.RandomState(seed)                       # RandomOverSampler(random_state=seed)

@@ -77,6 +77,23 @@ def test_balancing_targets_and_determinism():
     assert len(set(idx[y[idx] == 0].tolist())) == over[0]                                  # under-sampling draws without replacement
 
 
+def test_balancing_sample_order_is_imbalanced_learns():
+    """The row order of the balanced set, pinned with indices worked out BY HAND from imbalanced-learn 0.8's published
+    algorithm for dict sampling strategies (RandomUnderSampler: RandomState(seed).choice(range(n_c), target_c, replace=False) for
+    every class in sorted order, blocks concatenated; RandomOverSampler: a fresh RandomState(seed), per sorted class
+    choice(rows of c, needed_c, replace=True) appended) -- not with slnlp.balance itself.  y: classes of 12 / 2 / 5 / 1 / 8 rows,
+    mean 5.6 -> under-sampling targets 8 / 2 / 5 / 1 / 8, over-sampling targets 8 / 6 / 7 / 6 / 8 (helper.py:355-377)."""
+    y = np.array([0] * 12 + [1] * 2 + [2] * 5 + [3] + [4] * 8)
+    want = [7, 10, 2, 5, 0, 1, 11, 8,          # class 0: 8 of its 12 rows, drawn without replacement
+            13, 12,                            # class 1 keeps both rows -- permuted, as choice(range(2), 2, replace=False) returns them
+            15, 18, 16, 17, 14, 19,            # class 2 (5 rows, permuted), class 3 (1 row)
+            21, 25, 22, 26, 23, 27, 24, 20,    # class 4 (8 rows, permuted)
+            12, 13, 12, 13,                    # over-sampling: class 1 needs 4 more
+            17, 17,                            # class 2 needs 2
+            19, 19, 19, 19, 19]                # class 3 needs 5
+    assert balance.balance_indices(y, 7).tolist() == want
+
+
 def test_config_merge_grid_names_and_workdir(tmp_path):
     cfg_file = tmp_path / "c.yaml"
     cfg_file.write_text("seed: 1\nworkdir: '%s/{model}/run'\nmodel: model.Transformer\nlr:\nmodel_args:\n  embedding_size:\n"
