@@ -221,7 +221,8 @@ def fit_and_score_group(estimator_factory, params_list, trains, tests, scoring="
     if not all(lockstep_supported(n) for n in nets) or len({type(n.module_) for n in nets}) != 1 or \
             len({len(t) for t in trains}) != 1 or len({len(t) for t in tests}) != 1:
         del nets
-        return [default_fit_and_score(estimator_factory, p, tr, te, scoring, seed=s)
+        # concurrent=True: no hipGraph capture -- other host threads may be launching on the device's shared stream
+        return [default_fit_and_score(estimator_factory, p, tr, te, scoring, seed=s, concurrent=True)
                 for p, tr, te, s in zip(params_list, trains, tests, seeds)]
     fit_lockstep(nets, trains)
     probas = predict_proba_lockstep(nets, tests)
