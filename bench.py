@@ -401,6 +401,7 @@ def main():
     ndev = torch.cuda.device_count()
     shared = world > ndev                      # rehearsal on a box with fewer GPUs than ranks: ranks share GPUs, gloo barrier
     dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)           # before the process group: RCCL binds its communicator to the current device
     backend = None
     if world > 1:
         import datetime
@@ -411,7 +412,6 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(hours=2))
         backend = dist.get_backend()
-    torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
     from slnlp import synth, tf_engine as te
