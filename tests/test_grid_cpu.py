@@ -203,3 +203,16 @@ def test_fits_per_gpu_threads_same_results_and_seed_passed():
         assert len(seen) == (1 if k == 1 else min(k, gs.n_tasks_)) or k > 1
         res.append((gs.cv_results_["mean_test_score"].tolist(), gs.best_index_))
     assert res[0] == res[1]
+
+
+def test_estimate_fit_bytes_asks_the_library_and_orders_candidates():
+    """The device-memory estimate behind the lockstep unit cap: host-side size queries of the library (no GPU), larger for larger
+    models, None for a module that is not one of this package's."""
+    from slnlp.data import synthetic_dataset
+    ds = synthetic_dataset(20, seq_len=48, src_vocab=300, n_labels=20, seed=1, min_len=8)
+    base = dict(module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, batch_size=50, module__num_heads=4)
+    size = lambda E, F, N, **kw: grid.estimate_fit_bytes(dict(module__embedding_size=E, module__hidden_size=F, module__num_layers=N), 48, dict(base, **kw))
+    small, mid, big = size(128, 128, 2), size(512, 512, 2), size(1024, 512, 6)
+    assert 0 < small < mid < big and big > 2 * 2**30
+    assert size(512, 512, 4, module="model.EncoderDecoderLSTMAttn") > 0
+    assert size(128, 128, 2, module="torch.nn.Linear") is None
