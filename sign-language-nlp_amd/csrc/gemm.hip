@@ -185,9 +185,15 @@ constexpr int tile_lds_elems() {
 }
 
 // One workgroup's tile: block (bid_x, bid_y) of a (grid_x, grid_y) grid over C.
-template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC>
+// KS = 2: the workgroup has two groups of 256 threads; group g runs the K loop over its own half of the K tiles with its own
+// stage images (all loads of both halves are in flight together, the dependent chain of K steps is half as long), group 1 hands
+// its accumulators over through LDS and group 0 adds them and runs the epilogue.  For launches that cannot fill the chip anyway
+// (the decoder's 50-row GEMMs: 32 ... 96 workgroups of 8 K tiles, whose duration IS the K chain).
+template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bid_y, int grid_x, int grid_y,
-                                          unsigned short* __restrict__ smem) {
+                                          unsigned short* __restrict__ smem_base) {
+    const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
+    unsigned short* __restrict__ smem = smem_base + grp * tile_lds_elems<NSPLIT, AK, BK, BNT>();
     using TA = TileIO<AK, BM>;
     using TB = TileIO<BK, BNT>;
     constexpr int NP = (NSPLIT == 3) ? 2 : 1;
@@ -198,7 +204,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     float (*rsum)[BM] = reinterpret_cast<float (*)[BM]>(smem + NP * (TA::PLANE + TB::PLANE));
 
     const slnlp_gemm_args& g = p.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     // BNT=64: waves 2x2, each 32x32.  BNT=32: waves 2x2, each 32x16.  BNT=16: waves 4x1, each 16x16.
     const int wm0 = (BNT == 16) ? wave * 16 : (wave >> 1) * 32;
     const int wn0 = (BNT == 64) ? (wave & 1) * 32 : (BNT == 32) ? (wave & 1) * 16 : 0;
@@ -226,13 +232,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     float rowsum = 0.f;
 
     const int ktiles = (K + BKT - 1) / BKT;
+    // this group's K tiles [k0, k1); both groups make `trips` K steps (the barriers are the workgroup's), group 1 idles in its
+    // last one when the number of tiles is odd
+    const int trips = KS == 2 ? (ktiles + 1) / 2 : ktiles;
+    const int k0 = grp * trips, k1 = (KS == 2 && grp == 0) ? trips : ktiles;
     float4 ra0[TA::NV], ra1[TA::NV], rb0[TB::NV], rb1[TB::NV];
-    TA::template fetch<VEC>(g.A, g.lda, bm0, M, 0, K, tid, ra0);
-    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, 0, K, tid, rb0);
+    TA::template fetch<VEC>(g.A, g.lda, bm0, M, k0 * BKT, K, tid, ra0);
+    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, k0 * BKT, K, tid, rb0);
     // prefetches are UNCONDITIONAL (past-the-end tiles read a clamped, valid address and are never
     // stashed): a guard would add a join point and make hipcc fall back to conservative vmcnt counts.
-    TA::template fetch<VEC>(g.A, g.lda, bm0, M, BKT, K, tid, ra1);
-    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, BKT, K, tid, rb1);
+    TA::template fetch<VEC>(g.A, g.lda, bm0, M, (k0 + 1) * BKT, K, tid, ra1);
+    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (k0 + 1) * BKT, K, tid, rb1);
 
     auto consume = [&]() {
 #pragma unroll
@@ -271,22 +281,27 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     // two K-steps per trip so the prefetch registers keep compile-time names
     auto mainloop = [&](auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        for (int kt = 0; kt < ktiles; kt += 2) {
+        for (int it = 0; it < trips; it += 2) {
+            const int kt = k0 + it;
             lds_barrier();
-            TA::template stash<NSPLIT, EDGE>(As, tid, ra0, bm0, M, kt * BKT, K);
-            TB::template stash<NSPLIT, EDGE>(Bs, tid, rb0, bn0, N, kt * BKT, K);
+            if (KS == 1 || kt < k1) {
+                TA::template stash<NSPLIT, EDGE>(As, tid, ra0, bm0, M, kt * BKT, K);
+                TB::template stash<NSPLIT, EDGE>(Bs, tid, rb0, bn0, N, kt * BKT, K);
+            }
             lds_barrier();
             TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 2) * BKT, K, tid, ra0);
             TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 2) * BKT, K, tid, rb0);
-            consume();
-            if (kt + 1 >= ktiles) break;
+            if (KS == 1 || kt < k1) consume();
+            if (it + 1 >= trips) break;
             lds_barrier();
-            TA::template stash<NSPLIT, EDGE>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
-            TB::template stash<NSPLIT, EDGE>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
+            if (KS == 1 || kt + 1 < k1) {
+                TA::template stash<NSPLIT, EDGE>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
+                TB::template stash<NSPLIT, EDGE>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
+            }
             lds_barrier();
             TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 3) * BKT, K, tid, ra1);
             TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 3) * BKT, K, tid, rb1);
-            consume();
+            if (KS == 1 || kt + 1 < k1) consume();
         }
     };
     // interior tile (block-uniform): no bounds masks in the conversion
@@ -295,7 +310,34 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     if (do_rowsum) {
         rsum[tid >> 6][tid & 63] = rowsum;
         __syncthreads();
-        if (tid < 64 && bm0 + tid < M) g.rowsum_a[bm0 + tid] = rsum[0][tid] + rsum[1][tid] + rsum[2][tid] + rsum[3][tid];
+        if (KS == 2) {
+            float (*rs1)[BM] = reinterpret_cast<float (*)[BM]>(smem_base + tile_lds_elems<NSPLIT, AK, BK, BNT>() + NP * (TA::PLANE + TB::PLANE));
+            float (*rs0)[BM] = reinterpret_cast<float (*)[BM]>(smem_base + NP * (TA::PLANE + TB::PLANE));
+            if (grp == 0 && tid < 64 && bm0 + tid < M)
+                g.rowsum_a[bm0 + tid] = ((rs0[0][tid] + rs0[1][tid]) + (rs0[2][tid] + rs0[3][tid])) + ((rs1[0][tid] + rs1[1][tid]) + (rs1[2][tid] + rs1[3][tid]));
+        } else if (tid < 64 && bm0 + tid < M) {
+            g.rowsum_a[bm0 + tid] = rsum[0][tid] + rsum[1][tid] + rsum[2][tid] + rsum[3][tid];
+        }
+    }
+    if (KS == 2) {   // group 1's half of the K sum -> LDS -> group 0 (its stage images are free now)
+        float* red = reinterpret_cast<float*>(smem_base + tile_lds_elems<NSPLIT, AK, BK, BNT>());
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((i * NT + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * NT + j) * 4 + r) * 256 + tid];
     }
 
     // ---- epilogue: +bias -> relu -> gate -> dropout -> +resid
@@ -335,19 +377,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
         }
 }
 
-template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned short smem[tile_lds_elems<NSPLIT, AK, BK, BNT>()];
-    gemm_tile<NSPLIT, AK, BK, BNT, VEC>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void gemm_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, AK, BK, BNT>()];
+    gemm_tile<NSPLIT, AK, BK, BNT, VEC, KS>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
 }
 
 // Several independent fp32-operand GEMMs in ONE launch (e.g. the data- and weight-gradient of one dY in the
 // decoder, whose B-row GEMMs are pure launch latency): workgroups [block_begin, block_begin + gx*gy) run job j.
 // `tab` != nullptr: a merged (lockstep) launch -- the jobs of K fits in a device-resident table, blockmap[block] = job
-template <int NSPLIT>
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupParams P, const GemmJob* __restrict__ tab,
-                                                         const int* __restrict__ blockmap) {
-    __shared__ __attribute__((aligned(16))) unsigned short smem[tile_lds_elems<NSPLIT, false, false, 64>()];   // the largest variant
+template <int NSPLIT, int KS>
+__global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupParams P, const GemmJob* __restrict__ tab,
+                                                              const int* __restrict__ blockmap) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, false, false, 64>()];   // the largest variant
     GemmParams p;
     int variant, gx, gy, lid;
     if (tab) {
@@ -370,13 +412,22 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupParams P
     }
     const int bx = lid % gx, by = lid / gx;
     switch (variant) {
-        case 0: gemm_tile<NSPLIT, true, true, 64, true>(p, bx, by, gx, gy, smem); break;
-        case 1: gemm_tile<NSPLIT, true, true, 16, true>(p, bx, by, gx, gy, smem); break;
-        case 2: gemm_tile<NSPLIT, true, false, 64, true>(p, bx, by, gx, gy, smem); break;
-        case 3: gemm_tile<NSPLIT, true, false, 16, true>(p, bx, by, gx, gy, smem); break;
-        case 4: gemm_tile<NSPLIT, false, false, 64, true>(p, bx, by, gx, gy, smem); break;
-        default: gemm_tile<NSPLIT, false, false, 16, true>(p, bx, by, gx, gy, smem); break;
+        case 0: gemm_tile<NSPLIT, true, true, 64, true, KS>(p, bx, by, gx, gy, smem); break;
+        case 1: gemm_tile<NSPLIT, true, true, 16, true, KS>(p, bx, by, gx, gy, smem); break;
+        case 2: gemm_tile<NSPLIT, true, false, 64, true, KS>(p, bx, by, gx, gy, smem); break;
+        case 3: gemm_tile<NSPLIT, true, false, 16, true, KS>(p, bx, by, gx, gy, smem); break;
+        case 4: gemm_tile<NSPLIT, false, false, 64, true, KS>(p, bx, by, gx, gy, smem); break;
+        default: gemm_tile<NSPLIT, false, false, 16, true, KS>(p, bx, by, gx, gy, smem); break;
     }
+}
+
+// KS = 2 (two K halves per workgroup) for launches that cannot fill the chip and whose duration is the chain of K steps;
+// one rule for single launches, grouped launches and recorded (lockstep) ones, so a fit computes the same bits everywhere
+static int pick_ks(const slnlp_gemm_args* jobs, int njobs, int blocks) {
+    if (blocks > 256) return 1;
+    for (int i = 0; i < njobs; ++i)
+        if (ceil_div(jobs[i].K, BKT) < 4) return 1;       // (also splitting groups with one short job was measured: no gain)
+    return 2;
 }
 
 template <int NSPLIT, bool AK, bool BK, bool VEC>
@@ -384,12 +435,14 @@ static void launch2(const GemmParams& p, hipStream_t s) {
     // Skinny problems (one row-block) get 16-column tiles: 4x the workgroups, so a
     // [50 x 512] x [512 x 512] decoder GEMM runs on 32 CUs instead of 8.
     const bool narrow = p.a.M <= BM && p.a.rowsum_a == nullptr;
+    const dim3 grid(ceil_div(p.a.N, narrow ? 16 : 64), ceil_div(p.a.M, BM));
+    const int ks = VEC ? pick_ks(&p.a, 1, (int)(grid.x * grid.y)) : 1;
     if (narrow) {
-        dim3 grid(ceil_div(p.a.N, 16), ceil_div(p.a.M, BM));
-        hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 16, VEC>), grid, dim3(256), 0, s, p);
+        if (ks == 2) hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 16, VEC, VEC ? 2 : 1>), grid, dim3(VEC ? 512 : 256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 16, VEC>), grid, dim3(256), 0, s, p);
     } else {   // (64x32 tiles for ~1-block-per-CU grids were measured: no gain, 17.6 vs 16.0 us)
-        dim3 grid(ceil_div(p.a.N, 64), ceil_div(p.a.M, BM));
-        hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 64, VEC>), grid, dim3(256), 0, s, p);
+        if (ks == 2) hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 64, VEC, VEC ? 2 : 1>), grid, dim3(VEC ? 512 : 256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<NSPLIT, AK, BK, 64, VEC>), grid, dim3(256), 0, s, p);
     }
 }
 
@@ -470,9 +523,10 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
         SLNLP_CHECK_ARG(nb == 1 || (a.batch_stride_a % 4 == 0 && a.batch_stride_b % 4 == 0), "gemm_group: batch strides must keep 16-byte alignment");
         blocks += P.gx[i] * P.gy[i] * nb;
     }
+    const int ks = pick_ks(jobs, njobs, blocks);
     if (recording()) {
         SLNLP_CHECK_ARG(fusable, "gemm_group: an operand that cannot take 16-byte loads cannot join a lockstep launch");
-        return record_op(gemm_group_kernel_ptr(jobs[0].precision), dim3(blocks), dim3(256), 0, REC_GEMM_GROUP, &P, sizeof(P), "gemm_group");
+        return record_op(gemm_group_kernel_ptr(jobs[0].precision, ks), dim3(blocks), dim3(256 * ks), 0, REC_GEMM_GROUP, &P, sizeof(P), "gemm_group");
     }
     bool batched = false;
     for (int i = 0; i < njobs; ++i) batched = batched || jobs[i].batch > 1;
@@ -489,14 +543,21 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
         }
         return SLNLP_OK;
     }
-    if (jobs[0].precision == 3) hipLaunchKernelGGL(gemm_group_kernel<3>, dim3(blocks), dim3(256), 0, s, P, (const GemmJob*)nullptr, (const int*)nullptr);
-    else hipLaunchKernelGGL(gemm_group_kernel<1>, dim3(blocks), dim3(256), 0, s, P, (const GemmJob*)nullptr, (const int*)nullptr);
+    void* args[3] = {(void*)&P, nullptr, nullptr};
+    const GemmJob* no_tab = nullptr;
+    const int* no_map = nullptr;
+    args[1] = (void*)&no_tab; args[2] = (void*)&no_map;
+    if (hipLaunchKernel(gemm_group_kernel_ptr(jobs[0].precision, ks), dim3(blocks), dim3(256 * ks), args, 0, s) != hipSuccess) {
+        set_error("gemm_group: launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
     SLNLP_CHECK_LAUNCH("gemm_group");
     return SLNLP_OK;
 }
 
-const void* gemm_group_kernel_ptr(int precision) {
-    return precision == 3 ? (const void*)gemm_group_kernel<3> : (const void*)gemm_group_kernel<1>;
+const void* gemm_group_kernel_ptr(int precision, int ks) {
+    if (precision == 3) return ks == 2 ? (const void*)gemm_group_kernel<3, 2> : (const void*)gemm_group_kernel<3, 1>;
+    return ks == 2 ? (const void*)gemm_group_kernel<1, 2> : (const void*)gemm_group_kernel<1, 1>;
 }
 
 // ------------------------------------------------------------- fused recurrent step ---

@@ -59,7 +59,7 @@ __device__ __forceinline__ void launder(slnlp_gemm_args& a) {
 }
 
 // kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)
-const void* gemm_group_kernel_ptr(int precision);
+const void* gemm_group_kernel_ptr(int precision, int ks = 1);
 const void* gemm_planes_kernel_ptr(int precision);
 size_t gemm_planes_lds_bytes();
 

@@ -145,7 +145,9 @@ def test_dropout_path_vs_oracle_with_same_masks(rnn_type):
 @pytest.mark.parametrize("B,Hd", [(50, 512), (7, 40), (70, 64)])
 def test_fused_step_equals_gemm_plus_cell(lstm, B, Hd):
     """slnlp_rnn_step_fwd (recurrent GEMM + cell in one launch) against slnlp_gemm + slnlp_rnn_cell_fwd on the same
-    inputs: identical split-bf16 K order -> bit-identical state, gate activations and (dropped, length-masked) outputs."""
+    inputs: the same split-bf16 products -> the same state, gate activations and (dropped, length-masked) outputs.  Bit for
+    bit where both run the K tiles in one sequence (Hd < 256: fewer than four K tiles); where the stand-alone GEMM cuts its K
+    loop over two wave groups (gemm.hip, KS = 2) the two halves are added in another order: equal to fp32 rounding."""
     import ctypes as C
     from slnlp import ops
     from slnlp._lib import RnnCellDir, RnnStepDir, check, load, ptr, stream_ptr
@@ -174,12 +176,13 @@ def test_fused_step_equals_gemm_plus_cell(lstm, B, Hd):
                    ptr(f["out"]), t, t * B, Hd)
     check(load().slnlp_rnn_step_fwd(lstm, C.byref(s), 1, B, Hd, ptr(lengths), fill, ld_out, p, site, ptr(rng), 3, stream_ptr()), "step")
     torch.cuda.synchronize()
-    assert torch.equal(h_out, h_ref) and torch.equal(hprev_ref, h)
-    assert torch.equal(f["acts"], r["acts"]) and torch.equal(f["out"], r["out"])
+    same = torch.equal if Hd < 256 else (lambda a, b: torch.allclose(a, b, rtol=2e-6, atol=2e-6))
+    assert same(h_out, h_ref) and torch.equal(hprev_ref, h)
+    assert same(f["acts"], r["acts"]) and same(f["out"], r["out"])
     if lstm:
-        assert torch.equal(f["c"], r["c"]) and torch.equal(f["cprev"], r["cprev"])
+        assert same(f["c"], r["c"]) and torch.equal(f["cprev"], r["cprev"])
     else:
-        assert torch.equal(f["hn"], r["hn"])
+        assert same(f["hn"], r["hn"])
     assert (lengths <= t).any() and (lengths > t).any()          # both masked and live rows were exercised
 
 
