@@ -178,8 +178,19 @@ SLNLP_ZKERNEL(xmem_bwd_kernel, 256, xmem_bwd_body)
 __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, const float* __restrict__ dsc, const float* __restrict__ dmbar,
                                                const float* __restrict__ qk, int B, int S, int H, int E, float* __restrict__ dmem,
                                                int accumulate, float drop_p, unsigned drop_thr, int drop_site,
-                                               const unsigned long long* __restrict__ rng) {
+                                               const unsigned long long* __restrict__ rng, const float* __restrict__ dcp,
+                                               float* __restrict__ dbv) {
     __shared__ float ph[64], dh_[64];                    // this row's p_s (after dropout) and d score_s per head: computed once
+    if ((int)blockIdx.x >= S * B) {                      // the launch's last ceil(E / 256) workgroups: d bv = column sums of dcp, in row
+        const int c = ((int)blockIdx.x - S * B) * 256 + threadIdx.x;   // order (was a launch of its own: 5 us of dispatch for 100 KB)
+        if (c < E) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < B; ++r) a += dcp[(long)r * E + c];
+            dbv[c] = a;
+        }
+        return;
+    }
     const int m = blockIdx.x, s = m / B, b = m % B;
     if (threadIdx.x < H) {
         const long bh = (long)b * H + threadIdx.x;
@@ -260,9 +271,8 @@ int xmem_bwd(const float* mem, const float* bv, const float* probs, const float*
     if (lds > 65536) SLNLP_TRY(xmem_init());
     SLNLP_TRY(zlaunch(xmem_bwd_kernel, dim3(B * H), 256, lds, st, "xmem_bwd", mem, bv, probs, psum, dmbar, dctx, B, S, H, dh, dsc, dqk, dcp,
                       drop_p, dropout_threshold(drop_p), drop_site, rng));
-    SLNLP_TRY(zlaunch(xmem_dmem_kernel, dim3(S * B), 256, 0, st, "xmem_dmem", probs, (const float*)dsc, dmbar, qk, B, S, H, E, dmem,
-                      accumulate, drop_p, dropout_threshold(drop_p), drop_site, rng));
-    return zlaunch(xmem_colsum_kernel, dim3(ceil_div(E, 256)), 256, 0, st, "xmem_colsum", (const float*)dcp, B, E, dbv);
+    return zlaunch(xmem_dmem_kernel, dim3(S * B + ceil_div(E, 256)), 256, 0, st, "xmem_dmem", probs, (const float*)dsc, dmbar, qk, B, S, H, E, dmem,
+                   accumulate, drop_p, dropout_threshold(drop_p), drop_site, rng, (const float*)dcp, dbv);
 }
 
 }  // namespace slnlp

@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupPar
 // KS = 2 (two K halves per workgroup) for launches that cannot fill the chip and whose duration is the chain of K steps;
 // one rule for single launches, grouped launches and recorded (lockstep) ones, so a fit computes the same bits everywhere
 static int pick_ks(const slnlp_gemm_args* jobs, int njobs, int blocks) {
-    if (blocks > 256) return 1;
+    // <= 128 workgroups: the decoder's 50-row products.  The RNN's recurrent dgrad group (256 workgroups) gained 2.6 % of a solo
+    // LSTM step with KS = 2 but lost 15 % at 16 lockstep fits, where the merged launch is throughput-bound -- and a fit must run
+    // the same kernel alone and in lockstep (bit-identical results), so the rule cannot look at the merged size.
+    if (blocks > 128) return 1;
     for (int i = 0; i < njobs; ++i)
         if (ceil_div(jobs[i].K, BKT) < 4) return 1;       // (also splitting groups with one short job was measured: no gain)
     return 2;
