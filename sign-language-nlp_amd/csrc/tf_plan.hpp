@@ -388,7 +388,7 @@ struct slnlp_tf_plan {
     // side[k] may start once everything enqueued on `main` so far has finished
     // side_mode: which phases may fork work to the side streams: 0 = none -- every launch on the caller's stream (default),
     // 1 = forward only, 2 = forward and backward (env SLNLP_TF_SIDE_STREAMS at plan creation; experiments only).
-    // Round 2 measurements at cfg2 (tools/debug_race2.py): the serial step is as fast as the forked one (3.23 vs 3.21 ms;
+    // Round 2 measurements at cfg2 (tools/probes/debug_race2.py): the serial step is as fast as the forked one (3.23 vs 3.21 ms;
     // forward-only forks 3.35 ms) and it is the only fully deterministic one: with the backward forks 7 of 16 identical
     // steps differed from the single-stream result (first wrong value: one row of decoder layer l's norm1 LayerNorm
     // backward while the d-memory / K|V weight-gradient group of that layer ran on side[0]; gone under
