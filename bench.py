@@ -43,8 +43,8 @@ WORKLOADS = {
     # configs[0] -- the reference's own CPU-runnable debug case (.vscode/launch.json:26)
     "cfg1": dict(E=128, H=4, N=2, F=256, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
     "e1024": dict(E=1024, H=8, N=6, F=512, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
-    # configs[4] shape (d_model 1024, 6 layers, batch 256, len 64; F not stated in BASELINE.json -> grid max 512) in
-    # split-bf16: the fp8-weight variant is not built
+    # configs[4] shape (d_model 1024, 6 layers, batch 256, len 64; F not stated in BASELINE.json -> grid max 512); split-bf16
+    # by default, `--precision 8` runs its forward products on the fp8 MFMA (configs[4]'s "fp8 MFMA weights")
     "cfg5": dict(E=1024, H=8, N=6, F=512, Vs=3000, Vt=202, B=256, S=64, dropout=0.1),
     # configs[2] -- EncoderDecoderLSTMAttn hidden=512, 4 layers, batch=50
     "cfg3": dict(rnn="lstm", E=512, Hd=512, N=4, Vs=3000, Vt=202, B=50, S=48, dropout=0.1),
@@ -199,21 +199,22 @@ def concurrent_fits(c, precision, dev, ks=(4, 8, 16), steps=30):
             "note": f"{steps} steps per fit, every fit its own weights / data; the step's kernels carry a fit index (grid.z) or a merged job table"}
 
 
-# 48 of config-transformer.yaml's 324 candidates: every lr and dropout, two embedding sizes, two hidden sizes and both head
-# counts at num_layers 2 -> 8 shapes x 30 (candidate, fold) fits.  With lockstep 15 (the 3 learning rates x 5 folds of a
-# (shape, dropout) pair advance together) that is 16 work units: 8 at embedding_size 512 and 8 cheap ones at 128, so the
-# strong-scaling leg divides evenly over 1 / 2 / 4 / 8 GPUs (one large + one small unit per GPU at N = 8).
+# THE folds/hr sample (fixed from round 3 on; rounds 1-2 quoted smaller ones): 96 of config-transformer.yaml's 324 candidates --
+# every lr and dropout, two embedding sizes, two hidden sizes, both head counts, two depths -> 16 shapes x 30 (candidate, fold)
+# fits = 480 fits of 6 epochs over 4000 samples.  With lockstep 15 (the 3 learning rates x 5 folds of a (shape, dropout) pair
+# advance together) that is 32 work units in four cost classes (E512 N4 / E512 N2 / E128 N4 / E128 N2, 8 each): at N = 8 the
+# longest-first deal gives every GPU one unit of the first class, the host threads prefetch one of the second, and the 16 small
+# ones are pulled as GPUs fall idle (slnlp/grid.py WorkCounter) -- the strong-scaling leg stays balanced at 1 / 2 / 4 / 8 GPUs.
 GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__embedding_size": [512, 128],
-               "module__hidden_size": [512, 256], "module__num_heads": [8, 4]}
-GRID_FIXED = {"module__num_layers": 2}
-GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 8, 4000
+               "module__hidden_size": [512, 256], "module__num_heads": [8, 4], "module__num_layers": [4, 2]}
+GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 6, 4000
 
 
 def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
     from slnlp.net import NeuralNetClassifier
     return lambda: NeuralNetClassifier(
         module="model.Transformer", module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
-        module__embedding_size=512, module__num_heads=4, module__num_layers=GRID_FIXED["module__num_layers"],
+        module__embedding_size=512, module__num_heads=4, module__num_layers=2,
         module__hidden_size=256, module__dropout=0.1, criterion__ignore_index=1, optimizer__momentum=0.9, optimizer__nesterov=False, lr=0.01, max_epochs=max_epochs, batch_size=50,
         device=str(dev), gradient_clipping={"gradient_clip_value": 0.5},
         scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
@@ -221,7 +222,7 @@ def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
 
 def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=15):
     """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
-    on a bounded sample of config-transformer.yaml's grid -- 48 candidates x cv 5 = 240 fits of 8 epochs over 4000
+    on a bounded sample of config-transformer.yaml's grid -- 96 candidates x cv 5 = 480 fits of 6 epochs over 4000
     synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
     ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling).  Work unit =
     `lockstep` shape-compatible fits advancing through one launch sequence; `fits_per_gpu` host threads per rank each run
@@ -251,8 +252,8 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=15):
             "fits_per_gpu": fits_per_gpu, "lockstep": lockstep, "work_units": gs.n_units_, "ranks": world, "schedule": gs.schedule,
             "rank_seconds": [round(v, 2) for v in gs.rank_seconds_], "rank_fits": gs.rank_tasks_, "warmup_seconds": round(warm_s, 2),
             "best_index": gs.best_index_, "best_score": round(gs.best_score_, 5),
-            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x embedding_size x hidden_size x num_heads of config-transformer.yaml at "
-                      f"num_layers 2) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
+            "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x embedding_size x hidden_size x num_heads x num_layers of "
+                      f"config-transformer.yaml) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
                       "the reference's 5 epoch metrics on both; includes the dataset broadcast and the score all_gather"}
 
 

@@ -390,10 +390,18 @@ int slnlp_tf_params_changed(slnlp_tf_plan* plan);
 int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_bytes);
 
 /* slnlp_*_destroy wait for the device (hipDeviceSynchronize) before they return: the plan's buffers are the caller's and
- * may be freed next.  on = 0 drops that wait, process-wide -- only for callers whose buffers come from a stream-ordered
- * allocator on the stream the plans ran on (torch's caching allocator), where the device-wide wait stalls every other host
- * thread's queued work each time a fit ends. */
-int slnlp_set_destroy_sync(int on);
+ * may be freed next.  on = 0 drops that wait FOR THIS PLAN (never process-wide) -- only for a caller whose buffers come from
+ * a stream-ordered allocator on the stream the plan ran on (torch's caching allocator), where the device-wide wait stalls
+ * every other host thread's queued work each time a fit ends. */
+int slnlp_tf_set_destroy_sync(slnlp_tf_plan* plan, int on);
+
+/* One kernel sequence per device.  Kernels of this library on two hardware queues at once (two streams, or two processes on
+ * one GPU) have been measured to read each other's producer output stale on MI355X / ROCm 7.2.  The
+ * step entry points (slnlp_{tf,rnn}_{forward,backward,optim*,train_step,graph_launch}, slnlp_*_lockstep_{step,epoch})
+ * therefore serialise per device: host threads enqueue whole steps in turn, and a step issued on another stream than the
+ * device's previous step waits (event) for that stream's tail, so the library's kernels never overlap across streams inside
+ * one process.  serialise = 0 switches this off (experiments / probes only); two processes on one GPU stay unsupported. */
+int slnlp_set_stream_policy(int serialise);
 
 /* ---------------------------------------------------------------- lockstep --
  * K Transformer fits of ONE shape (own weights, lr, dropout rate, seed and data) advancing through one launch
@@ -421,6 +429,12 @@ int slnlp_tf_lockstep_epoch(slnlp_tf_lockstep* group, int slot, int batch, int t
                             void* stream);
 /* kernel launches per step of the cached program for (slot, B, train), or -1 if none has been recorded yet */
 int slnlp_tf_lockstep_num_launches(slnlp_tf_lockstep* group, int slot, int B, int train);
+/* train with clip_grad_norm_ + Adam instead of SGD-momentum from now on (what slnlp_tf_optim_adam does for one fit):
+ * exp_avg = each plan's momentum arena, exp_avg_sq[f] = an arena-shaped buffer of the caller's per fit (zero before the first
+ * step), step count = each plan's scalars[2]; `momentum` of the step calls is then ignored.  Drops recorded train programs. */
+int slnlp_tf_lockstep_set_adam(slnlp_tf_lockstep* group, float* const* exp_avg_sq, float beta1, float beta2, float eps,
+                               float weight_decay);
+int slnlp_tf_lockstep_set_destroy_sync(slnlp_tf_lockstep* group, int on);   /* as slnlp_tf_set_destroy_sync, for the group's tables */
 
 
 /* ------------------------------------------------- enc-dec RNN (+attn) plan --
@@ -457,6 +471,10 @@ int slnlp_rnn_health(slnlp_rnn_plan* plan, int* status);
 int slnlp_rnn_seed_dlogp(slnlp_rnn_plan* plan, const float* dlogp, void* stream);
 int slnlp_rnn_backward(slnlp_rnn_plan* plan, void* stream);
 int slnlp_rnn_optim(slnlp_rnn_plan* plan, float momentum, float max_norm, void* stream);
+/* clip + torch.optim.Adam on the arena, as slnlp_tf_optim_adam (exp_avg = buf.momentum, step count = scalars[2]) */
+int slnlp_rnn_optim_adam(slnlp_rnn_plan* plan, float* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay,
+                         float max_norm, void* stream);
+int slnlp_rnn_set_destroy_sync(slnlp_rnn_plan* plan, int on);   /* as slnlp_tf_set_destroy_sync */
 int slnlp_rnn_train_step(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, const int64_t* lengths, int B,
                          float momentum, float max_norm, float* logp, void* stream);
 int slnlp_rnn_graph_capture_train(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, const int64_t* lengths,
@@ -483,6 +501,9 @@ int slnlp_rnn_lockstep_step(slnlp_rnn_lockstep* group, int slot, int64_t row0, i
 int slnlp_rnn_lockstep_epoch(slnlp_rnn_lockstep* group, int slot, int batch, int train, float momentum, float max_norm,
                              void* stream);
 int slnlp_rnn_lockstep_num_launches(slnlp_rnn_lockstep* group, int slot, int B, int train);
+int slnlp_rnn_lockstep_set_adam(slnlp_rnn_lockstep* group, float* const* exp_avg_sq, float beta1, float beta2, float eps,
+                                float weight_decay);
+int slnlp_rnn_lockstep_set_destroy_sync(slnlp_rnn_lockstep* group, int on);
 
 #ifdef __cplusplus
 }

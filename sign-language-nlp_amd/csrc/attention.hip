@@ -566,15 +566,15 @@ constexpr size_t ATTN_BWD_MFMA_LDS = 10 * ATILE * sizeof(unsigned short);  // up
 
 // one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
 int attn_init() {
-    static int state = 0;  // 0 = not yet, 1 = ok
-    if (state == 1) return 0;
-    if (hipFuncSetAttribute((const void*)attn_self_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)ATTN_BWD_MFMA_LDS) != hipSuccess) {
-        set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
-        return SLNLP_ERR_LAUNCH;
-    }
-    state = 1;
-    return 0;
+    static DeviceOnce once;
+    return once.run([]() -> int {
+        if (hipFuncSetAttribute((const void*)attn_self_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ATTN_BWD_MFMA_LDS) != hipSuccess) {
+            set_error("attn_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+        return 0;
+    });
 }
 
 // S > 64: the wave-per-row kernels of attention_long.hip

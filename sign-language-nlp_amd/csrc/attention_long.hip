@@ -301,10 +301,8 @@ SLNLP_ZKERNEL(attn_cross_bwd_long_kernel, 256, attn_cross_bwd_long_body)
 // ------------------------------------------------------------------ launchers (called by attention.hip when S > 64)
 // 4 rows x S floats of dynamic LDS: above 64 KiB (S > 4096) the kernels' limit must be raised, once per device
 static int long_lds_init() {
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[dev]) return 0;
+    static DeviceOnce once;
+    return once.run([]() -> int {
     const int bytes = 4 * 5000 * (int)sizeof(float);
     const bool ok = hipFuncSetAttribute((const void*)attn_self_fwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
                     hipFuncSetAttribute((const void*)attn_self_bwd_long_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
@@ -314,8 +312,8 @@ static int long_lds_init() {
         set_error("attention_long: cannot raise the dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
-    done[dev] = true;
     return 0;
+    });
 }
 
 static int check_long(const char* who, int B, int S, int H, int dh) {

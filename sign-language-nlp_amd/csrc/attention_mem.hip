@@ -173,6 +173,8 @@ __device__ __forceinline__ void xmem_bwd_body(const float* __restrict__ mem, con
 }
 SLNLP_ZKERNEL(xmem_bwd_kernel, 256, xmem_bwd_body)
 
+constexpr int XMEM_MAX_HEADS = 64;      // heads per sequence the d-memory kernel keeps in LDS (xmem_check rejects more)
+
 // ------------------------------------------------------------------------------------ backward, per memory row ----
 // d mem[s*B+b, :] (+)= sum_h ( p_s(b,h) d mbar(b,h,:) + d score_s(b,h) qk(b,h,:) ),  p after dropout; heads in fixed order
 __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, const float* __restrict__ dsc, const float* __restrict__ dmbar,
@@ -180,7 +182,7 @@ __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, 
                                                int accumulate, float drop_p, unsigned drop_thr, int drop_site,
                                                const unsigned long long* __restrict__ rng, const float* __restrict__ dcp,
                                                float* __restrict__ dbv) {
-    __shared__ float ph[64], dh_[64];                    // this row's p_s (after dropout) and d score_s per head: computed once
+    __shared__ float ph[XMEM_MAX_HEADS], dh_[XMEM_MAX_HEADS];   // this row's p_s (after dropout) and d score_s per head: computed once
     if ((int)blockIdx.x >= S * B) {                      // the launch's last ceil(E / 256) workgroups: d bv = column sums of dcp, in row
         const int c = ((int)blockIdx.x - S * B) * 256 + threadIdx.x;   // order (was a launch of its own: 5 us of dispatch for 100 KB)
         if (c < E) {
@@ -227,23 +229,22 @@ SLNLP_ZKERNEL(xmem_colsum_kernel, 256, xmem_colsum_body)
 
 // ------------------------------------------------------------------------------------------------ launchers ----
 static int xmem_init() {                  // dynamic LDS beyond 64 KiB is only needed for S in the thousands; raise once per device
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[dev]) return 0;
-    const int bytes = (1024 + 5000 + 8) * (int)sizeof(float);
-    if (hipFuncSetAttribute((const void*)xmem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)xmem_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-        set_error("attention_mem: cannot raise the dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
-        return SLNLP_ERR_LAUNCH;
-    }
-    done[dev] = true;
-    return 0;
+    static DeviceOnce once;
+    return once.run([]() -> int {
+        const int bytes = (1024 + 5000 + 8) * (int)sizeof(float);
+        if (hipFuncSetAttribute((const void*)xmem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)xmem_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            set_error("attention_mem: cannot raise the dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+        return 0;
+    });
 }
 
 static int xmem_check(const char* who, int B, int S, int H, int dh) {
     SLNLP_CHECK_ARG(B > 0 && S > 0 && S <= 5000 && H > 0, "%s: bad B=%d S=%d H=%d", who, B, S, H);
     SLNLP_CHECK_ARG(dh > 0 && dh % 4 == 0 && dh <= 256 && H * dh <= 1024, "%s: head_dim %d / model dim %d unsupported", who, dh, H * dh);
+    SLNLP_CHECK_ARG(H <= XMEM_MAX_HEADS, "%s: %d heads (the per-head LDS tables of the d-memory kernel hold %d)", who, H, XMEM_MAX_HEADS);
     return 0;
 }
 

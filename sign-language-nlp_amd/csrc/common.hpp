@@ -1,6 +1,8 @@
 // Shared device/host helpers for the slnlp gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -38,6 +40,25 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time initialisation per device (hipFuncSetAttribute applies per device) that the fits_per_gpu host threads of a rank
+// may all reach at once: the first caller runs `init` under a mutex, everyone else waits for it or takes the lock-free path.
+struct DeviceOnce {
+    std::mutex mu;
+    std::atomic<bool> done[64];
+    DeviceOnce() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
+    template <class F>
+    int run(F&& init) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (done[dev].load(std::memory_order_acquire)) return 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done[dev].load(std::memory_order_relaxed)) return 0;
+        const int rc = init();
+        if (rc == 0) done[dev].store(true, std::memory_order_release);
+        return rc;
+    }
+};
 
 // ------------------------------------------------------------- dropout ------
 // Counter-based Philox4x32-10.  A dropout site is a logical [R, C] tensor;

@@ -932,10 +932,8 @@ __global__ __launch_bounds__(256) void rnn_layer_fwd_kernel(const RnnLayerParams
 
 // one-time opt-in to > 64 KiB dynamic LDS; called from plan creation so it never lands inside a graph capture
 int rnn_layer_init() {
-    static bool done[64] = {};                  // hipFuncSetAttribute applies per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[dev]) return 0;
+    static DeviceOnce once;                     // hipFuncSetAttribute applies per device
+    return once.run([]() -> int {
     const int lim = 156 * 1024;
     const bool ok =
         hipFuncSetAttribute((const void*)rnn_layer_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess &&
@@ -946,8 +944,8 @@ int rnn_layer_init() {
         set_error("rnn_layer_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
-    done[dev] = true;
     return 0;
+    });
 }
 
 static size_t rnn_layer_lds(int G, int Hd, int precision) {

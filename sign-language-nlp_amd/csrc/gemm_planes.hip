@@ -434,19 +434,17 @@ constexpr int GROUP_COUNTERS = 4096;                       // ints at the head o
 
 // set the kernels' LDS attribute up front (plan creation) so it never lands inside a graph capture
 int gemm_planes_init() {
-    static bool done[64] = {};                  // hipFuncSetAttribute applies per device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[dev]) return 0;
-    const bool ok =
-        hipFuncSetAttribute((const void*)gemm_planes_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLANE_LDS) == hipSuccess &&
-        hipFuncSetAttribute((const void*)gemm_planes_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLANE_LDS) == hipSuccess;
-    if (!ok) {
-        set_error("gemm_planes_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
-        return SLNLP_ERR_LAUNCH;
-    }
-    done[dev] = true;
-    return 0;
+    static DeviceOnce once;
+    return once.run([]() -> int {
+        const bool ok =
+            hipFuncSetAttribute((const void*)gemm_planes_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLANE_LDS) == hipSuccess &&
+            hipFuncSetAttribute((const void*)gemm_planes_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLANE_LDS) == hipSuccess;
+        if (!ok) {
+            set_error("gemm_planes_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+        return 0;
+    });
 }
 
 static int check_plane_job(const slnlp_gemm_args& a) {

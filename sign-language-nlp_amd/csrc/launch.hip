@@ -20,9 +20,55 @@ unsigned long long bump_params_generation(const float* params) {
     return ++gen_table[params];
 }
 
-static std::atomic<int> g_destroy_sync{1};
-void destroy_sync() {
-    if (g_destroy_sync.load(std::memory_order_relaxed)) (void)hipDeviceSynchronize();
+void destroy_sync(int plan_wants_sync) {
+    if (plan_wants_sync) (void)hipDeviceSynchronize();
+}
+
+// ---- one kernel sequence per device (launch.hpp, StepScope)
+static std::atomic<int> g_stream_policy{1};
+constexpr int MAX_DEV = 64;
+struct DevSeq {
+    std::recursive_mutex mu;            // recursive: a host thread's nested scopes
+    hipStream_t last = nullptr;         // stream of the last step enqueued on this device
+    bool any = false;
+    hipEvent_t ev = nullptr;
+};
+static DevSeq g_seq[MAX_DEV];
+static thread_local int tl_scope_depth = 0;
+
+StepScope::StepScope(hipStream_t st) : st_(st) {
+    if (tl_scope_depth++ > 0 || !g_stream_policy.load(std::memory_order_relaxed) || recording()) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    dev_ = dev;
+    outer_ = true;
+    DevSeq& q = g_seq[dev];
+    q.mu.lock();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return;               // a captured step is replayed later, under its own scope
+    if (q.any && q.last != st) {
+        // the tail of the other stream: everything enqueued there so far (nobody else enqueues: we hold the mutex)
+        bool ok = q.ev || hipEventCreateWithFlags(&q.ev, hipEventDisableTiming) == hipSuccess;
+        if (ok && hipEventRecord(q.ev, q.last) == hipSuccess) {
+            if (hipStreamWaitEvent(st, q.ev, 0) != hipSuccess) {
+                set_error("StepScope: cannot order stream %p behind stream %p: %s", (void*)st, (void*)q.last, hipGetErrorString(hipGetLastError()));
+                rc = SLNLP_ERR_LAUNCH;
+            }
+        } else {
+            (void)hipGetLastError();    // the other stream is gone (destroying it waited for its work): nothing to order against
+        }
+    }
+}
+
+StepScope::~StepScope() {
+    --tl_scope_depth;
+    if (!outer_) return;
+    DevSeq& q = g_seq[dev_];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st_, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone) { q.last = st_; q.any = true; }
+    q.mu.unlock();
 }
 
 static thread_local Recorder* tl_recorder = nullptr;
@@ -61,7 +107,7 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
 
 }  // namespace slnlp
 
-extern "C" int slnlp_set_destroy_sync(int on) {
-    slnlp::g_destroy_sync.store(on ? 1 : 0, std::memory_order_relaxed);
+extern "C" int slnlp_set_stream_policy(int serialise) {
+    slnlp::g_stream_policy.store(serialise ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }

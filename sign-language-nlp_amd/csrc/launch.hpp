@@ -149,10 +149,35 @@ int zlaunch(void (*kern)(P, const P*), dim3 grid, int threads, size_t lds, hipSt
 }
 
 // What a destroy call does about work still in flight.  Default: hipDeviceSynchronize() -- the plan's buffers belong to the
-// caller, who may free them next.  slnlp_set_destroy_sync(0): nothing -- for callers whose buffers come from a STREAM-ORDERED
-// allocator on the stream the plan ran on (torch's caching allocator: a freed block is only handed to later work of that
-// stream), where the device-wide wait would stall every other host thread's queued work behind each plan that goes away.
-void destroy_sync();
+// caller, who may free them next.  A plan (or lockstep group) whose owner switched it off -- slnlp_{tf,rnn}[_lockstep]_
+// set_destroy_sync(handle, 0), per object, never process-wide -- skips the wait: for callers whose buffers come from a
+// STREAM-ORDERED allocator on the stream the plan ran on (torch's caching allocator: a freed block is only handed to later
+// work of that stream), where the device-wide wait would stall every other host thread's queued work behind each plan that
+// goes away.
+void destroy_sync(int plan_wants_sync);
+
+// ONE kernel sequence per device.  Measured on MI355X / ROCm 7.2 (tools/probes/): kernels of this library
+// running on two hardware queues at once can read each other's ... producer output stale.  Until that is root-caused the
+// library itself keeps its kernels from overlapping across streams: every top-level step entry point opens a StepScope, which
+//   * holds a per-device mutex while the step's launches are enqueued (host threads take turns, whole steps at a time),
+//   * when the previous step of this device was enqueued on ANOTHER stream, records an event at that stream's tail and makes
+//     this step's stream wait for it (the common case -- one shared stream -- costs a mutex and nothing on the GPU).
+// Scopes nest (slnlp_tf_train_step -> slnlp_tf_forward ...): only the outermost acts.  Skipped while a launch recorder is
+// installed (nothing is launched) and on a capturing stream.  slnlp_set_stream_policy(0) switches it off for experiments.
+struct StepScope {
+    explicit StepScope(hipStream_t st);
+    ~StepScope();
+    StepScope(const StepScope&) = delete;
+    StepScope& operator=(const StepScope&) = delete;
+    int rc = 0;
+  private:
+    bool outer_ = false;
+    int dev_ = 0;
+    hipStream_t st_ = nullptr;
+};
+
+// the fused Adam update's constants, when a lockstep group trains with Adam instead of SGD-momentum (lockstep.hip)
+struct LsAdam { float beta1, beta2, eps, weight_decay; };
 
 // zero `bytes` (a multiple of 16, 16-B aligned) with a kernel of ours: recordable, unlike hipMemsetAsync
 int fill_zero(void* p, size_t bytes, hipStream_t st);

@@ -36,7 +36,7 @@ constexpr int LS_SLOTS = 4;
 // hooks of the RNN plan (its struct is private to rnn_plan.hip)
 int rnn_ls_prepare(slnlp_rnn_plan* pl, int B, hipStream_t st);
 int rnn_ls_record(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum,
-                  float max_norm, hipStream_t st);
+                  float max_norm, const LsAdam* adam, float* exp_avg_sq, hipStream_t st);
 void rnn_ls_outputs(slnlp_rnn_plan* pl, float* logp, float* loss, const int* dyn);
 void rnn_ls_replayed(slnlp_rnn_plan* pl, int B, int train);
 const slnlp_rnn_config* rnn_ls_cfg(slnlp_rnn_plan* pl);
@@ -97,7 +97,7 @@ struct LsFit {
     void* plan;
     int (*prepare)(void* plan, int B, hipStream_t st);      // work that must stay outside a recorded program (memsets, re-splits)
     int (*record)(void* plan, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum, float max_norm,
-                  hipStream_t st);                          // the ordinary step code, run under a Recorder
+                  const LsAdam* adam, float* exp_avg_sq, hipStream_t st);   // the ordinary step code, run under a Recorder
     void (*outputs)(void* plan, float* logp, float* loss, const int* dyn);
     void (*replayed)(void* plan, int B, int train);         // host bookkeeping after the step's launches were issued
 };
@@ -106,8 +106,9 @@ struct LockstepGroup {
     std::vector<LsFit> fits;
     bool has_len = false;
     int K = 0, S = 0, maxB = 0;
+    int destroy_sync = 1;                           // slnlp_*_lockstep_set_destroy_sync (launch.hpp)
     char* ws = nullptr;
-    size_t ws_bytes = 0, ws_used = 0;
+    size_t ws_bytes = 0, ws_used = 0, ws_mark = 0;  // ws_mark: bump position after ls_init (staging + pointer tables)
     std::vector<int64_t*> Xst, yst, Lst;            // per-fit staging (device)
     int64_t** d_Xst = nullptr;                      // device tables of the above
     int64_t** d_yst = nullptr;
@@ -119,9 +120,17 @@ struct LockstepGroup {
         const int64_t** d_X = nullptr;              // device tables [K]
         const int64_t** d_y = nullptr;
         const int64_t** d_len = nullptr;
+        std::vector<const int64_t*> hX, hy, hlen;   // host copies of the tables (re-uploaded when the table space is reclaimed)
         std::vector<float*> logp, loss;             // per-fit output buffers (device, caller-owned)
     } slot[LS_SLOTS];
     std::map<std::tuple<int, int, int>, Program> programs;   // (slot, B, train)
+    // the optimizer constants a train program baked into its recorded update launches: every later call must pass the same
+    bool have_opt = false;
+    float opt_momentum = 0.f, opt_max_norm = 0.f;
+    // slnlp_*_lockstep_set_adam: the group's train programs end in the fused Adam update instead of SGD-momentum
+    bool use_adam = false;
+    LsAdam adam{};
+    std::vector<float*> v2;                         // per-fit exp_avg_sq arenas (device, caller-owned)
 
     void* take(size_t bytes) {
         ws_used = (ws_used + 255) & ~(size_t)255;
@@ -257,11 +266,19 @@ static int ls_init(LockstepGroup* ls, int B, int S, void* workspace, int64_t wor
     SLNLP_TRY(upload(ls, ls->Xst.data(), K * sizeof(void*), (void**)&ls->d_Xst, st));
     SLNLP_TRY(upload(ls, ls->yst.data(), K * sizeof(void*), (void**)&ls->d_yst, st));
     if (ls->has_len) SLNLP_TRY(upload(ls, ls->Lst.data(), K * sizeof(void*), (void**)&ls->d_Lst, st));
+    ls->ws_mark = ls->ws_used;
+    return 0;
+}
+
+static int upload_slot_tables(LockstepGroup* ls, LockstepGroup::Slot& s, hipStream_t st) {
+    SLNLP_TRY(upload(ls, s.hX.data(), ls->K * sizeof(void*), (void**)&s.d_X, st));
+    SLNLP_TRY(upload(ls, s.hy.data(), ls->K * sizeof(void*), (void**)&s.d_y, st));
+    if (ls->has_len) SLNLP_TRY(upload(ls, s.hlen.data(), ls->K * sizeof(void*), (void**)&s.d_len, st));
     return 0;
 }
 
 static void ls_destroy(LockstepGroup* ls) {
-    destroy_sync();                    // tables live in caller memory that may be freed next
+    destroy_sync(ls->destroy_sync);    // tables live in caller memory that may be freed next
     for (LsFit& f : ls->fits) f.outputs(f.plan, nullptr, nullptr, nullptr);
 }
 
@@ -275,11 +292,21 @@ static int ls_set_data(LockstepGroup* ls, int slot, const int64_t* const* X, con
     s.rows = rows;
     s.logp.assign(logp, logp + ls->K);
     s.loss.assign(loss, loss + ls->K);
-    SLNLP_TRY(upload(ls, X, ls->K * sizeof(void*), (void**)&s.d_X, st));
-    SLNLP_TRY(upload(ls, y, ls->K * sizeof(void*), (void**)&s.d_y, st));
-    if (ls->has_len) SLNLP_TRY(upload(ls, len, ls->K * sizeof(void*), (void**)&s.d_len, st));
+    s.hX.assign(X, X + ls->K);
+    s.hy.assign(y, y + ls->K);
+    if (ls->has_len) s.hlen.assign(len, len + ls->K);
     s.set = true;
-    return 0;
+    if (ls->programs.empty()) {
+        // no recorded program refers to the table space any more: hand it all back (a long-lived group that keeps getting new
+        // data would otherwise run the bump allocator dry) and put the slots' pointer tables at its start again.  Ordered on
+        // `st` behind every launch that read the old tables.
+        ls->ws_used = ls->ws_mark;
+        ls->have_opt = false;
+        for (int k = 0; k < LS_SLOTS; ++k)
+            if (ls->slot[k].set) SLNLP_TRY(upload_slot_tables(ls, ls->slot[k], st));
+        return 0;
+    }
+    return upload_slot_tables(ls, s, st);
 }
 
 // One lockstep step of every fit on rows [row0, row0 + B) of slot `slot`: train != 0 -> forward + criterion + backward +
@@ -290,6 +317,15 @@ static int ls_step(LockstepGroup* ls, int slot, int64_t row0, int B, int step_in
     LockstepGroup::Slot& s = ls->slot[slot];
     SLNLP_CHECK_ARG(B > 0 && B <= ls->maxB && row0 >= 0 && row0 + B <= s.rows, "lockstep_step: rows [%ld, %ld) outside 0..%ld or batch > %d",
                     (long)row0, (long)(row0 + B), (long)s.rows, ls->maxB);
+    StepScope scope(st);               // one kernel sequence per device (launch.hpp)
+    SLNLP_TRY(scope.rc);
+    if (train) {
+        // momentum / max_norm are baked by value into the recorded update launches: a replay cannot change them
+        SLNLP_CHECK_ARG(!ls->have_opt || (ls->opt_momentum == momentum && ls->opt_max_norm == max_norm),
+                        "lockstep_step: momentum %g / max_norm %g differ from the values the group's train programs were recorded with "
+                        "(%g / %g); set new data (which drops the programs) or use another group",
+                        momentum, max_norm, ls->opt_momentum, ls->opt_max_norm);
+    }
     for (LsFit& f : ls->fits) SLNLP_TRY(f.prepare(f.plan, B, st));
     const auto key = std::make_tuple(slot, B, train ? 1 : 0);
     auto it = ls->programs.find(key);
@@ -300,13 +336,15 @@ static int ls_step(LockstepGroup* ls, int slot, int64_t row0, int B, int step_in
             LsFit& fit = ls->fits[f];
             fit.outputs(fit.plan, s.logp[f], s.loss[f], ls->dyn);
             set_recorder(&recs[f]);
-            rc = fit.record(fit.plan, ls->Xst[f], ls->yst[f], ls->Lst[f], B, train, momentum, max_norm, st);
+            rc = fit.record(fit.plan, ls->Xst[f], ls->yst[f], ls->Lst[f], B, train, momentum, max_norm, ls->use_adam ? &ls->adam : nullptr,
+                            ls->use_adam ? ls->v2[f] : nullptr, st);
             set_recorder(nullptr);
         }
         if (rc) return rc;
         Program prog;
         SLNLP_TRY(merge(ls, recs, prog, st));
         it = ls->programs.emplace(key, std::move(prog)).first;
+        if (train) { ls->have_opt = true; ls->opt_momentum = momentum; ls->opt_max_norm = max_norm; }
     }
     GatherArgs g;
     g.X = s.d_X; g.y = s.d_y; g.len = ls->has_len ? s.d_len : nullptr;
@@ -333,6 +371,20 @@ static int ls_epoch(LockstepGroup* ls, int slot, int batch, int train, float mom
     return 0;
 }
 
+// Train with clip_grad_norm_ + Adam from now on (exp_avg = each plan's momentum arena, exp_avg_sq[f] = an arena-shaped buffer of
+// the caller's, zero before the first step; the step count is each plan's scalars[2]).  Recorded train programs are dropped.
+static int ls_set_adam(LockstepGroup* ls, float* const* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay) {
+    SLNLP_CHECK_ARG(ls && exp_avg_sq, "lockstep_set_adam: null argument");
+    for (int f = 0; f < ls->K; ++f) SLNLP_CHECK_ARG(exp_avg_sq[f], "lockstep_set_adam: null exp_avg_sq for fit %d", f);
+    for (auto it = ls->programs.begin(); it != ls->programs.end();)
+        it = std::get<2>(it->first) ? ls->programs.erase(it) : std::next(it);
+    ls->v2.assign(exp_avg_sq, exp_avg_sq + ls->K);
+    ls->adam = LsAdam{beta1, beta2, eps, weight_decay};
+    ls->use_adam = true;
+    ls->have_opt = false;
+    return 0;
+}
+
 static int ls_num_launches(LockstepGroup* ls, int slot, int B, int train) {
     if (!ls) return -1;
     auto it = ls->programs.find(std::make_tuple(slot, B, train ? 1 : 0));
@@ -347,11 +399,12 @@ static int tf_prepare(void* p, int B, hipStream_t st) {
     return pl->ensure_wq(st);                  // precision 8: re-quantised weights, likewise outside the program
 }
 static int tf_record(void* p, const int64_t* X, const int64_t* y, const int64_t*, int B, int train, float momentum, float max_norm,
-                     hipStream_t st) {
+                     const LsAdam* adam, float* exp_avg_sq, hipStream_t st) {
     slnlp_tf_plan* pl = (slnlp_tf_plan*)p;
-    SLNLP_TRY(pl->forward_impl(X, y, B, train, nullptr, st, false));
+    SLNLP_TRY(pl->forward_impl(X, y, B, train, nullptr, st));
     if (!train) return 0;
     SLNLP_TRY(slnlp_tf_backward(pl, st));
+    if (adam) return slnlp_tf_optim_adam(pl, exp_avg_sq, adam->beta1, adam->beta2, adam->eps, adam->weight_decay, max_norm, st);
     return slnlp_tf_optim(pl, momentum, max_norm, st);
 }
 static void tf_outputs(void* p, float* logp, float* loss, const int* dyn) {
@@ -368,8 +421,8 @@ static void tf_replayed(void* p, int B, int train) {
 // ------------------------------------------------------------------------------------------------------ RNN hooks ----
 static int rnn_prepare(void* p, int B, hipStream_t st) { return rnn_ls_prepare((slnlp_rnn_plan*)p, B, st); }
 static int rnn_record(void* p, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum, float max_norm,
-                      hipStream_t st) {
-    return rnn_ls_record((slnlp_rnn_plan*)p, X, y, len, B, train, momentum, max_norm, st);
+                      const LsAdam* adam, float* exp_avg_sq, hipStream_t st) {
+    return rnn_ls_record((slnlp_rnn_plan*)p, X, y, len, B, train, momentum, max_norm, adam, exp_avg_sq, st);
 }
 static void rnn_outputs(void* p, float* logp, float* loss, const int* dyn) { rnn_ls_outputs((slnlp_rnn_plan*)p, logp, loss, dyn); }
 static void rnn_replayed(void* p, int B, int train) { rnn_ls_replayed((slnlp_rnn_plan*)p, B, train); }
@@ -378,12 +431,20 @@ extern "C" {
 
 int64_t slnlp_tf_lockstep_workspace_bytes(const slnlp_tf_config* cfg, int K) {
     if (!cfg || K < 1 || K > LS_MAX_FITS) return -1;
-    // staging + pointer tables + argument / job tables of the cached programs.  A program has ~45 + 55 N call sites;
-    // a z-table entry is <= 256 B per fit, a grouped-GEMM job ~400 B with up to 4 jobs per fit and a block map of
-    // 4 B per workgroup (<= ~1200 per fit at E 1024): budget 24 KiB per call site and fit, for 8 programs.
+    // staging + pointer tables + argument / job tables of the cached programs (<= 8: train / eval x full / tail batch x
+    // data slots).  Per fit a program holds, for each of its ~45 + 55 N call sites, either a <= 256-byte argument pack, or
+    // -- the 8 N plane-GEMM sites -- up to 2 jobs and a block map of 4 B per workgroup (the dgrad's tiles plus the wgrad's
+    // tiles x split-K, jobs padded to multiples of 8 blocks), or -- ~16 N + 4 fp32-operand group sites -- up to 4 jobs and
+    // a block map over the decoder's B-row tiles.  x 1.5 for alignment (256 B per table) and slack.
     const size_t staging = (size_t)K * ((size_t)cfg->B * cfg->S + cfg->B + 64) * sizeof(int64_t);
-    const size_t sites = 45 + 55 * (size_t)cfg->N;
-    return (int64_t)(staging + 65536 + 8 * sites * (size_t)K * 24576);
+    const size_t N = (size_t)cfg->N, E = (size_t)cfg->E, F = (size_t)cfg->F, M = (size_t)cfg->B * cfg->S;
+    auto cd = [](size_t a, size_t b) { return (a + b - 1) / b; };
+    const size_t wide = 3 * E > F ? 3 * E : F, inner = E > F ? E : F;
+    const size_t plane_blocks = cd(M, 64) * cd(wide, 64) + cd(wide, 64) * cd(inner, 64) * MAX_SPLITK + 16;
+    const size_t brow = cd((size_t)cfg->B, 64) * cd(wide > (size_t)cfg->Vt ? wide : (size_t)cfg->Vt, 16) * (size_t)cfg->H;
+    const size_t per_fit = (45 + 55 * N) * 256 + 8 * N * (2 * sizeof(PlaneJob) + 4 * plane_blocks) +
+                           (16 * N + 4) * (4 * sizeof(GemmJob) + 4 * 4 * brow);
+    return (int64_t)(staging + 65536 + 8 * ((45 + 55 * N) * 512 + (size_t)K * per_fit * 3 / 2));
 }
 
 int slnlp_tf_lockstep_create(slnlp_tf_plan** plans, int K, void* workspace, int64_t workspace_bytes, void* stream,
@@ -428,6 +489,14 @@ int slnlp_tf_lockstep_epoch(slnlp_tf_lockstep* ls, int slot, int batch, int trai
     return ls_epoch(ls, slot, batch, train, momentum, max_norm, (hipStream_t)stream);
 }
 int slnlp_tf_lockstep_num_launches(slnlp_tf_lockstep* ls, int slot, int B, int train) { return ls_num_launches(ls, slot, B, train); }
+int slnlp_tf_lockstep_set_adam(slnlp_tf_lockstep* ls, float* const* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay) {
+    return ls_set_adam(ls, exp_avg_sq, beta1, beta2, eps, weight_decay);
+}
+int slnlp_tf_lockstep_set_destroy_sync(slnlp_tf_lockstep* ls, int on) {
+    SLNLP_CHECK_ARG(ls, "lockstep_set_destroy_sync: null group");
+    ls->destroy_sync = on ? 1 : 0;
+    return 0;
+}
 
 // ---- the same for K EncoderDecoder{LSTM,GRU}Attn fits (rnn_plan.hip); a slot also carries the sequence lengths
 int64_t slnlp_rnn_lockstep_workspace_bytes(const slnlp_rnn_config* cfg, int K) {
@@ -482,5 +551,13 @@ int slnlp_rnn_lockstep_epoch(slnlp_rnn_lockstep* ls, int slot, int batch, int tr
     return ls_epoch(ls, slot, batch, train, momentum, max_norm, (hipStream_t)stream);
 }
 int slnlp_rnn_lockstep_num_launches(slnlp_rnn_lockstep* ls, int slot, int B, int train) { return ls_num_launches(ls, slot, B, train); }
+int slnlp_rnn_lockstep_set_adam(slnlp_rnn_lockstep* ls, float* const* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay) {
+    return ls_set_adam(ls, exp_avg_sq, beta1, beta2, eps, weight_decay);
+}
+int slnlp_rnn_lockstep_set_destroy_sync(slnlp_rnn_lockstep* ls, int on) {
+    SLNLP_CHECK_ARG(ls, "rnn_lockstep_set_destroy_sync: null group");
+    ls->destroy_sync = on ? 1 : 0;
+    return 0;
+}
 
 }  // extern "C"

@@ -254,6 +254,7 @@ struct slnlp_rnn_plan {
     std::map<int, hipGraphExec_t> graphs;
     bool use_planes = false;  // E, Hd multiples of 64: the M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
     int planes_B = -1;        // batch size the activation planes' zero padding is valid for
+    int destroy_sync = 1;     // slnlp_rnn_set_destroy_sync: wait for the device before the plan goes away (launch.hpp)
     bool persistent = false;  // opt-in: all timesteps of an encoder layer in one launch (not yet faster; needs one fit per GPU)
     // lockstep (lockstep.hip): where lsm_nll also puts the batch's log-probs / loss (device row and batch index in ls_dyn)
     float* ls_logp = nullptr;
@@ -381,7 +382,8 @@ int64_t slnlp_rnn_workspace_bytes(const slnlp_rnn_config* cfg) {
 
 void slnlp_rnn_destroy(slnlp_rnn_plan* plan) {
     if (!plan) return;
-    destroy_sync();
+    if (!plan->graphs.empty()) (void)hipDeviceSynchronize();   // graph execs are torn down below
+    else destroy_sync(plan->destroy_sync);
     for (auto& kv : plan->graphs) (void)hipGraphExecDestroy(kv.second);
     delete plan;
 }
@@ -419,6 +421,8 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
     SLNLP_CHECK_ARG(pl && X && y && lengths, "rnn_forward: X, y and lengths are required");
     SLNLP_CHECK_ARG(B > 0 && B <= pl->cfg.B, "rnn_forward: batch %d outside 1..%d", B, pl->cfg.B);
     hipStream_t st = (hipStream_t)stream;
+    StepScope scope(st);
+    SLNLP_TRY(scope.rc);
     const slnlp_rnn_config& c = pl->cfg;
     const RWs& w = pl->w;
     const RLayout& L = pl->L;
@@ -571,6 +575,8 @@ int slnlp_rnn_seed_dlogp(slnlp_rnn_plan* pl, const float* dlogp, void* stream) {
 int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "rnn_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
+    StepScope scope(st);
+    SLNLP_TRY(scope.rc);
     const slnlp_rnn_config& c = pl->cfg;
     const RWs& w = pl->w;
     const RLayout& L = pl->L;
@@ -697,12 +703,35 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
 
 int slnlp_rnn_optim(slnlp_rnn_plan* pl, float momentum, float max_norm, void* stream) {
     SLNLP_CHECK_ARG(pl, "rnn_optim: null plan");
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
     return clip_sgd_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, pl->L.total, pl->buf.lr, momentum, max_norm,
                          pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, (hipStream_t)stream);
 }
 
+// clip_grad_norm_ + torch.optim.Adam on the arena (any torch optimizer is reachable in the reference through
+// pydoc.locate, /root/reference/helper.py:91-104): exp_avg = buf.momentum, exp_avg_sq = the caller's arena-shaped buffer,
+// step count = scalars[2] (advanced on the device) -- the same fused kernel as slnlp_tf_optim_adam.
+int slnlp_rnn_optim_adam(slnlp_rnn_plan* pl, float* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay,
+                         float max_norm, void* stream) {
+    SLNLP_CHECK_ARG(pl && exp_avg_sq, "rnn_optim_adam: null argument");
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
+    return clip_adam_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, exp_avg_sq, pl->L.total, pl->buf.lr, beta1, beta2, eps,
+                          weight_decay, max_norm, pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, pl->buf.scalars + 2,
+                          (hipStream_t)stream);
+}
+
+int slnlp_rnn_set_destroy_sync(slnlp_rnn_plan* pl, int on) {
+    SLNLP_CHECK_ARG(pl, "rnn_set_destroy_sync: null plan");
+    pl->destroy_sync = on ? 1 : 0;
+    return 0;
+}
+
 int slnlp_rnn_train_step(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, const int64_t* lengths, int B,
                          float momentum, float max_norm, float* logp, void* stream) {
+    StepScope scope((hipStream_t)stream);        // one scope for the whole step (the nested entry points re-enter it)
+    SLNLP_TRY(scope.rc);
     SLNLP_TRY(slnlp_rnn_forward(pl, X, y, lengths, B, 1, logp, stream));
     SLNLP_TRY(slnlp_rnn_backward(pl, stream));
     return slnlp_rnn_optim(pl, momentum, max_norm, stream);
@@ -749,6 +778,8 @@ int slnlp_rnn_graph_launch(slnlp_rnn_plan* pl, int B, void* stream) {
     SLNLP_CHECK_ARG(pl, "rnn_graph_launch: null plan");
     auto it = pl->graphs.find(B);
     SLNLP_CHECK_ARG(it != pl->graphs.end(), "rnn_graph_launch: no captured graph for batch %d", B);
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
     SLNLP_TRY(pl->prepare_planes(B, (hipStream_t)stream));
     if (hipGraphLaunch(it->second, (hipStream_t)stream) != hipSuccess) {
         set_error("rnn_graph_launch: %s", hipGetErrorString(hipGetLastError()));
@@ -787,11 +818,12 @@ int slnlp_rnn_tap(slnlp_rnn_plan* pl, const char* name, float* out, int64_t max_
 namespace slnlp {
 int rnn_ls_prepare(slnlp_rnn_plan* pl, int B, hipStream_t st) { return pl->prepare_planes(B, st); }
 int rnn_ls_record(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, const int64_t* len, int B, int train, float momentum,
-                  float max_norm, hipStream_t st) {
+                  float max_norm, const LsAdam* adam, float* exp_avg_sq, hipStream_t st) {
     SLNLP_CHECK_ARG(!pl->persistent, "lockstep: the persistent RNN layer kernel needs the GPU to itself -- switch it off");
     SLNLP_TRY(slnlp_rnn_forward(pl, X, y, len, B, train, nullptr, st));
     if (!train) return 0;
     SLNLP_TRY(slnlp_rnn_backward(pl, st));
+    if (adam) return slnlp_rnn_optim_adam(pl, exp_avg_sq, adam->beta1, adam->beta2, adam->eps, adam->weight_decay, max_norm, st);
     return slnlp_rnn_optim(pl, momentum, max_norm, st);
 }
 void rnn_ls_outputs(slnlp_rnn_plan* pl, float* logp, float* loss, const int* dyn) {

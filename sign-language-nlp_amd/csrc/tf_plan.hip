@@ -57,14 +57,9 @@ int64_t slnlp_tf_workspace_bytes(const slnlp_tf_config* cfg) {
 
 void slnlp_tf_destroy(slnlp_tf_plan* plan) {
     if (!plan) return;
-    if (!plan->graphs.empty() || plan->side_mode > 0) (void)hipDeviceSynchronize();   // graph execs / side streams are torn down below
-    else destroy_sync();                      // nothing of this plan may still be in flight when its buffers go
+    if (!plan->graphs.empty()) (void)hipDeviceSynchronize();   // graph execs are torn down below
+    else destroy_sync(plan->destroy_sync);    // nothing of this plan may still be in flight when its buffers go
     for (auto& kv : plan->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (int k = 0; k < NSIDE; ++k) {
-        if (plan->side[k]) (void)hipStreamDestroy(plan->side[k]);
-        if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
-    }
-    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     delete plan;
 }
 
@@ -84,13 +79,6 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     p->w = carve(*cfg, buf->workspace);
     bool ok = attn_init() == 0 && gemm_planes_init() == 0;
     p->use_planes = (cfg->E % 64 == 0) && (cfg->F % 64 == 0);
-    if (const char* e = getenv("SLNLP_TF_SIDE_STREAMS")) p->side_mode = atoi(e);
-    if (p->side_mode > 0) {      // side streams / events only exist for the experimental forked modes
-        for (int k = 0; ok && k < NSIDE; ++k)
-            ok = hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-    }
     if (ok && cfg->precision == 8) {     // rows the fp8 forward products read: one {offset, K} entry each, uploaded once
         std::vector<QuantRow> rows;
         auto block = [&](long off, int nrows, int K) {
@@ -160,8 +148,7 @@ int slnlp_tf_plan::dec_self_block(int l, const float* t, int B, float p, hipStre
     return 0;
 }
 
-int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
-                                bool defer_join) {
+int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st) {
     slnlp_tf_plan* pl = this;
     const slnlp_tf_config& c = pl->cfg;
     const int E = c.E, F = c.F, H = c.H, S = c.S, dh = E / H, M = S * B, Vp = (int)align_up(c.Vt, 4);
@@ -170,13 +157,10 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     pl->last_B = B; pl->last_p = p; pl->last_X = X; pl->last_y = y;
 
     // The target side up to the first cross-attention (embedding, layer 0's single-key self-attention block and its
-    // query projection: five B-row launches) depends on nothing the encoder computes: it runs on side[1] next to the
-    // encoder and is joined right before layer 0's cross-attention.
-    in_backward = false;
-    hipStream_t f1 = side_or(st, 1);
-    SLNLP_TRY(fork(st, 1));
-    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, f1));
-    SLNLP_TRY(dec_self_block(0, w.t0, B, p, f1));
+    // query projection: five B-row launches) depends on nothing the encoder computes; everything runs on the caller's
+    // ONE stream in program order (round 1 forked it to a side stream: -3 % and a data race).
+    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st));
+    SLNLP_TRY(dec_self_block(0, w.t0, B, p, st));
     const bool up = use_planes;
     if (up) {   // weights as bf16 planes: current unless the arena changed outside the fused optimizer step
         SLNLP_TRY(prepare_planes(B, st));
@@ -217,8 +201,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
-        if (l == 0) SLNLP_TRY(join(st, 1));                     // layer 0's block ran on side[1] (above)
-        else SLNLP_TRY(dec_self_block(l, t, B, p, st));
+        if (l > 0) SLNLP_TRY(dec_self_block(l, t, B, p, st));   // (layer 0's block ran ahead of the encoder, above)
         // cross-attention over the memory itself: with ONE query per sequence the K / V projections of the S memory rows
         // re-associate into B-row products (attention_mem.hip) -- no [S*B, 2E] projection, no K|V gradient GEMMs:
         // qk = Wk_h^T q_h (batched GEMM) -> scores / softmax / dropout / mbar (+ ctx0 = bv sum_s p_s) -> ctx = Wv_h mbar + ctx0
@@ -245,7 +228,6 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     SLNLP_TRY(lsm_nll(w.logits, Vp, y, B, c.Vt, c.pad_tgt, w.logp, pl->buf.scalars, train ? w.dlogits : nullptr, Vp,
                       w.row_nll, st, nullptr, logp_out ? logp_out : ls_logp, logp_out ? nullptr : ls_dyn,
                       logp_out ? nullptr : ls_loss, (!logp_out && ls_dyn) ? ls_dyn + 1 : nullptr));
-    (void)defer_join;
     return 0;
 }
 
@@ -255,7 +237,9 @@ int slnlp_tf_forward(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int 
                      void* stream) {
     SLNLP_CHECK_ARG(pl && X && y, "tf_forward: `X` and `y` are required parameters");  // transformer.py:61-62
     SLNLP_CHECK_ARG(B > 0 && B <= pl->cfg.B, "tf_forward: batch %d outside 1..%d", B, pl->cfg.B);
-    return pl->forward_impl(X, y, B, train, logp_out, (hipStream_t)stream, false);
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
+    return pl->forward_impl(X, y, B, train, logp_out, (hipStream_t)stream);
 }
 
 int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
@@ -266,8 +250,8 @@ int slnlp_tf_seed_dlogp(slnlp_tf_plan* pl, const float* dlogp, void* stream) {
 int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_CHECK_ARG(pl && pl->last_B > 0, "tf_backward: needs a prior forward(train)");
     hipStream_t st = (hipStream_t)stream;
-    pl->in_backward = true;
-    hipStream_t s1 = pl->side_or(st, 1);
+    StepScope scope(st);
+    SLNLP_TRY(scope.rc);
     const slnlp_tf_config& c = pl->cfg;
     const Ws& w = pl->w;
     const Layout& L = pl->L;
@@ -277,9 +261,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     const int64_t *X = pl->last_X, *y = pl->last_y;
     const bool up = pl->use_planes;
     int nb;
-    // Everything runs on the main stream; the weight gradient of each dY shares a launch with its data gradient.
-    // (side_mode > 0, experimental: layer 0's self-attention gradient tail and the target-embedding gradient may go to
-    // side[1]; the default runs every launch on the caller's stream -- tf_plan.hpp, side_mode.)
+    // Everything runs on the caller's stream; the weight gradient of each dY shares a launch with its data gradient.
 
     // generator: logits = tfin lin_w^T + lin_b
     SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b)),
@@ -321,13 +303,8 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         }
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gq, E, B, E, a.t1, E, pl->G(q.cin_w), pl->G(q.cin_b)),
                                  pl->dgrad_args(a.gq, E, B, E, pl->P(q.cin_w), E, a.gt1, nullptr, 0.f, a.gA2), st));
-        // norm1 / self-attention (single key).  For layer 0 nothing downstream on the main stream needs these (they end
-        // in weight gradients and the target-embedding gradient): they go to side[1] while the encoder backward starts.
+        // norm1 / self-attention (single key)
         hipStream_t sb = st;
-        if (l == 0) {
-            SLNLP_TRY(pl->fork(st, 1));
-            sb = s1;
-        }
         SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
                                 pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, sb));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
@@ -342,7 +319,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                  pl->dgrad_args(a.gv, E, B, E, pl->P(q.sin_w) + 2L * E * E, E, a.gt0, nullptr, 0.f, a.gA1), sb));
         dt = a.gt0;
     }
-    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, s1));
+    SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, st));
 
     // encoder: needs the complete d memory
     SLNLP_TRY(layernorm_bwd(w.gmem, w.enc[c.N - 1].x2, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.gxl, nullptr, 0.f, 0,
@@ -391,14 +368,14 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         dx = a.gx0;
     }
     SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st, w.emb_keep));
-    SLNLP_TRY(pl->join_all(st));
     SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
-    pl->in_backward = false;
     return 0;
 }
 
 int slnlp_tf_optim(slnlp_tf_plan* pl, float momentum, float max_norm, void* stream) {
     SLNLP_CHECK_ARG(pl, "tf_optim: null plan");
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
     SLNLP_TRY(clip_sgd_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, pl->L.total, pl->buf.lr, momentum, max_norm,
                             pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, (hipStream_t)stream,
                             pl->use_planes ? pl->w.wp.out() : PlaneOut{}));
@@ -411,10 +388,18 @@ int slnlp_tf_optim(slnlp_tf_plan* pl, float momentum, float max_norm, void* stre
 int slnlp_tf_optim_adam(slnlp_tf_plan* pl, float* exp_avg_sq, float beta1, float beta2, float eps, float weight_decay,
                         float max_norm, void* stream) {
     SLNLP_CHECK_ARG(pl && exp_avg_sq, "tf_optim_adam: null argument");
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
     SLNLP_TRY(clip_adam_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, exp_avg_sq, pl->L.total, pl->buf.lr, beta1, beta2, eps,
                              weight_decay, max_norm, pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, pl->buf.scalars + 2,
                              (hipStream_t)stream, pl->use_planes ? pl->w.wp.out() : PlaneOut{}));
     if (!recording()) pl->params_stepped();
+    return 0;
+}
+
+int slnlp_tf_set_destroy_sync(slnlp_tf_plan* pl, int on) {
+    SLNLP_CHECK_ARG(pl, "tf_set_destroy_sync: null plan");
+    pl->destroy_sync = on ? 1 : 0;
     return 0;
 }
 
@@ -428,6 +413,8 @@ int slnlp_tf_params_changed(slnlp_tf_plan* pl) {
 
 int slnlp_tf_train_step(slnlp_tf_plan* pl, const int64_t* X, const int64_t* y, int B, float momentum, float max_norm,
                         float* logp, void* stream) {
+    StepScope scope((hipStream_t)stream);        // one scope for the whole step (the nested entry points re-enter it)
+    SLNLP_TRY(scope.rc);
     SLNLP_TRY(slnlp_tf_forward(pl, X, y, B, 1, logp, stream));
     SLNLP_TRY(slnlp_tf_backward(pl, stream));
     return slnlp_tf_optim(pl, momentum, max_norm, stream);
@@ -479,6 +466,8 @@ int slnlp_tf_graph_launch(slnlp_tf_plan* pl, int B, void* stream) {
     SLNLP_CHECK_ARG(pl, "tf_graph_launch: null plan");
     auto it = pl->graphs.find(B);
     SLNLP_CHECK_ARG(it != pl->graphs.end(), "tf_graph_launch: no captured graph for batch %d", B);
+    StepScope scope((hipStream_t)stream);
+    SLNLP_TRY(scope.rc);
     SLNLP_TRY(pl->prepare_planes(B, (hipStream_t)stream));
     if (hipGraphLaunch(it->second, (hipStream_t)stream) != hipSuccess) {
         set_error("tf_graph_launch: %s", hipGetErrorString(hipGetLastError()));
@@ -519,7 +508,7 @@ int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_byt
     add("logp", w.logp); add("row_nll", w.row_nll); add("gfin", w.gfin); add("gtl", w.gtl); add("gmem", w.gmem); add("gxl", w.gxl);
     add("emb_scratch_src", w.emb_scratch_src); add("emb_scratch_tgt", w.emb_scratch_tgt); add("emb_keep", w.emb_keep);
     add("opt_partials", w.opt_partials); add("ln_table", w.ln_table); add("wp.hi", w.wp.hi); add("wp.lo", w.wp.lo);
-    add("planes_begin", w.planes_begin); add("gscr0", w.gscr[0]); add("gscr1", w.gscr[1]); add("planes_end", w.planes_end);
+    add("planes_begin", w.planes_begin); add("gscr0", w.gscr[0]); add("planes_end", w.planes_end);
     add("end", (const char*)nullptr + w.bytes);
     SLNLP_CHECK_ARG((int64_t)s.size() + 1 <= out_bytes, "tf_debug_layout: needs %zu bytes", s.size() + 1);
     memcpy(out, s.c_str(), s.size() + 1);

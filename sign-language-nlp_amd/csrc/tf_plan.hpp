@@ -107,6 +107,7 @@ static int check_cfg(const slnlp_tf_config* c) {
     const int dh = c->E / c->H;
     SLNLP_CHECK_ARG(c->E % 4 == 0 && c->E <= 1024, "tf: E=%d must be a multiple of 4 and <= 1024", c->E);
     SLNLP_CHECK_ARG(dh % 4 == 0 && dh <= 256 && (dh <= 64 || dh % 64 == 0), "tf: head_dim %d unsupported", dh);
+    SLNLP_CHECK_ARG(c->H <= 64, "tf: num_heads %d > 64 (per-head LDS tables of the cross-attention backward)", c->H);
     SLNLP_CHECK_ARG(c->F > 0 && c->F % 4 == 0, "tf: hidden_size %d must be a multiple of 4", c->F);
     SLNLP_CHECK_ARG(c->N > 0 && c->Vs > 1 && c->Vt > 1, "tf: bad N/vocab");
     SLNLP_CHECK_ARG(c->B > 0 && c->B <= 1024, "tf: batch %d outside 1..1024", c->B);
@@ -136,8 +137,7 @@ struct Bump {
 };
 
 // forward activations kept for backward + this layer's gradient buffers.  Every gradient buffer is
-// written exactly once per step, so work forked to a side stream (wgrads) can keep reading it while
-// the main stream moves on -- there is nothing to overwrite until the next step.
+// written exactly once per step: there is nothing to overwrite until the next step.
 // bf16 hi/lo planes of a GEMM operand (same logical shape / row stride as its fp32 twin, rows
 // zero-padded to a multiple of 64): written once by the producer, read by gemm_planes.hip
 struct PP {
@@ -171,7 +171,7 @@ struct Ws {
     char *planes_begin, *planes_end;    // activation planes region (re-zeroed when the batch size changes)
     float* opt_partials;
     float* attn_scratch;    // S > 64: dS of one self-attention backward ([B,H,S,S], shared by all layers)
-    char* gscr[2];          // split-K scratch of the grouped GEMM launches: [0] main stream, [1] side stream
+    char* gscr[1];          // split-K scratch of the grouped GEMM launches (one stream: one scratch)
     size_t gscr_bytes;
     slnlp_ln_reduce_entry* ln_table;
     size_t bytes;
@@ -307,7 +307,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         const size_t tx = ((E > F ? E : F) + 63) / 64, ty = ((3 * E > F ? 3 * E : F) + 63) / 64;
         w.gscr_bytes = 16384 + tx * ty * MAX_SPLITK * (512 * 8 * sizeof(float)) + ty * MAX_SPLITK * 64 * sizeof(float);
         w.gscr_bytes = (w.gscr_bytes + 255) & ~(size_t)255;
-        for (int i = 0; i < 2; ++i) w.gscr[i] = b.take<char>(w.gscr_bytes);
+        w.gscr[0] = b.take<char>(w.gscr_bytes);
     }
     b.cur = (b.cur + 255) & ~(size_t)255;
     w.planes_end = b.base + b.cur;
@@ -322,8 +322,6 @@ using namespace slnlp;   // internal header, included only by the plan translati
 // dropout site ids
 enum { SITE_SRC_EMB = 1, SITE_TGT_EMB = 2, SITE_LAYER0 = 16, SITE_PER_LAYER = 8 };
 
-constexpr int NSIDE = 2;
-
 struct slnlp_tf_plan {
     slnlp_tf_config cfg;
     slnlp_tf_buffers buf;
@@ -335,13 +333,7 @@ struct slnlp_tf_plan {
     const int64_t* last_y = nullptr;
     std::map<int, hipGraphExec_t> graphs;   // one captured train step per batch size, kept until destroy
     int nbE = 0, nbD = 0;  // LN-backward block counts of the FULL batch (fixed: the reduce table is static)
-    // Side streams: independent work (weight gradients, the memory K/V projections, embedding
-    // gradients, the scalar loss) is forked off the dependent chain with events and joined before the
-    // optimizer.  A single B=50 fit cannot fill 256 CUs with one kernel at a time; under stream
-    // capture the forks become parallel branches of the hipGraph.
-    hipStream_t side[NSIDE] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr};
-    bool side_dirty[NSIDE] = {false, false};
+    int destroy_sync = 1;  // slnlp_tf_set_destroy_sync: wait for the device before the plan goes away (launch.hpp)
     // Lockstep (lockstep.hip): where this fit's per-step outputs go while it advances as one of K fits -- an epoch-long
     // log-prob buffer and a per-batch loss history, indexed through two device scalars the driver updates per step
     float* ls_logp = nullptr;       // [rows of the epoch, Vt]
@@ -384,42 +376,6 @@ struct slnlp_tf_plan {
     float* G(long off) const { return buf.grads + off; }
     int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
     int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
-
-    // side[k] may start once everything enqueued on `main` so far has finished
-    // side_mode: which phases may fork work to the side streams: 0 = none -- every launch on the caller's stream (default),
-    // 1 = forward only, 2 = forward and backward (env SLNLP_TF_SIDE_STREAMS at plan creation; experiments only).
-    // Round 2 measurements at cfg2 (tools/probes/debug_race2.py): the serial step is as fast as the forked one (3.23 vs 3.21 ms;
-    // forward-only forks 3.35 ms) and it is the only fully deterministic one: with the backward forks 7 of 16 identical
-    // steps differed from the single-stream result (first wrong value: one row of decoder layer l's norm1 LayerNorm
-    // backward while the d-memory / K|V weight-gradient group of that layer ran on side[0]; gone under
-    // AMD_SERIALIZE_KERNEL=3, never seen at cfg1).  Its mechanism was not isolated -- the forks are off.
-    int side_mode = 0;
-    bool in_backward = false;
-    bool forks_on() const { return !recording() && side_mode > (in_backward ? 1 : 0); }
-    hipStream_t side_or(hipStream_t main, int k) const { return forks_on() ? side[k] : main; }
-    int fork(hipStream_t main, int k) {
-        if (!forks_on()) return 0;     // serial: a recorded program is one launch list in program order
-        if (hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side[k], ev_fork, 0) != hipSuccess) {
-            set_error("tf: fork to side stream failed: %s", hipGetErrorString(hipGetLastError()));
-            return SLNLP_ERR_LAUNCH;
-        }
-        side_dirty[k] = true;
-        return 0;
-    }
-    // `main` waits for everything enqueued on side[k]
-    int join(hipStream_t main, int k) {
-        if (recording() || !side_dirty[k]) return 0;   // (a disabled fork never marked the side stream dirty)
-        if (hipEventRecord(ev_join[k], side[k]) != hipSuccess || hipStreamWaitEvent(main, ev_join[k], 0) != hipSuccess) {
-            set_error("tf: join of side stream failed: %s", hipGetErrorString(hipGetLastError()));
-            return SLNLP_ERR_LAUNCH;
-        }
-        side_dirty[k] = false;
-        return 0;
-    }
-    int join_all(hipStream_t main) {
-        for (int k = 0; k < NSIDE; ++k) SLNLP_TRY(join(main, k));
-        return 0;
-    }
 
     int dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const;
 
@@ -593,7 +549,6 @@ struct slnlp_tf_plan {
         planes_B = B;
         return 0;
     }
-    int forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st,
-                     bool defer_join);
+    int forward_impl(const int64_t* X, const int64_t* y, int B, int train, float* logp_out, hipStream_t st);
 };
 

@@ -116,6 +116,8 @@ SIGNATURES = {
     "slnlp_rnn_seed_dlogp": (i32, [vp, vp, vp]),
     "slnlp_rnn_backward": (i32, [vp, vp]),
     "slnlp_rnn_optim": (i32, [vp, f32, f32, vp]),
+    "slnlp_rnn_optim_adam": (i32, [vp, vp, f32, f32, f32, f32, f32, vp]),
+    "slnlp_rnn_set_destroy_sync": (i32, [vp, i32]),
     "slnlp_rnn_train_step": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_rnn_graph_capture_train": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_rnn_graph_launch": (i32, [vp, i32, vp]),
@@ -140,7 +142,8 @@ SIGNATURES = {
     "slnlp_tf_params_changed": (i32, [vp]),
     "slnlp_tf_optim_adam": (i32, [vp, vp, f32, f32, f32, f32, f32, vp]),
     "slnlp_tf_debug_layout": (i32, [vp, C.c_char_p, i64]),
-    "slnlp_set_destroy_sync": (i32, [i32]),
+    "slnlp_tf_set_destroy_sync": (i32, [vp, i32]),
+    "slnlp_set_stream_policy": (i32, [i32]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),
     "slnlp_tf_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),
     "slnlp_tf_lockstep_destroy": (None, [vp]),
@@ -148,6 +151,8 @@ SIGNATURES = {
     "slnlp_tf_lockstep_step": (i32, [vp, i32, i64, i32, i32, i32, C.c_float, C.c_float, vp]),
     "slnlp_tf_lockstep_epoch": (i32, [vp, i32, i32, i32, C.c_float, C.c_float, vp]),
     "slnlp_tf_lockstep_num_launches": (i32, [vp, i32, i32, i32]),
+    "slnlp_tf_lockstep_set_adam": (i32, [vp, vp, f32, f32, f32, f32]),
+    "slnlp_tf_lockstep_set_destroy_sync": (i32, [vp, i32]),
     "slnlp_rnn_lockstep_workspace_bytes": (i64, [vp, i32]),
     "slnlp_rnn_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),
     "slnlp_rnn_lockstep_destroy": (None, [vp]),
@@ -155,6 +160,8 @@ SIGNATURES = {
     "slnlp_rnn_lockstep_step": (i32, [vp, i32, i64, i32, i32, i32, C.c_float, C.c_float, vp]),
     "slnlp_rnn_lockstep_epoch": (i32, [vp, i32, i32, i32, C.c_float, C.c_float, vp]),
     "slnlp_rnn_lockstep_num_launches": (i32, [vp, i32, i32, i32]),
+    "slnlp_rnn_lockstep_set_adam": (i32, [vp, vp, f32, f32, f32, f32]),
+    "slnlp_rnn_lockstep_set_destroy_sync": (i32, [vp, i32]),
 }
 
 _lib = None

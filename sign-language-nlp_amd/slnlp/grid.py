@@ -9,10 +9,12 @@ Here: one process per GPU (``torch.distributed``, RCCL on GPUs / gloo in CPU tes
 * rank 0 broadcasts the integer dataset ONCE (``X[N,S]``, ``lengths[N]``, ``y[N]``),
 * every rank derives the identical work list (``ParameterGrid`` x ``StratifiedKFold(cv)``, no shuffle), sorted
   by estimated cost, longest first,
-* **dynamic distribution**: every worker (``fits_per_gpu`` host threads per rank) pulls the index of its next
-  work unit from ONE shared counter -- ``store.add`` on the process group's rendezvous store across ranks, a
-  locked integer inside one process -- so a rank whose fits stop early (``EarlyStopping``) simply takes more
-  units; fit times need not be predictable.  ``schedule="static"`` keeps the round-robin deal ``i % world``,
+* **dynamic distribution with admission control** (``WorkCounter``): the ``world`` longest units are dealt one per rank;
+  after that a rank that falls idle pulls the index of its next work unit from ONE shared counter -- ``store.add`` on
+  the process group's rendezvous store across ranks, a locked integer inside one process -- so a rank whose fits stop
+  early (``EarlyStopping``) simply takes more units; the extra ``fits_per_gpu`` host threads of a busy rank prefetch a
+  unit only while plenty are left and the rank stays within its fair share of the estimated work.
+  ``schedule="static"`` keeps the round-robin deal ``i % world``,
 * one ``all_gather`` of the per-task score rows at the end; every rank computes ``mean_test_score`` /
   ``rank_test_score`` / ``best_index_`` identically and rank 0 refits the best candidate on the whole training
   set (``refit=True``).  The refit needs every score, so it cannot start before the last fit ends; it is one
@@ -25,8 +27,9 @@ A **work unit** is a list of tasks.  With ``lockstep=k`` tasks that share every 
 fold sizes) are packed k to a unit and handed to ``fit_and_score_group`` in one call, which advances them through ONE
 launch sequence (slnlp.lockstep); otherwise a unit is one task.
 
-A task that raises does not strand the other ranks in the collective: its row carries NaN and an error flag, the
-gather completes, and then EVERY rank raises.
+A task that raises does not strand the other ranks in the collective: its row carries NaN and an error flag, a shared
+abort flag stops every rank from pulling further units (the reference searches with ``error_score='raise'``), the gather
+completes, and then EVERY rank raises.
 """
 import itertools
 import threading
@@ -70,9 +73,10 @@ def build_tasks(param_grid, y, cv, seq_len=48, defaults=None):
 SHAPE_KEYS_EXCLUDED = ("lr", "module__dropout")
 
 
-def estimate_fit_bytes(params, seq_len, defaults=None):
-    """Device bytes one resident fit of this candidate needs (plan workspace + parameter / gradient / momentum arenas), asked
-    from the library's host-side size queries; None when the module is not one of this package's."""
+def estimate_fit_bytes(params, seq_len, defaults=None, lockstep=1):
+    """Device bytes one resident fit of this candidate needs (plan workspace + parameter / gradient / momentum arenas + its
+    share of a ``lockstep``-wide group's table workspace), asked from the library's host-side size queries; None when the
+    module is not one of this package's."""
     d = dict(defaults or {})
     d.update(params)
     try:
@@ -86,10 +90,14 @@ def estimate_fit_bytes(params, seq_len, defaults=None):
             from . import tf_engine as te
             cfg = te.make_config(E, int(d["module__num_heads"]), N, F, Vs, Vt, B, int(seq_len), 1, 1, 0.1, 3)
             ws, arena = int(load().slnlp_tf_workspace_bytes(C.byref(cfg))), te.layout(cfg)[1]
+            if lockstep > 1:
+                ws += int(load().slnlp_tf_lockstep_workspace_bytes(C.byref(cfg), int(lockstep))) // int(lockstep)
         elif name.startswith("EncoderDecoder"):
             from . import rnn_engine as re_
             cfg = re_.make_config("lstm" if "LSTM" in name else "gru", E, F, N, Vs, Vt, B, int(seq_len), 1, 1, 0, 0.1, 3)
             ws, arena = int(load().slnlp_rnn_workspace_bytes(C.byref(cfg))), re_.layout(cfg)[1]
+            if lockstep > 1:
+                ws += int(load().slnlp_rnn_lockstep_workspace_bytes(C.byref(cfg), int(lockstep))) // int(lockstep)
         else:
             return None
         return ws + 3 * 4 * int(arena) if ws > 0 else None
@@ -169,26 +177,125 @@ def broadcast_dataset(ds, device="cpu", src=0, force=False):
 
 
 class WorkCounter:
-    """next() -> 0, 1, 2, ... handed out exactly once across every worker thread of every rank."""
+    """Hands out the unit indices 0 .. n_units-1, each exactly once across every worker thread of every rank.
 
-    def __init__(self, key, static=False):
+    ``schedule="dynamic"`` with **admission control** (the reference gives each GPU exactly ONE dask worker, and dask hands a
+    worker its next task when it falls idle -- /root/reference/helper.py:503-519, main.py:70-78; a rank here has
+    ``fits_per_gpu`` host threads whose units all serialise on the rank's one stream, so a unit taken early by an extra
+    thread is a unit another, idle GPU cannot run):
+
+    * the first ``world`` units -- the longest: the list is sorted longest first -- are dealt one per rank (unit r to rank r);
+    * after that a rank with nothing in flight always gets the next unit from the shared counter (``store.add`` on the process
+      group's rendezvous store; a locked integer inside one process);
+    * a rank that already runs k units gets another one only while more than ``world * k`` units are left (every other rank
+      can still be given as many) AND the unit would keep the rank's estimated load -- the sum of ``unit_costs`` of what it
+      has taken -- within its fair share ``sum(unit_costs) / world``: prefetching for the host threads never takes what the
+      longest-first deal would give to a less loaded rank.  Otherwise its extra threads wait; they leave when the list is
+      exhausted.
+
+    ``abort()`` (first failed unit, any rank) makes every later ``acquire`` on every rank return None, so a broken grid stops
+    at once instead of burning through the remaining units (the reference searches with ``error_score='raise'``,
+    helper.py:162,193).  ``static``: the round-robin deal ``i % world`` without a counter.
+    """
+
+    POLL_S = 0.01
+
+    def __init__(self, key, n_units, static=False, unit_costs=None):
         dist, self.rank, self.world = _dist()
         self._lock, self._n, self._store, self._key = threading.Lock(), 0, None, key
-        self.static = static
-        if self.world > 1 and not static:
+        self.n_units, self.static = int(n_units), static
+        self._costs = [float(c) for c in unit_costs] if unit_costs is not None else [1.0] * self.n_units
+        self._fair, self._load = sum(self._costs) / max(1, self.world), 0.0
+        self._in_flight, self._dealt, self._aborted = 0, False, False
+        if self.world > 1:
             try:
                 from torch.distributed.distributed_c10d import _get_default_store
                 self._store = _get_default_store()
             except Exception:                      # no rendezvous store reachable: fall back to the static deal
                 self.static = True
 
-    def next(self):
-        if self._store is not None:
-            return int(self._store.add(self._key, 1)) - 1
+    # ---- shared state: units handed out beyond the initial deal, and the abort flag
+    def _taken(self, inc):
+        if self._store is not None and not self.static:
+            return int(self._store.add(self._key, inc))
         with self._lock:
-            i = self._n
-            self._n += 1
-        return i * self.world + self.rank if self.world > 1 else i        # static deal: i-th unit of this rank
+            self._n += inc
+            return self._n
+
+    def aborted(self):
+        if not self._aborted and self._store is not None:
+            self._aborted = int(self._store.add(self._key + "/abort", 0)) > 0
+        return self._aborted
+
+    def abort(self):
+        self._aborted = True
+        if self._store is not None:
+            self._store.add(self._key + "/abort", 1)
+
+    def release(self):
+        with self._lock:
+            self._in_flight -= 1
+
+    def acquire(self):
+        """Index of this thread's next unit, or None when there is nothing (more) to run.  Pair with release()."""
+        if self.static:
+            if self.aborted():
+                return None
+            with self._lock:
+                i = self._n
+                self._n += 1
+                self._in_flight += 1
+            i = i * self.world + self.rank
+            if i >= self.n_units:
+                self.release()
+                return None
+            return i
+        while True:
+            i = self.try_acquire()
+            if i is not WorkCounter.WAIT:
+                return i
+            time.sleep(self.POLL_S)
+
+    WAIT = object()
+
+    def try_acquire(self):
+        """One admission decision: a unit index, None (nothing more to run) or WAIT (ask again later)."""
+        dealt = min(self.world, self.n_units)       # units 0 .. dealt-1: one per rank
+        while True:
+            if self.aborted():
+                return None
+            with self._lock:
+                if not self._dealt:
+                    self._dealt = True
+                    if self.rank < dealt:
+                        self._in_flight += 1
+                        self._load += self._costs[self.rank]
+                        return self.rank
+                k = self._in_flight
+                if k == 0:
+                    self._in_flight += 1            # reserve: an idle rank always pulls
+            if k == 0:
+                return self._pull(dealt)
+            nxt = dealt + self._taken(0)            # the unit the counter would hand out now
+            left = self.n_units - nxt
+            if left <= 0:
+                return None
+            if left > self.world * k and self._load + self._costs[nxt] <= self._fair * (1 + 1e-9):
+                with self._lock:
+                    if self._in_flight != k:
+                        continue                    # another thread of this rank moved meanwhile: look again
+                    self._in_flight += 1
+                return self._pull(dealt)
+            return WorkCounter.WAIT
+
+    def _pull(self, dealt):                         # (the caller has reserved the in-flight slot)
+        i = dealt + self._taken(1) - 1
+        if i >= self.n_units:
+            self.release()
+            return None
+        with self._lock:
+            self._load += self._costs[i]
+        return i
 
 
 def default_fit_and_score(estimator_factory, params, train, test, scoring="neg_log_loss", seed=None, concurrent=False):
@@ -262,7 +369,8 @@ class ShardedGridSearchCV:
         import torch
         dist, rank, world = _dist()
         ds = broadcast_dataset(dataset, self.device, force=self.force_collectives)
-        cands, folds, tasks, order = build_tasks(self.param_grid, ds.y, self.cv, ds.ids.shape[1], self._defaults())
+        self._defaults_cache = self._defaults()
+        cands, folds, tasks, order = build_tasks(self.param_grid, ds.y, self.cv, ds.ids.shape[1], self._defaults_cache)
         group_fn = self.fit_and_score_group
         if self.lockstep > 1 and group_fn is None:
             from .lockstep import fit_and_score_group as group_fn
@@ -275,15 +383,21 @@ class ShardedGridSearchCV:
 
             def cap(ci):
                 if ci not in per:
-                    b = estimate_fit_bytes(cands[ci], S, defaults)
+                    b = estimate_fit_bytes(cands[ci], S, defaults, min(self.lockstep, 64))
                     per[ci] = self.lockstep if not b else int(budget // (max(1, self.fits_per_gpu) * b))
                 return per[ci]
         units = build_units(cands, folds, tasks, order, self.lockstep if group_fn else 1, cap)
         call = next(_FIT_CALLS)
-        counter = WorkCounter(f"slnlp/grid/{call}/next", static=self.schedule == "static")
+        task_cost = lambda t: estimate_cost(cands[tasks[t][0]], ds.ids.shape[1], len(folds[tasks[t][1]][0]), self._defaults_cache)
+        counter = WorkCounter(f"slnlp/grid/{call}/next", len(units), static=self.schedule == "static",
+                              unit_costs=[sum(task_cost(t) for t in u) for u in units])
         rows = torch.full((len(tasks), 3), float("nan"), dtype=torch.float64)      # score, seconds, error flag
         rows[:, 2] = 0.0
         mine, errors = [], []
+        if dist is not None and world > 1:
+            # ranks reach this point at different times (imports, the first fold split): start the clock -- and the race for
+            # the dynamically scheduled units -- together, so rank_seconds_ are comparable across ranks
+            dist.all_reduce(torch.zeros(1, device=comm_device(self.device)))
         t_start = time.time()
         sig = inspect.signature(self.fit_and_score).parameters
         takes_seed, takes_conc = "seed" in sig, "concurrent" in sig
@@ -316,6 +430,7 @@ class ShardedGridSearchCV:
                     rows[t, 0], rows[t, 1], rows[t, 2] = float("nan"), time.time() - t0, 1.0
                 with lock:
                     errors.append((unit, e, traceback.format_exc()))
+                counter.abort()                                     # every rank stops pulling units (error_score='raise')
             if self.verbose:
                 for t in unit:
                     print(f"[rank {rank}] task {t} cand {tasks[t][0]} fold {tasks[t][1]}: score {float(rows[t, 0]):.4f} "
@@ -323,12 +438,15 @@ class ShardedGridSearchCV:
 
         def worker():
             while True:
-                i = counter.next()
-                if i >= len(units):
+                i = counter.acquire()
+                if i is None:
                     return
                 with lock:
                     mine.extend(units[i])
-                run_unit(units[i])
+                try:
+                    run_unit(units[i])
+                finally:
+                    counter.release()
 
         if self.fits_per_gpu > 1:
             threads = [threading.Thread(target=worker) for _ in range(self.fits_per_gpu)]

@@ -45,6 +45,7 @@ class LockstepGroup:
         out = C.c_void_p()
         check(self._fn("create")(handles, self.K, ptr(self.workspace), nbytes, self._sp(), C.byref(out)), f"{self.kind}_lockstep_create")
         self.handle = out
+        check(self._fn("set_destroy_sync")(out, 0), "lockstep_set_destroy_sync")   # torch-allocated tables: see tf_engine.py
         self.data, self.logp, self.loss, self.rows = {}, {}, {}, {}
 
     def _fn(self, name):                                 # a method, not a closure over self: no reference cycle
@@ -86,6 +87,12 @@ class LockstepGroup:
             check(self._fn("set_data")(self.handle, slot, _ptr_array(Xs), _ptr_array(ys), rows,
                                        _ptr_array(self.logp[slot]), _ptr_array(self.loss[slot]), self._sp()), "tf_lockstep_set_data")
 
+    def set_adam(self, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """Train with the fused clip + Adam update from now on; ``exp_avg_sq``: one arena-shaped buffer per fit."""
+        assert len(exp_avg_sq) == self.K
+        self._v2 = list(exp_avg_sq)                      # keep the tensors alive: the C side holds raw pointers
+        check(self._fn("set_adam")(self.handle, _ptr_array(self._v2), betas[0], betas[1], eps, weight_decay), f"{self.kind}_lockstep_set_adam")
+
     def _sync_versions(self):
         for e in self.engines:                           # Transformer: weight planes follow outside writes to the fp32 arena
             if hasattr(e, "sync_params_version"):
@@ -119,8 +126,15 @@ LOCKSTEP_MODULES = ("Transformer", "EncoderDecoderLSTMAttn", "EncoderDecoderGRUA
 
 
 def lockstep_supported(net):
-    """Fused SGD + CrossEntropyLoss on one of the path's three modules: what the lockstep launch sequences implement."""
-    return getattr(net, "_fused_kind", None) == "sgd" and type(net.module_).__name__ in LOCKSTEP_MODULES
+    """A fused update (SGD-momentum or Adam) + CrossEntropyLoss on one of the path's three modules: what the lockstep launch
+    sequences implement."""
+    return getattr(net, "_fused_kind", None) in ("sgd", "adam") and type(net.module_).__name__ in LOCKSTEP_MODULES
+
+
+def _adam_key(net):
+    ok = net._opt_kwargs
+    return (net._fused_kind,) + ((tuple(ok.get("betas", (0.9, 0.999))), float(ok.get("eps", 1e-8)), float(ok.get("weight_decay", 0.0)))
+                                 if net._fused_kind == "adam" else ())
 
 
 def fit_lockstep(nets, datasets):
@@ -135,8 +149,10 @@ def fit_lockstep(nets, datasets):
     with torch.cuda.stream(stream):
         runs = [_FitRun(n, d) for n, d in zip(nets, datasets)]
     r0 = runs[0]
-    assert all(lockstep_supported(n) for n in nets), "lockstep: fused SGD + CrossEntropyLoss on the model.* modules only"
+    assert all(lockstep_supported(n) for n in nets), "lockstep: fused SGD / Adam + CrossEntropyLoss on the model.* modules only"
     assert len({type(n.module_) for n in nets}) == 1, "lockstep: one module class per group"
+    assert len({_adam_key(n) for n in nets}) == 1, "lockstep: one optimizer (and one set of Adam constants) per group"
+    adam = _adam_key(nets[0]) if nets[0]._fused_kind == "adam" else None
     assert all((r.bs, r.momentum, r.max_norm, len(r.tr), (len(r.va) if r.va is not None else 0)) ==
                (r0.bs, r0.momentum, r0.max_norm, len(r0.tr), (len(r0.va) if r0.va is not None else 0)) for r in runs), \
         "lockstep: the fits of a group share batch size, momentum, clipping and split sizes"
@@ -152,6 +168,8 @@ def fit_lockstep(nets, datasets):
                     stream_sync(stream)
                     group.close()
                 group = LockstepGroup([engines[i] for i in active])
+                if adam is not None:
+                    group.set_adam([nets[i].module_.adam_second_moment() for i in active], adam[1], adam[2], adam[3])
                 group.set_data(TRAIN, [runs[i].Xtr for i in active], [runs[i].ytr for i in active], r0.bs,
                                [runs[i].Ltr for i in active])
                 if r0.va is not None:
@@ -218,7 +236,7 @@ def fit_and_score_group(estimator_factory, params_list, trains, tests, scoring="
                 torch.manual_seed(seed)
             net.initialize()
         nets.append(net)
-    if not all(lockstep_supported(n) for n in nets) or len({type(n.module_) for n in nets}) != 1 or \
+    if not all(lockstep_supported(n) for n in nets) or len({type(n.module_) for n in nets}) != 1 or len({_adam_key(n) for n in nets}) != 1 or \
             len({len(t) for t in trains}) != 1 or len({len(t) for t in tests}) != 1:
         del nets
         # concurrent=True: no hipGraph capture -- other host threads may be launching on the device's shared stream

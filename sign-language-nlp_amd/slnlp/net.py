@@ -61,10 +61,6 @@ def device_stream(dev):
         st = _DEVICE_STREAMS.get(dev.index)
         if st is None:
             st = _DEVICE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-            # every buffer of an estimator's plans is a torch tensor allocated and used on this stream, so a plan that goes away
-            # needs no device-wide wait (which would stall the other host threads' queued work each time a fit ends)
-            from ._lib import load
-            load().slnlp_set_destroy_sync(0)
         return st
 
 
@@ -342,8 +338,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         if ce and self._opt_cls is torch.optim.SGD and not ok.get("nesterov", False) and not ok.get("weight_decay", 0) \
                 and not ok.get("dampening", 0) and not ok.get("maximize", False):
             self._fused_kind = "sgd"
-        elif ce and self._opt_cls is torch.optim.Adam and not ok.get("amsgrad", False) and not ok.get("maximize", False) \
-                and type(self.module_).__name__ == "Transformer":
+        elif ce and self._opt_cls is torch.optim.Adam and not ok.get("amsgrad", False) and not ok.get("maximize", False):
             self._fused_kind = "adam"
         self._fused = self._fused_kind is not None
         if not self._fused:
@@ -428,7 +423,7 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
                 if self._fused_kind == "adam":
                     ok = self._opt_kwargs
                     logp = eng.train_step_adam(xb, yb, self.module_.adam_second_moment(), tuple(ok.get("betas", (0.9, 0.999))),
-                                               float(ok.get("eps", 1e-8)), float(ok.get("weight_decay", 0.0)), max_norm)
+                                               float(ok.get("eps", 1e-8)), float(ok.get("weight_decay", 0.0)), max_norm, lengths=lb)
                 else:
                     logp = eng.step(xb, yb, lb, momentum, max_norm, graph=self.use_graph if self.use_graph == "auto" else bool(self.use_graph))
                 losses.append(eng.scalars[0].clone())

@@ -54,6 +54,7 @@ class RnnEngine:
         handle = C.c_void_p()
         check(load().slnlp_rnn_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "rnn_create")
         self.handle = handle
+        check(load().slnlp_rnn_set_destroy_sync(handle, 0), "rnn_set_destroy_sync")   # torch-allocated buffers: see tf_engine.py
         self._graph_keys = {}
         self._launch = LaunchPolicy()
         self._xbuf = self._ybuf = self._lbuf = None
@@ -110,6 +111,18 @@ class RnnEngine:
 
     def optim(self, momentum=0.9, max_norm=0.5):
         check(load().slnlp_rnn_optim(self.handle, momentum, max_norm, self._sp()), "rnn_optim")
+
+    def optim_adam(self, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
+        """clip_grad_norm_ + torch.optim.Adam fused (exp_avg = the momentum arena, step count in ``scalars[2]``), as
+        TransformerEngine.optim_adam."""
+        check(load().slnlp_rnn_optim_adam(self.handle, ptr(exp_avg_sq), betas[0], betas[1], eps, weight_decay, max_norm, self._sp()),
+              "rnn_optim_adam")
+
+    def train_step_adam(self, X, y, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5, lengths=None):
+        logp = self.forward(X, y, lengths, train=True)
+        self.backward()
+        self.optim_adam(exp_avg_sq, betas, eps, weight_decay, max_norm)
+        return logp
 
     def train_step(self, X, y, lengths, momentum=0.9, max_norm=0.5):
         B = X.shape[0]

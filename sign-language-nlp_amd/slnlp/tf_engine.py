@@ -78,6 +78,10 @@ class TransformerEngine:
         handle = C.c_void_p()
         check(load().slnlp_tf_create(C.byref(cfg), C.byref(bufs), C.byref(handle)), "tf_create")
         self.handle = handle
+        # every buffer of this plan is a torch tensor from the stream-ordered caching allocator, and __del__ waits for the
+        # plan's last stream when that is not the allocating one: the plan itself needs no device-wide wait when it goes
+        # away (which would stall the other host threads' queued work each time a fit ends).  Per plan, not process-wide.
+        check(load().slnlp_tf_set_destroy_sync(handle, 0), "tf_set_destroy_sync")
         self._graph_keys = {}
         self._launch = LaunchPolicy()
         self._xbuf = self._ybuf = None
@@ -159,8 +163,8 @@ class TransformerEngine:
         check(load().slnlp_tf_optim_adam(self.handle, ptr(exp_avg_sq), betas[0], betas[1], eps, weight_decay, max_norm, self._sp()),
               "tf_optim_adam")
 
-    def train_step_adam(self, X, y, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5):
-        logp = self.forward(X, y, train=True)
+    def train_step_adam(self, X, y, exp_avg_sq, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.5, lengths=None):
+        logp = self.forward(X, y, train=True)            # (lengths: unused by the Transformer, transformer.py:60)
         self.backward()
         self.optim_adam(exp_avg_sq, betas, eps, weight_decay, max_norm)
         return logp

@@ -68,6 +68,31 @@ def _run_skewed(rank, world, port, out, schedule):
     dist.destroy_process_group()
 
 
+ADMIT_GRID = {"lr": [0.1, 0.01], "module__embedding_size": [64, 16]}     # x cv 2 = 8 units: 4 long (E 64) sort first, 4 short
+_ONE_STREAM = __import__("threading").Lock()                              # a rank's units serialise on its one stream
+
+
+def one_stream_fit_and_score(factory, params, train, test, scoring):
+    """A fit whose device work (the sleep) is serialised per process, like the kernels of a rank's fits_per_gpu host threads
+    on the rank's single stream: a unit taken early by an extra thread only queues up behind the rank's first one."""
+    import time
+    with _ONE_STREAM:
+        time.sleep(0.40 if params["module__embedding_size"] == 64 else 0.05)
+    return -float(params["lr"]) * params["module__embedding_size"] - 0.001 * len(test)
+
+
+def _run_admission(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3) if rank == 0 else None
+    gs = grid.ShardedGridSearchCV(lambda: None, ADMIT_GRID, cv=2, fit_and_score=one_stream_fit_and_score, refit=False, fits_per_gpu=3)
+    gs.fit(ds)
+    out[rank] = (gs.cv_results_["mean_test_score"].tolist(), gs.rank_seconds_, gs.rank_tasks_, sorted(gs.tasks_of_rank_), gs.best_index_)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def failing_fit_and_score(factory, params, train, test, scoring):
     if params["lr"] == 0.01 and params["module__embedding_size"] == 32 and params["module__num_layers"] == 2:
         raise ValueError("boom")
@@ -140,6 +165,84 @@ def test_dynamic_schedule_balances_skewed_fit_times():
     assert out[0][1] == out[1][1] and sum(ntasks) == single.n_tasks_       # every rank knows every rank's time
     assert max(secs) / (sum(secs) / len(secs)) <= 1.15, secs
     assert sorted(out[0][3] + out[1][3]) == list(range(single.n_tasks_))
+
+
+def test_admission_control_deals_long_units_one_per_rank_with_host_threads():
+    """world 4 x fits_per_gpu 3 x 8 skewed units: without admission control the 12 host threads race for the
+    8 units and one rank can take three of the four long ones, which then serialise on its stream.  With it every rank gets
+    exactly one long unit, the short ones are pulled as ranks fall idle, and the ranks finish together."""
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    single = grid.ShardedGridSearchCV(lambda: None, ADMIT_GRID, cv=2, fit_and_score=one_stream_fit_and_score, refit=False).fit(ds)
+    cands, folds, tasks, order = grid.build_tasks(ADMIT_GRID, ds.y, 2)
+    long_tasks = {t for t in range(len(tasks)) if cands[tasks[t][0]]["module__embedding_size"] == 64}
+    assert set(order[:4]) == long_tasks                                   # longest first
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_admission, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    owned = []
+    for r in range(world):
+        mean, secs, ntasks, mine, best = out[r]
+        assert np.allclose(mean, single.cv_results_["mean_test_score"], rtol=0, atol=1e-12) and best == single.best_index_
+        assert len(long_tasks & set(mine)) == 1, (r, mine)                # one long unit per rank
+        owned += mine
+    assert sorted(owned) == list(range(len(tasks)))
+    secs = out[0][1]
+    assert max(secs) / (sum(secs) / len(secs)) <= 1.15, secs
+    assert max(secs) < 0.40 + 2 * 0.05 + 0.35, secs                       # nobody ran two long units back to back
+
+
+def test_work_counter_admission_single_process():
+    """The same rule inside one process (world 1): an idle rank always pulls, a busy one only while units are left over."""
+    c = grid.WorkCounter("k", 4)
+    assert c.acquire() == 0                       # the deal
+    assert c.acquire() == 1                       # one unit in flight, 3 left > 1 x 1
+    c.release()                                   # (with two in flight the 2 units left would make a third thread wait)
+    assert c.acquire() == 2                       # 2 left > 1 x 1
+    c.release(); c.release()
+    assert c.acquire() == 3 and c.acquire() is None
+    c = grid.WorkCounter("k2", 3)
+    assert c.acquire() == 0
+    c.abort()
+    assert c.acquire() is None
+
+
+def test_admission_prefetch_stays_within_the_fair_share_of_estimated_work(monkeypatch):
+    """8 ranks, 32 units of estimated cost 2 / 1 / .15 / .08 (8 each, longest first -- the shape of bench.py's grid sample):
+    a rank's extra host threads may take ONE medium unit next to the dealt long one (3.0 <= the fair share 3.23) but not a
+    second one, whatever the number of units still left."""
+    class Store(dict):
+        def add(self, k, v):
+            self[k] = self.get(k, 0) + v
+            return self[k]
+    store = Store()
+    costs = [2.0] * 8 + [1.0] * 8 + [0.15] * 8 + [0.08] * 8
+    counters = []
+    for r in range(8):
+        monkeypatch.setattr(grid, "_dist", lambda r=r: (None, r, 8))
+        c = grid.WorkCounter("k", 32, unit_costs=costs)
+        c._store, c.static = store, False      # (no process group here: the constructor fell back to the static deal)
+        counters.append(c)
+    assert [c.try_acquire() for c in counters] == list(range(8))              # the deal: one long unit per rank
+    assert counters[0].try_acquire() == 8                                       # prefetch: 2 + 1 <= 25.84 / 8
+    assert counters[0].try_acquire() is grid.WorkCounter.WAIT                   # a third unit would exceed the share
+    assert [c.try_acquire() for c in counters[1:]] == list(range(9, 16))
+    assert all(c.try_acquire() is grid.WorkCounter.WAIT for c in counters)      # 16 left, but not > 8 x 2 in flight
+    counters[3].release(); counters[3].release()                                # rank 3 falls idle: it always pulls
+    assert counters[3].try_acquire() == 16
+
+
+def test_bench_grid_sample_has_four_units_per_gpu_at_eight_gpus():
+    """bench.py's strong-scaling sample: 480 fits -> 32 lockstep-15 units in four cost classes of 8, longest first, so the
+    admission rule above gives each of 8 GPUs one unit of every class."""
+    import bench
+    ds = synthetic_dataset(bench.GRID_SAMPLES, seq_len=48, src_vocab=300, n_labels=200, seed=1, min_len=8)
+    cands, folds, tasks, order = grid.build_tasks(bench.GRID_SAMPLE, ds.y, bench.GRID_CV, 48, {"max_epochs": bench.GRID_EPOCHS})
+    units = grid.build_units(cands, folds, tasks, order, 15)
+    assert len(cands) == 96 and len(tasks) == 480 and len(units) == 32 and all(len(u) == 15 for u in units)
+    shape = lambda u: (cands[tasks[u[0]][0]]["module__embedding_size"], cands[tasks[u[0]][0]]["module__num_layers"])
+    assert [shape(u) for u in units] == [(512, 4)] * 8 + [(512, 2)] * 8 + [(128, 4)] * 8 + [(128, 2)] * 8
 
 
 def test_failing_task_raises_on_every_rank_instead_of_hanging():
