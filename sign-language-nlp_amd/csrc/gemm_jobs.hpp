@@ -38,8 +38,9 @@ struct PlaneJob {
     int variant;        // 0: A,B k-major   1: A k-major, B m-major   2: A,B m-major
     int tiles_x, tiles_y, nks, block_begin;
     int vec_out;        // epilogue may use 16-byte row pieces (N % 4 == 0, aligned C / residual / planes)
-    float* part;        // [tile][nks][PTHREADS * 8]
-    float* part_rs;     // [tile_y][nks][PT]     (row sums of A)
+    int hand_off;       // split-K meeting point: 0 = sc1 accesses only; probes (SLNLP_SPLITK_MODE): 2 = + reader acquire, 3 = + writer release
+    float* part;        // [tile][nks][TILE x TILE]   (accumulator layout)
+    float* part_rs;     // [tile_y][nks][TILE]        (row sums of A)
     int* counters;      // [tiles], zero outside a launch
 };
 constexpr int MAX_JOBS = 4;
@@ -60,7 +61,12 @@ __device__ __forceinline__ void launder(slnlp_gemm_args& a) {
 
 // kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)
 const void* gemm_group_kernel_ptr(int precision, int ks = 1);
-const void* gemm_planes_kernel_ptr(int precision);
-size_t gemm_planes_lds_bytes();
+const void* gemm_planes_kernel_ptr(int precision, int tile);
+int plane_tile_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs);   // 64 or 128: the tile a launch of these jobs takes
+void plane_job_retile(PlaneJob& j, int tile);
+size_t plane_lds_bytes(int tile);
+int plane_kernel_precision(const void* fn);
+int plane_tile_forced();
+int plane_big_tile_min_units();
 
 }  // namespace slnlp

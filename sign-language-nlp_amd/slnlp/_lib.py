@@ -144,6 +144,7 @@ SIGNATURES = {
     "slnlp_tf_debug_layout": (i32, [vp, C.c_char_p, i64]),
     "slnlp_tf_set_destroy_sync": (i32, [vp, i32]),
     "slnlp_set_stream_policy": (i32, [i32]),
+    "slnlp_set_plane_tile": (i32, [i32]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),
     "slnlp_tf_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),
     "slnlp_tf_lockstep_destroy": (None, [vp]),

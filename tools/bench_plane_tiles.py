@@ -1,0 +1,69 @@
+"""Plane-GEMM launches at the 64 x 64 and the 128 x 128 tile (slnlp_set_plane_tile): device time per launch, algorithmic
+TFLOP/s, and that both tiles return the same bits (same K partition => same accumulation order).
+
+    python tools/bench_plane_tiles.py [quick]
+"""
+import sys, torch
+sys.path.insert(0, "sign-language-nlp_amd")
+from slnlp import ops
+from slnlp._lib import load, check
+
+def timeit(fn, n=100, warm=10):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+def case(name, Mtok, Nout, Kin, split, copies=1, check_ref=False):
+    """dgrad + wgrad of `copies` independent dY [Mtok, Nout] against W [Nout, Kin] / X [Mtok, Kin] in ONE launch (<= 4 jobs)."""
+    g = torch.Generator().manual_seed(0)
+    jobs, splits, outs, refs = [], [], [], []
+    for c in range(copies):
+        dY, X, W = [torch.randn(*s, generator=g).cuda() for s in ((Mtok, Nout), (Mtok, Kin), (Nout, Kin))]
+        dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+        rs = torch.empty(Nout, device="cuda")
+        jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
+        jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+        jobs += [jw, jd]; splits += [split, 1]; outs += [dW, rs, dX]
+        if check_ref and c == 0:
+            refs = [dY.double().T @ X.double(), dY.double().sum(0), dY.double() @ W.double()]
+        keep.append((dYp, Xp, Wp))
+    scr = ops.gemm_group(jobs, splits)
+    flops = copies * 2 * 2.0 * Mtok * Nout * Kin
+    res = {}
+    for tile in (64, 128):
+        check(load().slnlp_set_plane_tile(tile), "set_plane_tile")
+        for o in outs: o.fill_(float("nan"))
+        ops.gemm_group(jobs, splits, scr)
+        torch.cuda.synchronize()
+        res[tile] = [o.clone() for o in outs]
+        t = timeit(lambda: ops.gemm_group(jobs, splits, scr))
+        err = ""
+        if refs:
+            e = max(float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(res[tile][:3], refs))
+            err = f"  rel err vs fp64 {e:.1e}"
+        cd = lambda a, b: (a + b - 1) // b
+        units = copies * (cd(Nout, tile) * cd(Kin, tile) * split + cd(Mtok, tile) * cd(Kin, tile))
+        print(f"{name:34s} tile {tile:3d}: {units:5d} workgroups {t:8.1f} us  {flops / t / 1e6:7.1f} TFLOP/s{err}", flush=True)
+    same = all(torch.equal(a, b) for a, b in zip(res[64], res[128]))
+    print(f"{'':34s} tiles bit-identical: {same}", flush=True)
+    check(load().slnlp_set_plane_tile(0), "set_plane_tile")
+    return same
+
+keep = []
+quick = len(sys.argv) > 1
+ok = True
+ok &= case("cfg2 dgrad+wgrad E512", 2400, 512, 512, 3, check_ref=True)
+ok &= case("cfg2 x2 fits (one launch)", 2400, 512, 512, 3, copies=2)
+ok &= case("cfg2 in_proj grads 1536", 2400, 1536, 512, 3)
+ok &= case("ragged 1000 x 320 x 192", 1000, 320, 192, 2, check_ref=True)
+if not quick:
+    ok &= case("tokens x4 (9600) E512", 9600, 512, 512, 8)
+    ok &= case("tokens x16 (38400) E512", 38400, 512, 512, 8)
+    ok &= case("cfg5 FFN grads 16384x1024x512", 16384, 1024, 512, 8)
+    ok &= case("cfg5 in_proj grads 16384x3072x1024", 16384, 3072, 1024, 6)
+print("ALL TILES BIT-IDENTICAL" if ok else "TILE MISMATCH")
+sys.exit(0 if ok else 1)
