@@ -60,6 +60,28 @@ struct DeviceOnce {
     }
 };
 
+// ------------------------------------------------- probe builds (tools/probes) ----
+// -DSLNLP_PROBE_FENCES=k builds a library whose kernels bracket themselves with agent-scope fences: bit 0 = every wave starts
+// with an acquire (invalidates its CU's L1 and the XCD L2's non-local lines), bit 1 = every wave ends with a release (writes the
+// XCD L2's dirty lines back).  Never the shipped build (k = 0: both helpers compile to nothing): it exists to tell whether the
+// multi-queue nondeterminism is a cache-maintenance gap at kernel boundaries.
+#ifndef SLNLP_PROBE_FENCES
+#define SLNLP_PROBE_FENCES 0
+#endif
+__device__ __forceinline__ void probe_kernel_begin() {
+#if SLNLP_PROBE_FENCES & 1
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void probe_kernel_end() {
+#if SLNLP_PROBE_FENCES & 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ------------------------------------------------------------- dropout ------
 // Counter-based Philox4x32-10.  A dropout site is a logical [R, C] tensor;
 // element (r, c) takes word (r & 3) of philox(counter = {c, r >> 2, site, 0},

@@ -380,7 +380,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
 __global__ __launch_bounds__(256 * KS) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, AK, BK, BNT>()];
+    probe_kernel_begin();
     gemm_tile<NSPLIT, AK, BK, BNT, VEC, KS>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+    probe_kernel_end();
 }
 
 // Several independent fp32-operand GEMMs in ONE launch (e.g. the data- and weight-gradient of one dY in the
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupPar
         if (p.a.resid) p.a.resid += (long)z * p.a.batch_stride_c;
     }
     const int bx = lid % gx, by = lid / gx;
+    probe_kernel_begin();
     switch (variant) {
         case 0: gemm_tile<NSPLIT, true, true, 64, true, KS>(p, bx, by, gx, gy, smem); break;
         case 1: gemm_tile<NSPLIT, true, true, 16, true, KS>(p, bx, by, gx, gy, smem); break;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupPar
         case 4: gemm_tile<NSPLIT, false, false, 64, true, KS>(p, bx, by, gx, gy, smem); break;
         default: gemm_tile<NSPLIT, false, false, 16, true, KS>(p, bx, by, gx, gy, smem); break;
     }
+    probe_kernel_end();
 }
 
 // KS = 2 (two K halves per workgroup) for launches that cannot fill the chip and whose duration is the chain of K steps;

@@ -39,8 +39,8 @@ struct PlaneJob {
     int tiles_x, tiles_y, nks, block_begin;
     int vec_out;        // epilogue may use 16-byte row pieces (N % 4 == 0, aligned C / residual / planes)
     int hand_off;       // split-K meeting point: 0 = sc1 accesses only; probes (SLNLP_SPLITK_MODE): 2 = + reader acquire, 3 = + writer release
-    float* part;        // [tile][nks][TILE x TILE]   (accumulator layout)
-    float* part_rs;     // [tile_y][nks][TILE]        (row sums of A)
+    float* part;        // [tile][nks][bm x bn]   (accumulator layout)
+    float* part_rs;     // [tile_y][nks][bm]      (row sums of A)
     int* counters;      // [tiles], zero outside a launch
 };
 constexpr int MAX_JOBS = 4;
@@ -61,12 +61,12 @@ __device__ __forceinline__ void launder(slnlp_gemm_args& a) {
 
 // kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)
 const void* gemm_group_kernel_ptr(int precision, int ks = 1);
-const void* gemm_planes_kernel_ptr(int precision, int tile);
-int plane_tile_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs);   // 64 or 128: the tile a launch of these jobs takes
-void plane_job_retile(PlaneJob& j, int tile);
-size_t plane_lds_bytes(int tile);
-int plane_kernel_precision(const void* fn);
-int plane_tile_forced();
-int plane_big_tile_min_units();
+// tile geometries of the plane GEMM (gemm_planes.hip, GEO[]): 0 = 64 x 64, 1 = 128 x 128, 2 = 128 x 128 with 32-k stages, 3 = 256 x 128
+const void* gemm_planes_kernel_ptr(int precision, int geo);
+int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs);   // the geometry a launch of these jobs takes
+int plane_geo_auto(long units128, bool fp8);                                      // ... from its number of 128 x 128 tiles
+long plane_units128(const slnlp_gemm_args& a, int nks);
+void plane_job_retile(PlaneJob& j, int geo);
+void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, const void** fn, size_t* lds);
 
 }  // namespace slnlp

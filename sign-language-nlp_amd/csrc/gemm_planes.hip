@@ -29,9 +29,7 @@ typedef __attribute__((address_space(1))) const void* glb_vp;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int PT = 64;                 // tile edge (M, N and K)
-constexpr int IMG = PT * PT;           // bf16 elements per plane image (8 KiB)
 constexpr int PTHREADS = 512;
-constexpr int NSTAGE = 2;              // LDS ring depth (NSTAGE-1 tiles in flight)
 
 __device__ __forceinline__ int mswz(int k) { return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1; }
 
@@ -68,6 +66,41 @@ __device__ __forceinline__ bf16x8 pfrag(const unsigned short* __restrict__ img, 
     }
 }
 
+// ---- 32-k stages (deeper rings / larger tiles in the same LDS): a plane image is 64 rows x 32 k = 4 KiB.
+//   k-major: 64-byte rows would put a ds_read_b128 lane group on two 16-B slots of the bank row, so TWO rows share a 128-B
+//            line -- line L = rows 2L, 2L+1; logical slot s = (row & 1) * 4 + k / 8; physical slot = s ^ (L & 7): conflict-free
+//            fragment reads, and the DMA still writes lane-linearly (source address = the logical slot the swizzle maps there);
+//   m-major: [k][64 rows] lines of 128 B as above, 32 of them.
+// One DMA instruction of a wave moves 1 KiB = 8 lines; a SLAB (128 rows x 32 k of one plane = two images) is one instruction
+// of each of the 8 waves: wave -> image (wave >> 2), lines 8 * (wave & 3) ...
+template <bool KMAJOR>
+__device__ __forceinline__ int img32_off(int row, int k) {
+    if (KMAJOR) {
+        const int line = row >> 1, sl = ((row & 1) << 2) | (k >> 3);
+        return line * PT + (((sl ^ (line & 7)) << 3) | (k & 7));
+    }
+    return img_off<false>(row, k);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void dma_slab32(const unsigned short* __restrict__ plane, long ld, int row0, int row_last, int k0,
+                                           unsigned short* slab, int wave, int lane) {
+    const int h = wave >> 2, line = 8 * (wave & 3) + (lane >> 3), ps = lane & 7;
+    const int r_img = min(row0 + PT * h, row_last);       // (planes are padded to 64 rows: never read past the last padded block)
+    const unsigned short* src;
+    if (KMAJOR) {
+        const int sl = ps ^ (line & 7);
+        src = plane + (long)(r_img + 2 * line + (sl >> 2)) * ld + k0 + ((sl & 3) << 3);
+    } else {
+        src = plane + (long)(k0 + line) * ld + r_img + ((ps ^ mswz(line)) << 3);
+    }
+    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(slab + wave * 512), 16, 0, 0);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 pfrag32(const unsigned short* __restrict__ img, int r0, int lane) {
+    if (KMAJOR) return *reinterpret_cast<const bf16x8*>(img + img32_off<true>(r0 + (lane & 15), (lane >> 4) << 3));
+    return pfrag<false>(img, r0, 0, lane);
+}
+
 __device__ __forceinline__ float pbf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 // 8-byte agent-scope (sc1) store / load: write-through to / fetched from the memory side, never a stale XCD-L2 line
@@ -82,26 +115,30 @@ __device__ __forceinline__ float2 ld_agent2(const float* p) {
 
 // One block's work: output tile (bx, by) of the job, K-tiles [kt0, kt1).
 //
-// Tile geometry (template): BM x BN output tile, K-step 64, 8 waves as 4 (M) x 2 (N), each wave a (BM/4) x (BN/2) sub-tile =
-// MT x NT MFMA tiles of 16 x 16.  An operand panel of BM rows is BM/64 of the 64 x 64 plane images above, so the DMA pattern,
-// the swizzles and the fragment reads are those of the 64 x 64 tile whatever BM / BN:
-//   64 x 64   : 16 x 32 per wave -- 6 fragment reads for 6 MFMAs per 32-k; 32 KiB of operand planes per K-step for 64 x 64 x 64
-//               products; two workgroups per CU.  The shape for launches that need every CU for a few hundred tiles (cfg2 solo).
-//   128 x 128 : 32 x 64 per wave -- 12 fragment reads for 24 MFMAs per 32-k (half the LDS reads per MFMA) and 64 KiB per K-step
-//               for 4x the products (half the L2 -> LDS bytes per FLOP, the measured wall of the 64 x 64 tile: DESIGN.md section 5);
-//               2 stages = 128 KiB, one workgroup per CU.  The shape for launches with thousands of tiles (merged lockstep
-//               launches, the configs[4] shapes).
-// Split-K, the meeting point and the epilogues are the same code for both.
-template <int NSPLIT, bool AK, bool BK, int BM, int BN>
+// Tile geometry (template): BM x BN output tile, 8 waves as 4 (M) x 2 (N), each wave a (BM/4) x (BN/2) sub-tile = MT x NT MFMA
+// tiles of 16 x 16; K-step BKS (64 or 32) through an NST-deep LDS ring.  An operand panel of BM rows is BM/64 plane images,
+// so the DMA pattern, the swizzles and the fragment reads are those of the 64 x 64 tile whatever BM / BN:
+//   64 x 64 x 64, 2 stages   : 16 x 32 per wave -- 6 fragment reads for 6 MFMAs per 32-k; 32 KiB of operand planes per K-step for
+//                              64 x 64 x 64 products; two workgroups per CU.  Launches that need every CU for a few hundred tiles.
+//   128 x 128 x 64, 2 stages : 32 x 64 per wave -- 12 fragment reads for 24 MFMAs per 32-k, half the L2 -> LDS bytes per FLOP
+//                              (the measured wall of the 64 x 64 tile); 128 KiB, one workgroup per CU.
+//   128 x 128 x 32, 4 stages : the same tile with three K-steps in flight instead of one.
+//   256 x 128 x 32, 3 stages : 64 x 64 per wave -- 16 fragment reads for 48 MFMAs, 3/8 of the 64 x 64 tile's bytes per FLOP; 144 KiB.
+// Split-K, the meeting point and the epilogues are the same code for all; the K partition (in units of 64) does not depend on
+// the geometry, so every geometry accumulates every output element in the same order: identical bits.
+template <int NSPLIT, bool AK, bool BK, int BM, int BN, int BKS, int NST>
 __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
     constexpr int NP = NSPLIT == 3 ? 2 : 1;
-    constexpr int SUBM = BM / PT, SUBN = BN / PT;            // 64 x 64 plane images per operand panel
+    constexpr int SUBM = BM / PT, SUBN = BN / PT;            // 64-row plane images per operand panel
     constexpr int MT = BM / 64, NT = BN / 32;                // 16 x 16 MFMA tiles per wave: (BM/4)/16 x (BN/2)/16
+    constexpr int IMG_E = PT * BKS;                          // elements of one image (8 KiB at 64 k, 4 KiB at 32 k)
     constexpr int A_IMGS = NP * SUBM, B_IMGS = NP * SUBN;
-    constexpr int STAGE = (A_IMGS + B_IMGS) * IMG;           // A planes then B planes
-    constexpr int PIECES = A_IMGS + B_IMGS;                  // DMA instructions per wave and stage
+    constexpr int STAGE = (A_IMGS + B_IMGS) * IMG_E;         // A planes then B planes
+    constexpr int PIECES = (A_IMGS + B_IMGS) * BKS / 64;     // DMA instructions per wave and stage
+    constexpr int KSUB = PT / BKS;                           // ring steps per 64-k tile
+    static_assert(BKS == 64 || (BM % 128 == 0 && BN % 128 == 0), "32-k stages move 128-row slabs");
     const slnlp_gemm_args& g = job.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * (BM / 4), wn0 = (wave & 1) * (BN / 2);
     const int nks = job.nks;
     int bx, by, ks, tile;
@@ -114,31 +151,51 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         const int ntiles = job.tiles_x * job.tiles_y;
         ks = t / ntiles;
         tile = t - ks * ntiles;
-        by = tile / job.tiles_x;
-        bx = tile - by * job.tiles_x;
+        // tiles in groups of GR tile rows, column by column inside a group: the workgroups resident on an XCD at one time
+        // (32 at one per CU, 64 at two) then form a GR x (32 / GR) block of the tile grid whatever tiles_x is, and share its
+        // GR + 32 / GR operand panels through the XCD's L2 instead of fetching 32 + 1
+        constexpr int GR = BM >= 128 ? 4 : 8;
+        const int grp = tile / (GR * job.tiles_x), rem = tile - grp * (GR * job.tiles_x);
+        const int rows_here = min(GR, job.tiles_y - grp * GR);
+        bx = rem / rows_here;
+        by = grp * GR + (rem - bx * rows_here);
+        tile = by * job.tiles_x + bx;                          // (the id the partial tiles and arrival counters use)
     }
     const int bm0 = by * BM, bn0 = bx * BN;
     const int M = g.M, N = g.N, K = g.K;
     const int ktiles = (K + PT - 1) / PT;
-    const int kt0 = (int)((long)ktiles * ks / nks), kt1 = (int)((long)ktiles * (ks + 1) / nks);
-    // planes are zero-padded to multiples of 64 rows; a 128-row panel may reach one 64-row block further: read the last padded
-    // block again instead (its products land in rows >= M / columns >= N, which no epilogue stores)
+    const int kt0 = (int)((long)ktiles * ks / nks) * KSUB, kt1 = (int)((long)ktiles * (ks + 1) / nks) * KSUB;   // ring steps
+    // planes are zero-padded to multiples of 64 rows; a wider panel may reach further: read the last padded block again
+    // instead (its products land in rows >= M / columns >= N, which no epilogue stores)
     const int am_last = ((M + PT - 1) / PT - 1) * PT, bn_last = ((N + PT - 1) / PT - 1) * PT;
 
     auto issue = [&](int kt, int stage) {
-        const int k0 = (kt < kt1 ? kt : kt0) * PT;        // past-the-end prefetch re-reads a valid tile (never consumed)
+        const int k0 = (kt < kt1 ? kt : kt0) * BKS;       // past-the-end prefetch re-reads a valid tile (never consumed)
         unsigned short* s = smem + stage * STAGE;
+        if constexpr (BKS == 64) {
 #pragma unroll
-        for (int sm = 0; sm < SUBM; ++sm) {
-            const int r0 = BM > PT ? min(bm0 + sm * PT, am_last) : bm0;
-            dma_plane<AK>(g.A_hi, g.lda_p, r0, k0, s + sm * IMG, wave, lane);
-            if (NSPLIT == 3) dma_plane<AK>(g.A_lo, g.lda_p, r0, k0, s + (SUBM + sm) * IMG, wave, lane);
-        }
+            for (int sm = 0; sm < SUBM; ++sm) {
+                const int r0 = BM > PT ? min(bm0 + sm * PT, am_last) : bm0;
+                dma_plane<AK>(g.A_hi, g.lda_p, r0, k0, s + sm * IMG_E, wave, lane);
+                if (NSPLIT == 3) dma_plane<AK>(g.A_lo, g.lda_p, r0, k0, s + (SUBM + sm) * IMG_E, wave, lane);
+            }
 #pragma unroll
-        for (int sn = 0; sn < SUBN; ++sn) {
-            const int r0 = BN > PT ? min(bn0 + sn * PT, bn_last) : bn0;
-            dma_plane<BK>(g.B_hi, g.ldb_p, r0, k0, s + (A_IMGS + sn) * IMG, wave, lane);
-            if (NSPLIT == 3) dma_plane<BK>(g.B_lo, g.ldb_p, r0, k0, s + (A_IMGS + SUBN + sn) * IMG, wave, lane);
+            for (int sn = 0; sn < SUBN; ++sn) {
+                const int r0 = BN > PT ? min(bn0 + sn * PT, bn_last) : bn0;
+                dma_plane<BK>(g.B_hi, g.ldb_p, r0, k0, s + (A_IMGS + sn) * IMG_E, wave, lane);
+                if (NSPLIT == 3) dma_plane<BK>(g.B_lo, g.ldb_p, r0, k0, s + (A_IMGS + SUBN + sn) * IMG_E, wave, lane);
+            }
+        } else {
+#pragma unroll
+            for (int sm = 0; sm < SUBM; sm += 2) {            // a slab = images sm, sm + 1
+                dma_slab32<AK>(g.A_hi, g.lda_p, bm0 + sm * PT, am_last, k0, s + sm * IMG_E, wave, lane);
+                if (NSPLIT == 3) dma_slab32<AK>(g.A_lo, g.lda_p, bm0 + sm * PT, am_last, k0, s + (SUBM + sm) * IMG_E, wave, lane);
+            }
+#pragma unroll
+            for (int sn = 0; sn < SUBN; sn += 2) {
+                dma_slab32<BK>(g.B_hi, g.ldb_p, bn0 + sn * PT, bn_last, k0, s + (A_IMGS + sn) * IMG_E, wave, lane);
+                if (NSPLIT == 3) dma_slab32<BK>(g.B_lo, g.ldb_p, bn0 + sn * PT, bn_last, k0, s + (A_IMGS + SUBN + sn) * IMG_E, wave, lane);
+            }
         }
     };
 
@@ -148,36 +205,46 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = (g.rowsum_a != nullptr) && (bx == 0);
-    float rowsum[SUBM];
+    float rowsum[SUBM];                                      // (64 k: one per image; 32 k: image pair p -> [2p] even steps, [2p + 1] odd steps)
 #pragma unroll
     for (int i = 0; i < SUBM; ++i) rowsum[i] = 0.f;
 
-    // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-1 are in flight while tile kt is consumed (a K-step's
-    // MFMA work is ~0.2 us, one DMA round trip ~1 us).  ONE barrier per step: the stage refilled at step kt
-    // was consumed at step kt-1, which every wave has finished once it passes this step's barrier.
-    for (int t = 0; t < NSTAGE - 1; ++t) issue(kt0 + t, t);
+    // NST-deep LDS ring: steps kt+1 .. kt+NST-1 are in flight while step kt is consumed (a K-step's MFMA work is
+    // ~0.2 - 0.6 us, one DMA round trip ~1 us).  ONE barrier per step: the stage refilled at step kt was consumed at
+    // step kt-1, which every wave has finished once it passes this step's barrier.
+    for (int t = 0; t < NST - 1; ++t) issue(kt0 + t, t);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int it = kt - kt0;
-        // this wave's DMA of tile kt has landed once only the (NSTAGE-2) newer tiles' pieces are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NSTAGE - 2) * PIECES) : "memory");
+        // this wave's DMA of step kt has landed once only the (NST-2) newer steps' pieces are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NST - 2) * PIECES) : "memory");
         __builtin_amdgcn_s_barrier();                      // ... and so has every other wave's part
         asm volatile("" ::: "memory");
-        issue(kt + NSTAGE - 1, (it + NSTAGE - 1) % NSTAGE);
-        const unsigned short* s = smem + (it % NSTAGE) * STAGE;
+        issue(kt + NST - 1, (it + NST - 1) % NST);
+        const unsigned short* s = smem + (it % NST) * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BKS / 32; ++kk) {
             bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = wm0 + 16 * i;              // a 16-row MFMA tile never straddles two 64-row images
-                ah[i] = pfrag<AK>(s + (row / PT) * IMG, row % PT, kk, lane);
-                if (NSPLIT == 3) al[i] = pfrag<AK>(s + (SUBM + row / PT) * IMG, row % PT, kk, lane);
+                if constexpr (BKS == 64) {
+                    ah[i] = pfrag<AK>(s + (row / PT) * IMG_E, row % PT, kk, lane);
+                    if (NSPLIT == 3) al[i] = pfrag<AK>(s + (SUBM + row / PT) * IMG_E, row % PT, kk, lane);
+                } else {
+                    ah[i] = pfrag32<AK>(s + (row / PT) * IMG_E, row % PT, lane);
+                    if (NSPLIT == 3) al[i] = pfrag32<AK>(s + (SUBM + row / PT) * IMG_E, row % PT, lane);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int row = wn0 + 16 * j;
-                bh[j] = pfrag<BK>(s + (A_IMGS + row / PT) * IMG, row % PT, kk, lane);
-                if (NSPLIT == 3) bl[j] = pfrag<BK>(s + (A_IMGS + SUBN + row / PT) * IMG, row % PT, kk, lane);
+                if constexpr (BKS == 64) {
+                    bh[j] = pfrag<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, kk, lane);
+                    if (NSPLIT == 3) bl[j] = pfrag<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, kk, lane);
+                } else {
+                    bh[j] = pfrag32<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, lane);
+                    if (NSPLIT == 3) bl[j] = pfrag32<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, lane);
+                }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -190,33 +257,51 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (do_rowsum) {   // thread owns row (tid & 63) of every 64-row image, k-octet (tid >> 6)
-            const int row = tid & 63, kq = (tid >> 6) * 8;
+        if (do_rowsum) {
+            // 64 k: thread = row (tid & 63) of every image, k-octet tid >> 6 of the step.  32 k: a step holds 4 octets, so the
+            // waves cover two images per pass (image pair p: sm + wave / 4, octet wave % 4) and a thread keeps the sums of the
+            // even and the odd steps apart -- octets o and o + 4 of the 64-k tile -- so the eight octet sums, and their final
+            // order, are those of the 64-k path: the bias gradient keeps its bits across geometries.
+            constexpr int OCT = BKS / 8;                      // k-octets per image and step
+            const int row = tid & 63, kq = ((tid >> 6) % OCT) * 8, sub0 = (tid >> 6) / OCT;
 #pragma unroll
-            for (int sm = 0; sm < SUBM; ++sm) {
+            for (int sm = 0; sm < SUBM; sm += 8 / OCT) {
+                const int im = sm + sub0;
                 float t = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int off = img_off<AK>(row, kq + k);
-                    t += pbf2f(s[sm * IMG + off]);
-                    if (NSPLIT == 3) t += pbf2f(s[(SUBM + sm) * IMG + off]);
+                    const int off = BKS == 64 ? img_off<AK>(row, kq + k) : img32_off<AK>(row, kq + k);
+                    t += pbf2f(s[im * IMG_E + off]);
+                    if (NSPLIT == 3) t += pbf2f(s[(SUBM + im) * IMG_E + off]);
                 }
-                rowsum[sm] += t;
+                if (BKS == 64) rowsum[sm] += t;
+                else if (kt & 1) rowsum[sm + 1] += t;          // (kt0 is even: a split starts on a 64-k tile)
+                else rowsum[sm] += t;
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the dummy prefetches before LDS is reused / freed
     __builtin_amdgcn_s_barrier();
     float* rs = reinterpret_cast<float*>(smem);
-    int* flag = reinterpret_cast<int*>(smem) + SUBM * PTHREADS;
+    int* flag = reinterpret_cast<int*>(smem) + SUBM * PTHREADS;   // (behind the rs table: SUBM * 8 * 64 floats at most)
     float rs_row = 0.f;                                      // tid < BM: this block's row sum of A row bm0 + tid
     if (do_rowsum) {
+        // rs[image][octet of the 64-k tile][row]
+        if (BKS == 64) {
 #pragma unroll
-        for (int sm = 0; sm < SUBM; ++sm) rs[(sm * (PTHREADS / 64) + (tid >> 6)) * PT + (tid & 63)] = rowsum[sm];
+            for (int sm = 0; sm < SUBM; ++sm) rs[(sm * 8 + (tid >> 6)) * PT + (tid & 63)] = rowsum[sm];
+        } else {
+#pragma unroll
+            for (int sm = 0; sm < SUBM; sm += 2) {
+                const int im = sm + (tid >> 8), o = (tid >> 6) & 3;
+                rs[(im * 8 + o) * PT + (tid & 63)] = rowsum[sm];
+                rs[(im * 8 + o + 4) * PT + (tid & 63)] = rowsum[sm + 1];
+            }
+        }
         __syncthreads();
         if (tid < BM) {
 #pragma unroll
-            for (int w = 0; w < PTHREADS / 64; ++w) rs_row += rs[((tid / PT) * (PTHREADS / 64) + w) * PT + (tid % PT)];
+            for (int w = 0; w < 8; ++w) rs_row += rs[((tid / PT) * 8 + w) * PT + (tid % PT)];
         }
     }
     if (nks > 1) {
@@ -385,8 +470,8 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
 // inside a K-step is permuted the same way for A and B, which a contraction does not see).  Per algorithmic FLOP that is a
 // quarter of the operand bytes and a third of the MFMA issue slots of the three-pass split-bf16 kernel.
 constexpr int Q8_BK = 128;             // k (= bytes) per K-step
-constexpr int Q8_IMG = PT * Q8_BK;     // bytes per operand image (8 KiB)
-constexpr int Q8_STAGES = 4;
+constexpr int Q8_IMG = PT * Q8_BK;     // bytes per 64-row operand image (8 KiB)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 __device__ __forceinline__ void dma_q8(const unsigned char* __restrict__ plane, long ld, int row0, int k0, unsigned char* img,
                                        int wave, int lane) {
@@ -395,90 +480,182 @@ __device__ __forceinline__ void dma_q8(const unsigned char* __restrict__ plane, 
     __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(img + wave * 1024), 16, 0, 0);
 }
 
+// fragment of v_mfma_scale_f32_16x16x128_f8f6f4: lane (row = lane & 15, quarter = lane >> 4) holds 32 consecutive k-bytes of its
+// row -- 16-byte slots 2q and 2q + 1 of the 128-byte image row (each under the row's swizzle).  A and B use the same map, so
+// whatever order the instruction gives the 128 k inside a step, both operands agree on it.
+__device__ __forceinline__ i32x8 q8_frag(const unsigned char* __restrict__ img, int r0, int lane) {
+    const int row = r0 + (lane & 15), q = lane >> 4;
+    const uint4 lo = *reinterpret_cast<const uint4*>(img + row * Q8_BK + (((2 * q) ^ (row & 7)) << 4));
+    const uint4 hi = *reinterpret_cast<const uint4*>(img + row * Q8_BK + (((2 * q + 1) ^ (row & 7)) << 4));
+    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+}
+
+// precision 8 tile: BM x BN outputs, 128-k steps through an NST-deep LDS-DMA ring, 8 waves as 4 (M) x 2 (N), ONE block-scaled
+// MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3, every block scale 2^0) per 16 x 16 tile and step: twice the MFMA rate
+// of the plain fp8 forms (MI355X guide, matrix cores) -- the instruction behind the 5 PFLOP/s dense fp8 peak.  Per algorithmic
+// FLOP a 256 x 256 tile moves 1/16 of the operand bytes of the three-pass split-bf16 64 x 64 tile.
+template <int BM, int BN, int NST>
 __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned char* smem) {
+    constexpr int SUBM = BM / PT, SUBN = BN / PT, MT = BM / 64, NT = BN / 32;
+    constexpr int STAGE = (SUBM + SUBN) * Q8_IMG, PIECES = SUBM + SUBN;
+    constexpr int E8M0_ONE = 0x7F7F7F7F;                        // four block scales of 2^0
     const slnlp_gemm_args& g = job.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 16, wn0 = (wave & 1) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * (BM / 4), wn0 = (wave & 1) * (BN / 2);
     int bx, by;
     {
         const int nwg = job.tiles_x * job.tiles_y;
         const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
-        by = t / job.tiles_x;
-        bx = t - by * job.tiles_x;
+        constexpr int GR = BM >= 128 ? 4 : 8;                   // tiles in groups of GR tile rows (see plane_tile)
+        const int grp = t / (GR * job.tiles_x), rem = t - grp * (GR * job.tiles_x);
+        const int rows_here = min(GR, job.tiles_y - grp * GR);
+        bx = rem / rows_here;
+        by = grp * GR + (rem - bx * rows_here);
     }
-    const int bm0 = by * PT, bn0 = bx * PT, M = g.M, N = g.N;
+    const int bm0 = by * BM, bn0 = bx * BN, M = g.M, N = g.N;
     const int ktiles = (g.K + Q8_BK - 1) / Q8_BK;
+    const int am_last = ((M + PT - 1) / PT - 1) * PT, bn_last = ((N + PT - 1) / PT - 1) * PT;
     const unsigned char* A8 = reinterpret_cast<const unsigned char*>(g.A_hi);
     const unsigned char* B8 = reinterpret_cast<const unsigned char*>(g.B_hi);
     auto issue = [&](int kt, int stage) {
         const int k0 = (kt < ktiles ? kt : 0) * Q8_BK;          // past-the-end prefetch re-reads a valid tile (never consumed)
-        unsigned char* st = smem + stage * 2 * Q8_IMG;
-        dma_q8(A8, g.lda_p, bm0, k0, st, wave, lane);
-        dma_q8(B8, g.ldb_p, bn0, k0, st + Q8_IMG, wave, lane);
+        unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int sm = 0; sm < SUBM; ++sm) dma_q8(A8, g.lda_p, BM > PT ? min(bm0 + sm * PT, am_last) : bm0, k0, st + sm * Q8_IMG, wave, lane);
+#pragma unroll
+        for (int sn = 0; sn < SUBN; ++sn) dma_q8(B8, g.ldb_p, BN > PT ? min(bn0 + sn * PT, bn_last) : bn0, k0, st + (SUBM + sn) * Q8_IMG, wave, lane);
     };
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    for (int t = 0; t < Q8_STAGES - 1; ++t) issue(t, t);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NST - 1; ++t) issue(t, t);
     for (int kt = 0; kt < ktiles; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((Q8_STAGES - 2) * 2) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NST - 2) * PIECES) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(kt + Q8_STAGES - 1, (kt + Q8_STAGES - 1) % Q8_STAGES);
-        const unsigned char* sa = smem + (kt % Q8_STAGES) * 2 * Q8_IMG;
-        const unsigned char* sb = sa + Q8_IMG;
-        const int rowa = wm0 + (lane & 15), qd = lane >> 4;
+        issue(kt + NST - 1, (kt + NST - 1) % NST);
+        const unsigned char* sa = smem + (kt % NST) * STAGE;
+        const unsigned char* sb = sa + SUBM * Q8_IMG;
+        i32x8 af[MT];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {                           // lane group qd reads 16-byte slot 4r + qd of its row
-            const int slot = 4 * r + qd;
-            const uint4 a = *reinterpret_cast<const uint4*>(sa + rowa * Q8_BK + ((slot ^ (rowa & 7)) << 4));
+        for (int i = 0; i < MT; ++i) {
+            const int row = wm0 + 16 * i;
+            af[i] = q8_frag(sa + (row / PT) * Q8_IMG, row % PT, lane);
+        }
+        constexpr int JB = NT > 4 ? 4 : NT;                     // B fragments live at a time (register pressure of the widest tile)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int rowb = wn0 + 16 * j + (lane & 15);
-                const uint4 b = *reinterpret_cast<const uint4*>(sb + rowb * Q8_BK + ((slot ^ (rowb & 7)) << 4));
-                const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
-                const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc[j], 0, 0, 0);
+        for (int j0 = 0; j0 < NT; j0 += JB) {
+            i32x8 bf[JB];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const int row = wn0 + 16 * (j0 + j);
+                bf[j] = q8_frag(sb + (row / PT) * Q8_IMG, row % PT, lane);
             }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+                    acc[i][j0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf[j], acc[i][j0 + j], 0, 0, 0, E8M0_ONE, 0, E8M0_ONE);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // drain the dummy prefetches
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // drain the dummy prefetches before the ring is reused
+    __builtin_amdgcn_s_barrier();
     // ---- epilogue: * col_scale -> +bias -> relu -> dropout -> +resid ; fp32 store (+ optional bf16 / fp8 planes)
     const int crow = (lane >> 4) << 2, ccol = lane & 15;
+    if (job.vec_out) {
+        // 64 tile rows at a time through an fp32 LDS image (the whole 256 x 256 tile would not fit): the waves that own the
+        // rows apply the element-wise part in the accumulator layout, then every thread stores 16-byte row pieces.
+        constexpr int SLD = BN + 4, CH = BM / PT;
+        float* stg = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int gm0 = bm0 + wm0 + crow, gn = bn0 + wn0 + j * 16 + ccol;
-        if (gn >= N || gm0 >= M) continue;
-        const float cs = g.col_scale ? g.col_scale[gn] : 1.f, bias = g.bias ? g.bias[gn] : 0.f;
-        uint4 bits = make_uint4(0, 0, 0, 0);
-        if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+        for (int ch = 0; ch < CH; ++ch) {
+            if (ch) __syncthreads();
+            if (wm0 / PT == ch) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gm = gm0 + r;
-            if (gm >= M) break;
-            float v = acc[j][r] * cs + bias;
-            if (g.relu == 1) v = fmaxf(v, 0.f);
-            else if (g.relu == 2) v = tanhf(v);
-            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
-            if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
-            if (g.C) g.C[(long)gm * g.ldc + gn] = v;
-            if (g.C_hi) {
-                unsigned short h, l;
-                split_bf16(v, h, l);
-                g.C_hi[(long)gm * g.ldc_p + gn] = h;
-                if (g.C_lo) g.C_lo[(long)gm * g.ldc_p + gn] = l;
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int lm0 = wm0 % PT + 16 * i + crow, ln = wn0 + 16 * j + ccol;
+                        const int gm0 = bm0 + ch * PT + lm0, gn = bn0 + ln;
+                        const bool live = gn < N && gm0 < M;
+                        const float cs = (live && g.col_scale) ? g.col_scale[gn] : 1.f, bias = (live && g.bias) ? g.bias[gn] : 0.f;
+                        uint4 bits = make_uint4(0, 0, 0, 0);
+                        if (live && g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[i][j][r] * cs + bias;
+                            if (g.relu == 1) v = fmaxf(v, 0.f);
+                            else if (g.relu == 2) v = tanhf(v);
+                            if (live && gm0 + r < M && g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                            stg[(lm0 + r) * SLD + ln] = v;
+                        }
+                    }
             }
-            if (g.C_q8) g.C_q8[(long)gm * g.ldc_p + gn] = (unsigned char)(pack_fp8x4(v, 0.f, 0.f, 0.f) & 0xFFu);
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < PT * BN / 4 / PTHREADS; ++pass) {
+                const int piece = pass * PTHREADS + tid, row = piece / (BN / 4), c4 = (piece % (BN / 4)) << 2;
+                const int gm = bm0 + ch * PT + row, gn = bn0 + c4;
+                if (gm >= M || gn >= N) continue;
+                float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+                if (g.resid) {
+                    const float4 rr = *reinterpret_cast<const float4*>(g.resid + (long)gm * g.ldr + gn);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (g.C) *reinterpret_cast<float4*>(g.C + (long)gm * g.ldc + gn) = v;
+                if (g.C_hi && g.C_lo) {
+                    PlaneOut po;
+                    po.hi = g.C_hi; po.lo = g.C_lo; po.q8 = g.C_q8;
+                    store_planes4(po, (long)gm * g.ldc_p + gn, v);
+                } else if (g.C_q8) {
+                    *reinterpret_cast<unsigned*>(g.C_q8 + (long)gm * g.ldc_p + gn) = pack_fp8x4(v.x, v.y, v.z, v.w);
+                }
+            }
         }
+        return;
     }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int gm0 = bm0 + wm0 + 16 * i + crow, gn = bn0 + wn0 + j * 16 + ccol;
+            if (gn >= N || gm0 >= M) continue;
+            const float cs = g.col_scale ? g.col_scale[gn] : 1.f, bias = g.bias ? g.bias[gn] : 0.f;
+            uint4 bits = make_uint4(0, 0, 0, 0);
+            if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = gm0 + r;
+                if (gm >= M) break;
+                float v = acc[i][j][r] * cs + bias;
+                if (g.relu == 1) v = fmaxf(v, 0.f);
+                else if (g.relu == 2) v = tanhf(v);
+                if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
+                if (g.C) g.C[(long)gm * g.ldc + gn] = v;
+                if (g.C_hi) {
+                    unsigned short h, l;
+                    split_bf16(v, h, l);
+                    g.C_hi[(long)gm * g.ldc_p + gn] = h;
+                    if (g.C_lo) g.C_lo[(long)gm * g.ldc_p + gn] = l;
+                }
+                if (g.C_q8) g.C_q8[(long)gm * g.ldc_p + gn] = (unsigned char)(pack_fp8x4(v, 0.f, 0.f, 0.f) & 0xFFu);
+            }
+        }
 }
 
-// TILE: 64 (64 x 64 output tiles, 64 KiB of LDS, two workgroups per CU) or 128 (128 x 128, 128 KiB, one per CU); every job
-// of a launch uses the launch's tile (the host picks it per launch: plane_tile_for()).
-template <int NSPLIT, int TILE>
+// GEO: the launch's tile geometry (table below); every job of a launch uses it (the host picks it per launch: plane_geo_for()).
+struct GeoInfo { int bm, bn, bks, nst; };
+constexpr int NGEO = 4;
+constexpr GeoInfo GEO[NGEO] = {{64, 64, 64, 2}, {128, 128, 64, 2}, {128, 128, 32, 4}, {256, 128, 32, 3}};
+
+template <int NSPLIT, int G>
 __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
                                                                const int* __restrict__ blockmap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // NSTAGE stages (+ scratch after the loop)
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // the LDS ring (+ scratch after the loop)
     PlaneJob job;
     if (tab) {
         job = tab[blockmap[blockIdx.x]];
@@ -492,15 +669,72 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupP
     job.part = as_global(job.part); job.part_rs = as_global(job.part_rs); job.counters = as_global(job.counters);
     const int lid = blockIdx.x - job.block_begin;
     if (lid >= job.tiles_x * job.tiles_y * job.nks) return;                 // padding block of a merged launch (jobs start on multiples of 8)
-    if (TILE == 64 && job.variant == 3) { q8_tile(job, lid, reinterpret_cast<unsigned char*>(smem)); return; }
-    if (job.variant == 0) plane_tile<NSPLIT, true, true, TILE, TILE>(job, lid, smem);
-    else if (job.variant == 1) plane_tile<NSPLIT, true, false, TILE, TILE>(job, lid, smem);
-    else plane_tile<NSPLIT, false, false, TILE, TILE>(job, lid, smem);
+    constexpr GeoInfo g = GEO[G];
+    probe_kernel_begin();
+    if (job.variant == 0) plane_tile<NSPLIT, true, true, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
+    else if (job.variant == 1) plane_tile<NSPLIT, true, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
+    else plane_tile<NSPLIT, false, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
+    probe_kernel_end();
 }
 
-// NSTAGE x (A, B) x (hi, lo) x (TILE / 64) x 8 KiB: 64 KiB at 64 x 64, 128 KiB at 128 x 128
-constexpr size_t plane_lds(int tile) { return (size_t)NSTAGE * 2 * 2 * (tile / PT) * IMG * sizeof(unsigned short); }
+// ring bytes: stages x (A + B panels) x (hi, lo) x bks k x 2 B -- 64 KiB, 128 KiB, 128 KiB, 144 KiB; the epilogue's fp32 image of
+// the tile (bm x (bn + 4) floats) lives in the same memory and is never the larger of the two
+constexpr size_t plane_lds(int geo) {
+    const size_t ring = (size_t)GEO[geo].nst * 2 * (GEO[geo].bm + GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);
+    const size_t image = (size_t)GEO[geo].bm * (GEO[geo].bn + 4) * sizeof(float);
+    return ring > image ? ring : image;
+}
 constexpr int GROUP_COUNTERS = 4096;                       // ints at the head of the scratch buffer
+
+// ---- precision 8 launches: their own kernel (all jobs of a launch are fp8 jobs), four geometries
+struct Q8GeoInfo { int bm, bn, nst; };
+constexpr int NQGEO = 4;
+constexpr Q8GeoInfo QGEO[NQGEO] = {{64, 64, 4}, {128, 128, 4}, {256, 128, 3}, {256, 256, 2}};
+
+template <int G>
+__global__ __launch_bounds__(PTHREADS) void gemm_q8_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
+                                                           const int* __restrict__ blockmap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    PlaneJob job;
+    if (tab) {
+        job = tab[blockmap[blockIdx.x]];
+    } else {
+        int j = 0;
+        for (int t = 1; t < P.njobs; ++t)
+            if ((int)blockIdx.x >= P.job[t].block_begin) j = t;
+        job = P.job[j];
+    }
+    launder(job.a);
+    const int lid = blockIdx.x - job.block_begin;
+    if (lid >= job.tiles_x * job.tiles_y) return;
+    q8_tile<QGEO[G].bm, QGEO[G].bn, QGEO[G].nst>(job, lid, reinterpret_cast<unsigned char*>(smem));
+}
+constexpr size_t q8_lds(int geo) {
+    const size_t ring = (size_t)QGEO[geo].nst * (QGEO[geo].bm + QGEO[geo].bn) * Q8_BK;
+    const size_t image = (size_t)PT * (QGEO[geo].bn + 4) * sizeof(float);
+    return ring > image ? ring : image;
+}
+static const void* q8_kernel_ptr(int geo) {
+    switch (geo) {
+        case 1: return (const void*)gemm_q8_kernel<1>;
+        case 2: return (const void*)gemm_q8_kernel<2>;
+        case 3: return (const void*)gemm_q8_kernel<3>;
+        default: return (const void*)gemm_q8_kernel<0>;
+    }
+}
+static int q8_geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 256128 ? 2 : knob == 256256 ? 3 : -1; }
+static std::atomic<int> g_q8_geo{[] { const char* e = getenv("SLNLP_Q8_TILE"); return q8_geo_of_knob(e ? atoi(e) : 0); }()};
+// the widest tile that still gives every CU a few workgroups
+static int q8_geo_auto(const PlaneJob* jobs, int njobs) {
+    const int forced = g_q8_geo.load(std::memory_order_relaxed);
+    if (forced >= 0) return forced;
+    for (int geo = NQGEO - 1; geo > 0; --geo) {
+        long units = 0;
+        for (int i = 0; i < njobs; ++i) units += (long)ceil_div(jobs[i].a.M, QGEO[geo].bm) * ceil_div(jobs[i].a.N, QGEO[geo].bn);
+        if (units >= 512) return geo;
+    }
+    return 0;
+}
 
 // Probe switch for the split-K meeting point (tools/probes): env SLNLP_SPLITK_MODE = 1: never split K;
 // 2: the last workgroup runs an agent-scope acquire before it reads the partials; 3: 2 + an agent-scope release in front of
@@ -510,35 +744,40 @@ static int splitk_mode() {
     return mode;
 }
 
-// ---- which tile a launch uses.  0 = automatic (plane_tile_for), 64 / 128 = forced (slnlp_set_plane_tile: tuning, tests)
-static std::atomic<int> g_plane_tile{[] { const char* e = getenv("SLNLP_PLANE_TILE"); const int t = e ? atoi(e) : 0; return t == 64 || t == 128 ? t : 0; }()};
+// ---- which geometry a launch uses.  -1 = automatic (plane_geo_for), 0 .. NGEO-1 = forced (slnlp_set_plane_tile: tuning, tests)
+static int geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 12832 ? 2 : knob == 256128 ? 3 : -1; }
+static std::atomic<int> g_plane_geo{[] { const char* e = getenv("SLNLP_PLANE_TILE"); return geo_of_knob(e ? atoi(e) : 0); }()};
 constexpr int BIG_TILE_MIN_UNITS = 512;    // a launch takes 128 x 128 tiles when it still has at least this many of them
 
-static int units_at(const slnlp_gemm_args& a, int tile, int nks) { return ceil_div(a.M, tile) * ceil_div(a.N, tile) * (nks < 1 ? 1 : nks); }
-
-// 128 x 128 tiles move half the operand bytes per FLOP through the L2 -> LDS path and issue half the LDS fragment reads per
-// MFMA, but one such workgroup owns a CU: they pay once a launch has enough of them to fill the chip a few times over
-// (merged lockstep launches are tiled per job by the same rule, so a merged launch of K fits keeps the tile of one fit --
-// bit-identical results need the same tile and split as the solo launch).
-int plane_tile_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
-    const int forced = g_plane_tile.load(std::memory_order_relaxed);
-    for (int i = 0; i < njobs; ++i)
-        if (jobs[i].precision == 8) return 64;               // the fp8 tile is built at 64 x 64
-    if (forced == 64 || forced == 128) return forced;
+// Larger tiles move fewer operand bytes per FLOP through the L2 -> LDS path and issue fewer LDS fragment reads per MFMA, but
+// one such workgroup owns a CU: they pay once a launch has enough of them to fill the chip a few times over.
+int plane_geo_auto(long units128, bool fp8) {
+    if (fp8) return 0;                                       // the fp8 tile is built at 64 x 64
+    const int forced = g_plane_geo.load(std::memory_order_relaxed);
+    if (forced >= 0) return forced;
+    return units128 >= BIG_TILE_MIN_UNITS ? 1 : 0;
+}
+long plane_units128(const slnlp_gemm_args& a, int nks) { return (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) * (nks < 1 ? 1 : nks); }
+int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
     long units = 0;
-    for (int i = 0; i < njobs; ++i) units += units_at(jobs[i], 128, split_k ? split_k[i] : 1);
-    return units >= BIG_TILE_MIN_UNITS ? 128 : 64;
+    bool fp8 = false;
+    for (int i = 0; i < njobs; ++i) {
+        fp8 = fp8 || jobs[i].precision == 8;
+        units += plane_units128(jobs[i], split_k ? split_k[i] : 1);
+    }
+    return plane_geo_auto(units, fp8);
 }
 
 // set the kernels' LDS attribute up front (plan creation) so it never lands inside a graph capture
 int gemm_planes_init() {
     static DeviceOnce once;
     return once.run([]() -> int {
-        const bool ok =
-            hipFuncSetAttribute((const void*)gemm_planes_kernel<3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_lds(64)) == hipSuccess &&
-            hipFuncSetAttribute((const void*)gemm_planes_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_lds(64)) == hipSuccess &&
-            hipFuncSetAttribute((const void*)gemm_planes_kernel<3, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_lds(128)) == hipSuccess &&
-            hipFuncSetAttribute((const void*)gemm_planes_kernel<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_lds(128)) == hipSuccess;
+        bool ok = true;
+        for (int prec = 1; prec <= 3; prec += 2)
+            for (int geo = 0; geo < NGEO; ++geo)
+                ok = ok && hipFuncSetAttribute(gemm_planes_kernel_ptr(prec, geo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_lds(geo)) == hipSuccess;
+        for (int geo = 0; geo < NQGEO; ++geo)
+            ok = ok && hipFuncSetAttribute(q8_kernel_ptr(geo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q8_lds(geo)) == hipSuccess;
         if (!ok) {
             set_error("gemm_planes_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
             return SLNLP_ERR_LAUNCH;
@@ -573,15 +812,15 @@ static int check_plane_job(const slnlp_gemm_args& a) {
     return 0;
 }
 
-// split-K scratch: arrival counters, then per job its partial tiles [tile][split][TILE x TILE] and row sums [tile_y][split][TILE].
-// Sized for whichever tile the launch may take (dimensions rounded up to 128 cover both).
+// split-K scratch: arrival counters, then per job its partial tiles [tile][split][bm x bn] and row sums [tile_y][split][bm].
+// Sized for whichever geometry the launch may take (M rounded up to 256, N to 128 cover all of them).
 size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
     size_t floats = 0;
     for (int i = 0; i < njobs; ++i) {
         const int nks = split_k ? split_k[i] : 1;
         if (nks <= 1) continue;
-        const size_t n128 = (size_t)ceil_div(jobs[i].N, 128) * 128, m128 = (size_t)ceil_div(jobs[i].M, 128) * 128;
-        floats += n128 * m128 * nks + m128 * nks;
+        const size_t n128 = (size_t)ceil_div(jobs[i].N, 128) * 128, m256 = (size_t)ceil_div(jobs[i].M, 256) * 256;
+        floats += n128 * m256 * nks + m256 * nks;
     }
     return GROUP_COUNTERS * sizeof(int) + floats * sizeof(float);
 }
@@ -591,15 +830,13 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
     SLNLP_CHECK_ARG(jobs && njobs >= 1 && njobs <= MAX_JOBS, "gemm_group: 1..%d jobs", MAX_JOBS);
     PlaneGroupParams P;
     P.njobs = njobs;
-    const int T = plane_tile_for(jobs, split_k, njobs);
+    const int geo = plane_geo_for(jobs, split_k, njobs);
     int blocks = 0, ctr = 0;
     size_t off = GROUP_COUNTERS * sizeof(int);
     for (int i = 0; i < njobs; ++i) {
         const slnlp_gemm_args& a = jobs[i];
         SLNLP_TRY(check_plane_job(a));
-        // fp8 jobs run inside the split-bf16 kernel's launch (its 64 KiB of LDS is their 4-stage ring); single-pass bf16 not
-        SLNLP_CHECK_ARG((a.precision == 8 ? 3 : a.precision) == (jobs[0].precision == 8 ? 3 : jobs[0].precision),
-                        "gemm_group: jobs of one launch share the precision");
+        SLNLP_CHECK_ARG(a.precision == jobs[0].precision, "gemm_group: jobs of one launch share the precision");
         PlaneJob& j = P.job[i];
         j.a = a;
         j.drop_thr = dropout_threshold(a.drop_p);
@@ -611,8 +848,8 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
                     (!a.C_hi || (a.ldc_p % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C_hi) & 7) == 0 &&
                                  (!a.C_lo || (reinterpret_cast<uintptr_t>(a.C_lo) & 7) == 0)));
         if (a.precision == 8) SLNLP_CHECK_ARG(!split_k || split_k[i] <= 1, "gemm_group: fp8 jobs do not split K");
-        j.tiles_x = ceil_div(a.N, T);
-        j.tiles_y = ceil_div(a.M, T);
+        j.tiles_x = ceil_div(a.N, GEO[geo].bn);
+        j.tiles_y = ceil_div(a.M, GEO[geo].bm);
         const int ktiles = ceil_div(a.K, PT);
         int nks = split_k ? split_k[i] : 1;
         if (nks < 1 || splitk_mode() == 1) nks = 1;          // (probe mode 1: no split-K at all)
@@ -629,24 +866,37 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
             j.counters = reinterpret_cast<int*>(scratch) + ctr;
             ctr += tiles;
             j.part = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + off);
-            // region sizes do not depend on the tile (dimensions rounded up to 128): a merged launch may re-tile the job
-            const size_t n128 = (size_t)ceil_div(a.N, 128) * 128, m128 = (size_t)ceil_div(a.M, 128) * 128;
-            off += n128 * m128 * nks * sizeof(float);
+            // region sizes do not depend on the geometry (M rounded up to 256, N to 128): a merged launch may re-tile the job
+            const size_t n128 = (size_t)ceil_div(a.N, 128) * 128, m256 = (size_t)ceil_div(a.M, 256) * 256;
+            off += n128 * m256 * nks * sizeof(float);
             j.part_rs = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + off);
-            off += m128 * nks * sizeof(float);
+            off += m256 * nks * sizeof(float);
             SLNLP_CHECK_ARG(off <= scratch_bytes, "gemm_group: scratch too small (%zu > %zu bytes)", off, scratch_bytes);
         }
         blocks += tiles * nks;
     }
     SLNLP_TRY(gemm_planes_init());
-    const int kprec = jobs[0].precision == 8 ? 3 : jobs[0].precision;
-    if (recording())
-        return record_op(gemm_planes_kernel_ptr(kprec, T), dim3(blocks), dim3(PTHREADS), plane_lds(T), REC_PLANE_GROUP, &P, sizeof(P), "gemm_planes");
+    const void* fn = gemm_planes_kernel_ptr(jobs[0].precision, geo);
+    size_t lds = plane_lds(geo);
+    if (jobs[0].precision == 8) {        // fp8 launch: its own kernel and geometries; re-tile the jobs for the one it takes
+        const int qg = q8_geo_auto(P.job, njobs);
+        blocks = 0;
+        for (int i = 0; i < njobs; ++i) {
+            PlaneJob& j = P.job[i];
+            j.tiles_x = ceil_div(j.a.N, QGEO[qg].bn);
+            j.tiles_y = ceil_div(j.a.M, QGEO[qg].bm);
+            j.block_begin = blocks;
+            blocks += j.tiles_x * j.tiles_y;
+        }
+        fn = q8_kernel_ptr(qg);
+        lds = q8_lds(qg);
+    }
+    if (recording()) return record_op(fn, dim3(blocks), dim3(PTHREADS), lds, REC_PLANE_GROUP, &P, sizeof(P), "gemm_planes");
     void* args[3];
     const PlaneJob* tab = nullptr;
     const int* bmap = nullptr;
     args[0] = &P; args[1] = &tab; args[2] = &bmap;
-    if (hipLaunchKernel(gemm_planes_kernel_ptr(kprec, T), dim3(blocks), dim3(PTHREADS), args, plane_lds(T), s) != hipSuccess) {
+    if (hipLaunchKernel(fn, dim3(blocks), dim3(PTHREADS), args, lds, s) != hipSuccess) {
         set_error("gemm_planes: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
     }
@@ -655,21 +905,46 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
 
 // A recorded job re-tiled for a merged launch (lockstep.hip): only the tile grid changes -- the K partition (nks) and the
 // scratch regions stay, so every output element is accumulated in the same order and the result keeps its bits.
-void plane_job_retile(PlaneJob& j, int tile) {
-    j.tiles_x = ceil_div(j.a.N, tile);
-    j.tiles_y = ceil_div(j.a.M, tile);
+void plane_job_retile(PlaneJob& j, int geo) {
+    j.tiles_x = ceil_div(j.a.N, GEO[geo].bn);
+    j.tiles_y = ceil_div(j.a.M, GEO[geo].bm);
 }
-size_t plane_lds_bytes(int tile) { return plane_lds(tile); }
-int plane_kernel_precision(const void* fn) {
-    return (fn == (const void*)gemm_planes_kernel<3, 64> || fn == (const void*)gemm_planes_kernel<3, 128>) ? 3 : 1;
+// The concatenated job list of a merged launch (lockstep.hip): pick the geometry for ALL its tiles and re-tile every job.
+// `recorded_fn` is the kernel one fit's own launch recorded (it tells the family: fp8, split-bf16 or single-pass bf16).
+void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, const void** fn, size_t* lds) {
+    bool q8 = false;
+    for (int geo = 0; geo < NQGEO; ++geo) q8 = q8 || recorded_fn == q8_kernel_ptr(geo);
+    if (q8) {
+        const int qg = q8_geo_auto(jobs, njobs);
+        for (int i = 0; i < njobs; ++i) {
+            jobs[i].tiles_x = ceil_div(jobs[i].a.N, QGEO[qg].bn);
+            jobs[i].tiles_y = ceil_div(jobs[i].a.M, QGEO[qg].bm);
+        }
+        *fn = q8_kernel_ptr(qg);
+        *lds = q8_lds(qg);
+        return;
+    }
+    int prec = 1;
+    for (int geo = 0; geo < NGEO; ++geo)
+        if (recorded_fn == gemm_planes_kernel_ptr(3, geo)) prec = 3;
+    long units = 0;
+    for (int i = 0; i < njobs; ++i) units += plane_units128(jobs[i].a, jobs[i].nks);
+    const int geo = plane_geo_auto(units, false);
+    for (int i = 0; i < njobs; ++i) plane_job_retile(jobs[i], geo);
+    *fn = gemm_planes_kernel_ptr(prec, geo);
+    *lds = plane_lds(geo);
 }
-int plane_tile_forced() { return g_plane_tile.load(std::memory_order_relaxed); }
-int plane_big_tile_min_units() { return BIG_TILE_MIN_UNITS; }
 
-const void* gemm_planes_kernel_ptr(int precision, int tile) {
-    if (tile == 128) return precision == 3 ? (const void*)gemm_planes_kernel<3, 128> : (const void*)gemm_planes_kernel<1, 128>;
-    return precision == 3 ? (const void*)gemm_planes_kernel<3, 64> : (const void*)gemm_planes_kernel<1, 64>;
+template <int NSPLIT>
+static const void* kernel_of(int geo) {
+    switch (geo) {
+        case 1: return (const void*)gemm_planes_kernel<NSPLIT, 1>;
+        case 2: return (const void*)gemm_planes_kernel<NSPLIT, 2>;
+        case 3: return (const void*)gemm_planes_kernel<NSPLIT, 3>;
+        default: return (const void*)gemm_planes_kernel<NSPLIT, 0>;
+    }
 }
+const void* gemm_planes_kernel_ptr(int precision, int geo) { return precision == 1 ? kernel_of<1>(geo) : kernel_of<3>(geo); }
 
 int gemm_planes(const slnlp_gemm_args& a, hipStream_t s) { return gemm_planes_group(&a, nullptr, 1, nullptr, 0, s); }
 
@@ -749,11 +1024,20 @@ extern "C" int slnlp_quant_rows_fp8(const float* x, int64_t ld, int R, int K, ui
 }
 
 extern "C" int slnlp_set_plane_tile(int tile) {
-    if (tile != 0 && tile != 64 && tile != 128) {
-        slnlp::set_error("set_plane_tile: %d (0 = automatic, 64 or 128)", tile);
+    if (tile != 0 && slnlp::geo_of_knob(tile) < 0) {
+        slnlp::set_error("set_plane_tile: %d (0 = automatic, 64, 128, 12832 = 128 x 128 with 32-k stages, 256128 = 256 x 128)", tile);
         return SLNLP_ERR_INVALID_ARG;
     }
-    slnlp::g_plane_tile.store(tile, std::memory_order_relaxed);
+    slnlp::g_plane_geo.store(slnlp::geo_of_knob(tile), std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int slnlp_set_fp8_tile(int tile) {
+    if (tile != 0 && slnlp::q8_geo_of_knob(tile) < 0) {
+        slnlp::set_error("set_fp8_tile: %d (0 = automatic, 64, 128, 256128 = 256 x 128, 256256 = 256 x 256)", tile);
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    slnlp::g_q8_geo.store(slnlp::q8_geo_of_knob(tile), std::memory_order_relaxed);
     return 0;
 }
 

@@ -95,7 +95,9 @@ struct PackOf<void (*)(T...)> {
         typename PO::type a;                                                                                         \
         if (tab) a = tab[blockIdx.z];                                                                                \
         else a = a0;                                                                                                 \
+        ::slnlp::probe_kernel_begin();                                                                               \
         PO::template call<&body>(a, typename PO::seq{});                                                             \
+        ::slnlp::probe_kernel_end();                                                                                 \
     }
 
 // ------------------------------------------------------------------ recording ----

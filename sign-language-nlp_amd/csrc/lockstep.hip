@@ -193,35 +193,19 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
         } else if (o0.kind == REC_PLANE_GROUP) {
             std::vector<PlaneJob> jobs;
             std::vector<int> map;
-            // The merged launch has K times the tiles of a solo one: once it holds enough 128 x 128 tiles to fill the chip a
-            // few times it takes them (half the operand bytes per FLOP through L2 -> LDS, gemm_planes.hip).  The K partition of
-            // every job stays, so each fit's results keep the bits of its solo launch whatever the tile.
-            int T = 64;
-            {
-                long units128 = 0;
-                bool fp8 = false;
-                for (int f = 0; f < K; ++f) {
-                    const PlaneGroupParams* P = reinterpret_cast<const PlaneGroupParams*>(recs[f].ops[i].args.data());
-                    for (int j = 0; j < P->njobs; ++j) {
-                        fp8 = fp8 || P->job[j].variant == 3;
-                        units128 += (long)((P->job[j].a.M + 127) / 128) * ((P->job[j].a.N + 127) / 128) * P->job[j].nks;
-                    }
-                }
-                const int forced = plane_tile_forced();
-                if (!fp8) T = forced ? forced : (units128 >= plane_big_tile_min_units() ? 128 : 64);
-            }
-            m.fn = gemm_planes_kernel_ptr(plane_kernel_precision(o0.fn), T);
-            m.lds = plane_lds_bytes(T);
             for (int f = 0; f < K; ++f) {
                 const PlaneGroupParams* P = reinterpret_cast<const PlaneGroupParams*>(recs[f].ops[i].args.data());
-                for (int j = 0; j < P->njobs; ++j) {
-                    PlaneJob job = P->job[j];
-                    plane_job_retile(job, T);
-                    const int blocks = job.tiles_x * job.tiles_y * job.nks, padded = (blocks + 7) & ~7;
-                    job.block_begin = (int)map.size();
-                    map.insert(map.end(), padded, (int)jobs.size());
-                    jobs.push_back(job);
-                }
+                for (int j = 0; j < P->njobs; ++j) jobs.push_back(P->job[j]);
+            }
+            // The merged launch has K times the tiles of a solo one: once it holds enough large tiles to fill the chip a few
+            // times it takes them (fewer operand bytes per FLOP through L2 -> LDS, gemm_planes.hip).  The K partition of every
+            // job stays, so each fit's results keep the bits of its solo launch whatever the geometry.
+            plane_merge_geometry(o0.fn, jobs.data(), (int)jobs.size(), &m.fn, &m.lds);
+            for (size_t j = 0; j < jobs.size(); ++j) {
+                PlaneJob& job = jobs[j];
+                const int blocks = job.tiles_x * job.tiles_y * job.nks, padded = (blocks + 7) & ~7;
+                job.block_begin = (int)map.size();
+                map.insert(map.end(), padded, (int)j);
             }
             m.tab = (void*)(blob.add(jobs.data(), jobs.size() * sizeof(PlaneJob)) + 1);
             m.blockmap = (int*)(blob.add(map.data(), map.size() * sizeof(int)) + 1);

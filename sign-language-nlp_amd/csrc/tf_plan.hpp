@@ -305,7 +305,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     }
     {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
         // (the weight gradients' partial tiles: [3E or F] x [E or F] outputs rounded up to the 128 x 128 tile, x MAX_SPLITK)
-        const size_t nx = ((E > F ? E : F) + 127) / 128 * 128, ny = ((3 * E > F ? 3 * E : F) + 127) / 128 * 128;
+        const size_t nx = ((E > F ? E : F) + 127) / 128 * 128, ny = ((3 * E > F ? 3 * E : F) + 255) / 256 * 256;
         w.gscr_bytes = 16384 + nx * ny * MAX_SPLITK * sizeof(float) + ny * MAX_SPLITK * sizeof(float);
         w.gscr_bytes = (w.gscr_bytes + 255) & ~(size_t)255;
         w.gscr[0] = b.take<char>(w.gscr_bytes);

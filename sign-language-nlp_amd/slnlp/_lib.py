@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libslnlp.so")
+# SLNLP_PROBE_LIB=k: load lib/libslnlp_probe<k>.so instead (tools/probes only: `make PROBE=k` builds it with agent-scope fences
+# around every kernel, csrc/common.hpp); the product never sets it
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib",
+                        f"libslnlp_probe{os.environ['SLNLP_PROBE_LIB']}.so" if os.environ.get("SLNLP_PROBE_LIB") else "libslnlp.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -145,6 +148,7 @@ SIGNATURES = {
     "slnlp_tf_set_destroy_sync": (i32, [vp, i32]),
     "slnlp_set_stream_policy": (i32, [i32]),
     "slnlp_set_plane_tile": (i32, [i32]),
+    "slnlp_set_fp8_tile": (i32, [i32]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),
     "slnlp_tf_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),
     "slnlp_tf_lockstep_destroy": (None, [vp]),

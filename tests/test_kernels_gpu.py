@@ -414,3 +414,84 @@ def test_gemm_group_large_shapes_split_k_and_epilogue(ops):
                                     bias=bias.cuda(), relu=True, resid=R.cuda(), want_planes=True)
     assert rel(out, ref) < 1e-4
     assert rel((hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float())[:M, :N], ref) < 1e-4
+
+
+@pytest.mark.parametrize("knob", [128, 12832, 256128])
+def test_plane_tile_geometries_return_the_bits_of_the_64_tile(ops, knob):
+    """Every tile geometry of the plane GEMM (slnlp_set_plane_tile: 128 x 128 with 64-k or 32-k stages, 256 x 128) accumulates
+    every output element in the order of the 64 x 64 tile -- the K partition is the same -- so a launch may take whichever is
+    fastest (merged lockstep launches do) without changing a bit: all three layouts, ragged edges, bias / ReLU / residual /
+    output planes, split-K with the fused bias-gradient row sums."""
+    from slnlp._lib import load, check
+    def planes(x):
+        xp = torch.zeros(x.shape[0], (x.shape[1] + 3) // 4 * 4); xp[:, :x.shape[1]] = x
+        return ops.split_planes(xp.cuda())
+    def run():
+        outs = []
+        for (M, N, K) in [(300, 200, 128), (2400, 512, 512), (130, 70, 100), (700, 384, 1000)]:
+            A, B, bias, R = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+            Ap, Bp = planes(A), planes(B)
+            if N % 4 == 0:
+                out, (hi, lo) = ops.gemm_planes(Ap, Bp, M=M, N=N, K=K, bias=bias.cuda(), relu=True, resid=R.cuda(), want_planes=True)
+                outs += [out.clone(), hi.clone(), lo.clone()]
+            else:
+                outs.append(ops.gemm_planes(Ap, Bp, M=M, N=N, K=K, bias=bias.cuda()).clone())
+            outs.append(ops.gemm_planes(Ap, planes(B.T.contiguous()), M=M, N=N, K=K, b_kmajor=False).clone())           # dgrad layout
+            rs = torch.empty(M, device="cuda")
+            outs.append(ops.gemm_planes(planes(A.T.contiguous()), planes(B.T.contiguous()), M=M, N=N, K=K, a_kmajor=False, b_kmajor=False,
+                                        rowsum_a=rs).clone())                                                         # wgrad layout
+            outs.append(rs.clone())
+        Mtok, Nout, Kin = 2400, 192, 320
+        dY, X, W = rnd(Mtok, Nout, seed=1), rnd(Mtok, Kin, seed=2), rnd(Nout, Kin, seed=3)
+        dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
+        rs = torch.empty(Nout, device="cuda")
+        jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
+        jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+        scratch = ops.gemm_group([jw, jd], [5, 1])
+        assert int(scratch[:16384].view(torch.int32).abs().max()) == 0
+        outs += [dW.clone(), rs.clone(), dX.clone()]
+        assert rel(dW, dY.double().T @ X.double()) < 2e-4 and rel(dX, dY.double() @ W.double()) < 1e-4 and rel(rs, dY.double().sum(0)) < 1e-4
+        torch.cuda.synchronize()
+        return outs
+    try:
+        check(load().slnlp_set_plane_tile(64), "set_plane_tile")
+        ref = run()
+        check(load().slnlp_set_plane_tile(knob), "set_plane_tile")
+        got = run()
+    finally:
+        load().slnlp_set_plane_tile(0)
+    assert len(ref) == len(got)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), f"output {i} differs between the 64 x 64 tile and geometry {knob}"
+
+
+@pytest.mark.parametrize("knob", [64, 128, 256128, 256256])
+def test_fp8_tile_geometries(ops, knob):
+    """precision 8 on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, every block scale 2^0) at each tile geometry
+    (slnlp_set_fp8_tile): equals the fp64 product of the dequantised operands, the epilogue (per-column weight scale, bias, ReLU,
+    residual, bf16 + fp8 output planes) included, on aligned and ragged shapes; all geometries agree bit for bit."""
+    from slnlp._lib import load, check
+    def run():
+        outs = []
+        for (M, N, K) in [(300, 200, 256), (1000, 512, 1024), (130, 70, 384)]:
+            A, W, bias, R = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+            Aq, sa = ops.quant_rows_fp8(A.cuda())
+            Wq, sw = ops.quant_rows_fp8(W.cuda())
+            Ad, Wd = _e4m3_decode(Aq[:M, :K].cpu()), _e4m3_decode(Wq[:N, :K].cpu())
+            want = torch.relu((Ad @ Wd.T) * sw.cpu().double()[None, :] + bias.double()) + R.double()
+            got, cq = ops.gemm_fp8(Aq, Wq, M=M, N=N, K=K, col_scale=sw, bias=bias.cuda(), relu=True, resid=R.cuda(), want_q8=True)
+            assert rel(got.cpu().double(), want) < 2e-4, (M, N, K)
+            back = _e4m3_decode(cq[:M, :N].cpu())
+            assert float((back - want.clamp(-448, 448)).abs().max() / want.abs().max()) < 2 ** -4
+            assert int(cq[M:].to(torch.int32).abs().max()) == 0                     # padding untouched
+            outs += [got.clone(), cq.clone()]
+        return outs
+    try:
+        check(load().slnlp_set_fp8_tile(64), "set_fp8_tile")
+        ref = run()
+        check(load().slnlp_set_fp8_tile(knob), "set_fp8_tile")
+        got = run()
+    finally:
+        load().slnlp_set_fp8_tile(0)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), f"output {i} differs between fp8 geometries 64 and {knob}"

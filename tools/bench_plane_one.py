@@ -1,0 +1,23 @@
+"""ONE plane-GEMM launch shape at ONE tile geometry, a few launches -- the thing to run under rocprofv3 --pmc.
+    python tools/bench_plane_one.py <tokens> <n_out> <k_in> <split> <tile knob> [launches]"""
+import sys, torch
+sys.path.insert(0, "sign-language-nlp_amd")
+from slnlp import ops
+from slnlp._lib import load, check
+Mtok, Nout, Kin, split, tile = [int(v) for v in sys.argv[1:6]]
+n = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+g = torch.Generator().manual_seed(0)
+dY, X, W = [torch.randn(*s, generator=g).cuda() for s in ((Mtok, Nout), (Mtok, Kin), (Nout, Kin))]
+dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+rs = torch.empty(Nout, device="cuda")
+jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
+jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+check(load().slnlp_set_plane_tile(tile), "set_plane_tile")
+scr = ops.gemm_group([jw, jd], [split, 1])
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(n): ops.gemm_group([jw, jd], [split, 1], scr)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / n * 1e3
+print(f"tokens {Mtok} n_out {Nout} k_in {Kin} split {split} tile {tile}: {t:.1f} us/launch, {2 * 2.0 * Mtok * Nout * Kin / t / 1e6:.1f} TFLOP/s")

@@ -34,7 +34,7 @@ def case(name, Mtok, Nout, Kin, split, copies=1, check_ref=False):
     scr = ops.gemm_group(jobs, splits)
     flops = copies * 2 * 2.0 * Mtok * Nout * Kin
     res = {}
-    for tile in (64, 128):
+    for tile in TILES:
         check(load().slnlp_set_plane_tile(tile), "set_plane_tile")
         for o in outs: o.fill_(float("nan"))
         ops.gemm_group(jobs, splits, scr)
@@ -46,20 +46,26 @@ def case(name, Mtok, Nout, Kin, split, copies=1, check_ref=False):
             e = max(float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(res[tile][:3], refs))
             err = f"  rel err vs fp64 {e:.1e}"
         cd = lambda a, b: (a + b - 1) // b
-        units = copies * (cd(Nout, tile) * cd(Kin, tile) * split + cd(Mtok, tile) * cd(Kin, tile))
-        print(f"{name:34s} tile {tile:3d}: {units:5d} workgroups {t:8.1f} us  {flops / t / 1e6:7.1f} TFLOP/s{err}", flush=True)
-    same = all(torch.equal(a, b) for a, b in zip(res[64], res[128]))
+        bm, bn = DIMS[tile]
+        units = copies * (cd(Nout, bm) * cd(Kin, bn) * split + cd(Mtok, bm) * cd(Kin, bn))
+        print(f"{name:34s} tile {tile:6d}: {units:5d} workgroups {t:8.1f} us  {flops / t / 1e6:7.1f} TFLOP/s{err}", flush=True)
+    same = all(torch.equal(a, b) for tile in TILES[1:] for a, b in zip(res[TILES[0]], res[tile]))
     print(f"{'':34s} tiles bit-identical: {same}", flush=True)
     check(load().slnlp_set_plane_tile(0), "set_plane_tile")
     return same
 
 keep = []
-quick = len(sys.argv) > 1
+TILES = (64, 128, 12832, 256128)            # slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages), 128 x 128 (32-k x 4), 256 x 128 (32-k x 3)
+DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128), 256128: (256, 128)}
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+big_only = len(sys.argv) > 1 and sys.argv[1] == "big"
 ok = True
-ok &= case("cfg2 dgrad+wgrad E512", 2400, 512, 512, 3, check_ref=True)
-ok &= case("cfg2 x2 fits (one launch)", 2400, 512, 512, 3, copies=2)
-ok &= case("cfg2 in_proj grads 1536", 2400, 1536, 512, 3)
-ok &= case("ragged 1000 x 320 x 192", 1000, 320, 192, 2, check_ref=True)
+if not big_only:
+    ok &= case("cfg2 dgrad+wgrad E512", 2400, 512, 512, 3, check_ref=True)
+    ok &= case("cfg2 x2 fits (one launch)", 2400, 512, 512, 3, copies=2)
+    ok &= case("cfg2 in_proj grads 1536", 2400, 1536, 512, 3)
+    ok &= case("ragged 1000 x 320 x 192", 1000, 320, 192, 2, check_ref=True)
+    ok &= case("ragged 300 x 72 x 200 (K 300)", 300, 72, 200, 2, check_ref=True)
 if not quick:
     ok &= case("tokens x4 (9600) E512", 9600, 512, 512, 8)
     ok &= case("tokens x16 (38400) E512", 38400, 512, 512, 8)

@@ -18,6 +18,9 @@
 // load_mode  0: plain 16-byte global loads                           1: global_load_lds (LDS-DMA) then ds_read
 // streams    1 (default): everything on one stream; n > 1: n independent producer/consumer chains on n streams of this
 //            process (each with its own buffers) -- the in-process version of running n copies.
+// rows       rows of the buffer (default 2400)
+// rmw        n > 0: n read-modify-write kernels (X += 1, ONE workgroup per row, like the d-memory accumulation over the decoder
+//            layers) between producer and consumer; the consumer expects f + n.
 //
 // Exit code 0 and "mismatches 0" = this stack keeps a producer's output visible to the next kernel of the same stream while
 // other queues are busy; anything else is a reproducer that needs none of this library's kernels.
@@ -36,7 +39,10 @@
         }                                                                              \
     } while (0)
 
-constexpr int ROWS = 2400, COLS = 512, TILE = 64;
+constexpr int COLS = 512, TILE = 64;
+static int ROWS_H = 2400;                 // rows of X (argv[5]): 2400 = the cfg2 activations (4.9 MB, cycles through the 4 MiB L2s);
+                                          // 128 = 256 KB, stays resident in every XCD's L2 between iterations
+__constant__ int ROWS;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef __attribute__((address_space(1))) const void* glb_vp;
 
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512) void producer(float* __restrict__ X, unsigned 
 // 4 waves per workgroup, one row per wave (the LayerNorm kernels' geometry)
 template <int LOAD, bool PLANES>
 __global__ __launch_bounds__(256) void consumer(const float* __restrict__ X, const unsigned short* __restrict__ P, unsigned it,
-                                                unsigned* __restrict__ count, Bad* __restrict__ bad, float* __restrict__ sink) {
+                                                unsigned* __restrict__ count, Bad* __restrict__ bad, float* __restrict__ sink, unsigned add) {
     __shared__ __attribute__((aligned(16))) float stage[4][COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x * 4 + wave;
     if (row >= ROWS) return;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void consumer(const float* __restrict__ X, con
         }
         const float f[4] = {v.x, v.y, v.z, v.w};
         for (int e = 0; e < 4; ++e) {
-            const unsigned want = fval(it, row, c + e), got = (unsigned)f[e];
+            const unsigned want = fval(it, row, c + e) + add, got = (unsigned)f[e];
             acc += f[e];
             if (got != want || f[e] != (float)want) {
                 const unsigned k = atomicAdd(count, 1u);
@@ -121,6 +127,14 @@ __global__ __launch_bounds__(256) void consumer(const float* __restrict__ X, con
     if (lane == 0) sink[row] = acc;     // a store of the consumer's own (like dx), so it is not a pure reader
 }
 
+// one workgroup per row: X[row][:] += 1 (and the planes' low halves follow): a different row -> CU / XCD map than the producer's
+__global__ __launch_bounds__(256) void rmw(float* __restrict__ X) {
+    const int row = blockIdx.x, c = threadIdx.x * 2;
+    float2 v = *reinterpret_cast<float2*>(X + (long)row * COLS + c);
+    v.x += 1.f; v.y += 1.f;
+    *reinterpret_cast<float2*>(X + (long)row * COLS + c) = v;
+}
+
 struct Chain {
     hipStream_t st;
     float *X, *sink;
@@ -133,6 +147,10 @@ int main(int argc, char** argv) {
     const int store_mode = argc > 1 ? atoi(argv[1]) : 0, load_mode = argc > 2 ? atoi(argv[2]) : 0;
     const double seconds = argc > 3 ? atof(argv[3]) : 5.0;
     const int nstreams = argc > 4 ? atoi(argv[4]) : 1;
+    ROWS_H = argc > 5 ? atoi(argv[5]) : 2400;
+    const int nrmw = argc > 6 ? atoi(argv[6]) : 0;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(ROWS), &ROWS_H, sizeof(int)));
+    const int ROWS = ROWS_H;
     std::vector<Chain> ch(nstreams);
     for (Chain& c : ch) {
         CK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
@@ -156,12 +174,13 @@ int main(int argc, char** argv) {
                 if (store_mode == 0) hipLaunchKernelGGL(producer<0>, dim3(pgrid), dim3(512), 0, c.st, c.X, c.P, it);
                 else if (store_mode == 1) hipLaunchKernelGGL(producer<1>, dim3(pgrid), dim3(512), 0, c.st, c.X, c.P, it);
                 else hipLaunchKernelGGL(producer<2>, dim3(pgrid), dim3(512), 0, c.st, c.X, c.P, it);
+                for (int k2 = 0; k2 < nrmw; ++k2) hipLaunchKernelGGL(rmw, dim3(ROWS), dim3(256), 0, c.st, c.X);
                 if (store_mode == 2) {
-                    if (load_mode == 1) hipLaunchKernelGGL((consumer<1, true>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink);
-                    else hipLaunchKernelGGL((consumer<0, true>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink);
+                    if (load_mode == 1) hipLaunchKernelGGL((consumer<1, true>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink, (unsigned)nrmw);
+                    else hipLaunchKernelGGL((consumer<0, true>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink, (unsigned)nrmw);
                 } else {
-                    if (load_mode == 1) hipLaunchKernelGGL((consumer<1, false>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink);
-                    else hipLaunchKernelGGL((consumer<0, false>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink);
+                    if (load_mode == 1) hipLaunchKernelGGL((consumer<1, false>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink, (unsigned)nrmw);
+                    else hipLaunchKernelGGL((consumer<0, false>), dim3(cgrid), dim3(256), 0, c.st, c.X, c.P, it, c.count, c.bad, c.sink, (unsigned)nrmw);
                 }
             }
         }
@@ -181,6 +200,6 @@ int main(int argc, char** argv) {
                        (b[k].c >> 31) ? " (plane)" : "", b[k].got, b[k].want);
         }
     }
-    printf("store_mode %d load_mode %d streams %d: %u iterations, mismatches %u\n", store_mode, load_mode, nstreams, it, total);
+    printf("store_mode %d load_mode %d streams %d rows %d rmw %d: %u iterations, mismatches %u\n", store_mode, load_mode, nstreams, ROWS, nrmw, it, total);
     return total ? 1 : 0;
 }
