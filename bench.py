@@ -114,7 +114,7 @@ def dominant_kernel_roofline(c, precision, dev, workload):
     flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the 3 split-bf16 MFMA passes are not counted)
     tf = flops / (us * 1e-6) / 1e12
     blocks = tw * split + td
-    return {"kernel": f"gemm_planes_kernel<{precision}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {blocks} workgroups",
+    return {"kernel": f"gemm_planes_kernel<{precision}, 64x64> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {blocks} workgroups",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}> x{blocks}"),
             "us_per_launch_hip_events": round(us, 2), "us_per_launch_rocprof": rocprof_kernel_times(workload), "flops_per_launch": flops,
@@ -123,8 +123,40 @@ def dominant_kernel_roofline(c, precision, dev, workload):
                     "MFMA passes are not counted; bytes = operand planes (hi+lo) read once + fp32 results + result planes"}
 
 
-FP8_DENSE_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: ~5 PF dense fp8 (reached only by the block-scaled K=128 MFMA; the plain
-                                  # v_mfma_f32_16x16x32_fp8_fp8 this kernel issues runs at the bf16 rate, 2.5 PF)
+FP8_DENSE_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: ~5 PF dense fp8, the rate of the block-scaled K=128 MFMA
+                                  # (v_mfma_scale_f32_16x16x128_f8f6f4) the precision-8 kernel issues since round 3
+
+
+def large_launch_roofline(precision, dev):
+    """The same plane-GEMM kernel on a launch large enough to fill the chip many times over: the dgrad + wgrad group of
+    configs[4]'s in_proj ([16384 x 3072] dY, W [3072 x 1024]; 2176 workgroups at the 128 x 128 tile the launch takes by itself).
+    What a merged lockstep launch of many fits looks like to the kernel; reported beside the cfg2 launch, never instead of it."""
+    from slnlp import ops
+    M, Nout, Kin, split = 16384, 3072, 1024, 6
+    g = torch.Generator().manual_seed(0)
+    dY, X, W = [torch.randn(*sh, generator=g).to(dev) for sh in ((M, Nout), (M, Kin), (Nout, Kin))]
+    dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+    rs = torch.empty(Nout, device=dev)
+    jw, _ = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=precision)
+    jd, _ = ops.plane_job(dYp, Wp, M=M, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=precision)
+    scr = ops.gemm_group([jw, jd], [split, 1])
+    for _ in range(3):
+        ops.gemm_group([jw, jd], [split, 1], scr)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.gemm_group([jw, jd], [split, 1], scr)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    flops = 2.0 * 2 * M * Nout * Kin
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": f"gemm_planes_kernel<{precision}, 128x128> dgrad+wgrad group [{M}x{Nout}]x[{Nout}x{Kin}], wgrad split-K {split} (configs[4] in_proj)",
+            "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
+            "traffic": None, "us_per_launch_hip_events": round(us, 1), "flops_per_launch": flops,
+            "mfma_pipe_frac": round(3 * tf / BF16_DENSE_PEAK_TFLOPS, 3),
+            "note": "algorithmic FLOPs (the 3 split-bf16 MFMA passes are not counted: the MFMA pipe itself is busy 3x this fraction)"}
 
 
 def fp8_kernel_roofline(c, dev):
@@ -149,11 +181,12 @@ def fp8_kernel_roofline(c, dev):
     us = e0.elapsed_time(e1) / n * 1e3
     flops = 2.0 * M * 3 * E * E
     tf = flops / (us * 1e-6) / 1e12
-    return {"kernel": f"gemm_planes_kernel fp8 tile, in_proj [{M}x{E}]x[{3 * E}x{E}]^T, {((M + 63) // 64) * (3 * E // 64)} workgroups",
+    return {"kernel": f"gemm_q8_kernel (block-scaled fp8 MFMA), in_proj [{M}x{E}]x[{3 * E}x{E}]^T",
             "bound": "mfma", "achieved": round(tf, 1), "peak": FP8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP8_DENSE_PEAK_TFLOPS, 4),
             "traffic": None, "us_per_launch_hip_events": round(us, 2), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 1.0 * (M * E + 3 * E * E) + 4.0 * M * 3 * E,
-            "note": "e4m3 operand planes (1 B/element) read once + fp32 result; plain fp8 MFMA (bf16 issue rate), priced against the 5 PF dense fp8 peak"}
+            "note": "e4m3 operand planes (1 B/element) read once + fp32 result; v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, "
+                    "priced against the 5 PF dense fp8 peak; the fp32 result alone is 4 B per 2K FLOP of output traffic"}
 
 
 def concurrent_fits(c, precision, dev, ks=(4, 8, 16), steps=30):
@@ -528,6 +561,8 @@ def main():
                     out["roofline_fp8"] = fp8_kernel_roofline(c, dev)
             if dk:
                 out["roofline"] = dk
+                with torch.cuda.stream(stream):
+                    out["roofline_large_launch"] = large_launch_roofline(3 if args.precision == 8 else args.precision, dev)
         if world == 1 and not args.no_cpu_baseline and args.precision != 8:
             out["concurrent_fits"] = concurrent_fits(c, args.precision, dev)
         out.setdefault("roofline", dict(out["roofline_step"]))   # RNN workloads: no single dominant GEMM, the step is the unit

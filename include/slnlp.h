@@ -103,13 +103,12 @@ int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
  * slnlp_gemm_group_scratch_bytes(...) bytes, 16-byte aligned, its first 16 KiB zero before the first use (the
  * library leaves them zero); one scratch buffer must not serve two launches that may run concurrently. */
 int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs);
-/* Output tile of the plane-GEMM launches: 0 = automatic (a larger tile once a launch holds enough of them -- merged lockstep
- * launches, the configs[4] shapes -- else 64 x 64); forced: 64, 128 (128 x 128, 64-k stages), 12832 (128 x 128, 32-k stages),
- * 256128 (256 x 128).  A tuning / test knob: results do not depend on it (the K partition, hence every element's accumulation
- * order, is the same for every geometry). */
+/* Output tile of the plane-GEMM launches: 0 = automatic (128 x 128 once a launch holds >= 200 of them -- merged lockstep
+ * launches, the configs[4] shapes, cfg2's in_proj gradients -- else 64 x 64); forced: 64, 128 (128 x 128, 64-k stages),
+ * 12832 (128 x 128, 32-k stages).  A tuning / test knob: results do not depend on it (the K partition, hence every element's
+ * accumulation order, is the same for every geometry). */
 int slnlp_set_plane_tile(int tile);
-/* the same knob for precision-8 launches: 0 = automatic (the widest tile that still gives the launch >= 512 workgroups), 64,
- * 128, 256128 (256 x 128) or 256256 (256 x 256) */
+/* the same knob for precision-8 launches: 0 = automatic (128 x 128 once the launch holds >= 512 of them), 64 or 128 */
 int slnlp_set_fp8_tile(int tile);
 int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
                      int64_t scratch_bytes, void* stream);

@@ -79,17 +79,7 @@ __device__ __forceinline__ f32x4 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 b
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
-// reductions over the 16 lanes that hold one accumulator row
-__device__ __forceinline__ float row16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// reductions over the 16 lanes that hold one accumulator row: row16_max / row16_sum of common.hpp (DPP, no LDS crossbar)
 // keep flags of rows row0..row0+3 at column col of a dropout site (one Philox call when row0 % 4 == 0)
 __device__ __forceinline__ unsigned keep_mask4(const unsigned long long* rng, int site, unsigned row0, unsigned col,
                                                unsigned thr) {
@@ -418,8 +408,8 @@ __device__ __forceinline__ float xrow_dot(const float* __restrict__ T, const flo
         const float4 v = *reinterpret_cast<const float4*>(vec + c0 + 4 * u);
         a += t.x * v.x + t.y * v.y + t.z * v.z + t.w * v.w;
     }
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
+    a += dpp_mov<DPP_XOR1>(a);
+    a += dpp_mov<DPP_XOR2>(a);
     return a;
 }
 // sum_j w[j] * T[j][d] for d = tid & 63: rows split over the 4 waves, combined through red[4][64]

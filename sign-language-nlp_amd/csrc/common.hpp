@@ -175,15 +175,44 @@ __device__ __forceinline__ void store_planes4(const PlaneOut& po, long idx, floa
 }
 
 // ------------------------------------------------------------- wave ops -----
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions WITHOUT the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 on gfx950 -- an LDS-unit
+// instruction -- and round 3's probes (tools/probes/probe_victim.py) found the one kind of kernel whose
+// result changed when kernels of another hardware queue ran on the same CUs to be the ones reducing through it (layernorm_bwd on
+// CONSTANT inputs: 85 % of the runs differ beside two other fits, 4-lane and whole-row patterns that only a wrong shuffle
+// result explains; the GEMMs beside it, which reduce nothing across lanes, never differ).  These use DPP row operations inside a
+// row of 16 lanes and v_readlane across the four rows: VALU only.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {      // every lane has a valid source for the controls used here
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;          // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;   // lane i <-> 7 - i within 8 / 15 - i within 16
+__device__ __forceinline__ float lane_bcast(float v, int lane) {   // `lane` wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// sum / max over the 16 lanes of a DPP row (lanes 16k .. 16k+15); every lane of the row gets the result
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);      // quads hold one value each: mirroring inside 8 lanes swaps the two quads
+    v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
     return v;
+}
+// over the whole wave (all 64 lanes active); every lane gets the result
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
 }  // namespace slnlp

@@ -85,7 +85,7 @@ __device__ __forceinline__ void embed_bwd_chunk_body(const long* __restrict__ id
         my_id = (v < 0 || v >= V) ? -1 : (int)v;
     }
     const float ik = 1.f / (1.f - drop_p);
-    const int id = __shfl(my_id, t, 64);
+    const int id = __builtin_amdgcn_readlane(my_id, __builtin_amdgcn_readfirstlane(t));   // t is block-uniform
     const unsigned long long mask = __ballot(my_id == id && id >= 0);
     const bool first = id >= 0 && (mask & ((1ull << t) - 1ull)) == 0ull;
     if (threadIdx.x == 0) pid[m] = first ? id : -1;
@@ -294,86 +294,98 @@ __device__ __forceinline__ void layernorm_fwd_body(const float* __restrict__ x,
 }
 SLNLP_ZKERNEL(layernorm_fwd_kernel, 256, layernorm_fwd_body)
 
-__device__ __forceinline__ void layernorm_bwd_body(
+// U = float4 slots per lane that can be live (E <= 256 * U), RB = rows of a group whose loads are in flight together.
+// REGISTER BUDGET: U * RB <= 8.  The first version kept 4 rows x 4 slots live for every E: 256 VGPRs + 91 AGPRs -- the only kernel
+// of the library above 256 registers -- and exactly that kernel returned wrong rows whenever waves of another hardware queue
+// shared its SIMDs (constant inputs, 44 % of the runs differ beside two other fits, never alone; the GEMMs
+// beside it never differ).  Same rows per wave, same row order in every sum: results are bit-identical to that version.
+template <int U, int RB>
+__device__ __forceinline__ void layernorm_bwd_rows(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
     float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng, float* __restrict__ partial, PlaneOut po_dx, PlaneOut po_drop, int gs) {
-    // gs = 4 (many rows): one wave per group of 4 CONSECUTIVE rows: the loads of all four rows are issued together (one memory round trip
-    // instead of four), and the dropout mask of the group costs one Philox call per column -- its four words are the
+    const unsigned long long* __restrict__ rng, float* __restrict__ partial, PlaneOut po_dx, PlaneOut po_drop, int gs, float (*red)[2][LN_MAXU * 256]) {
+    // gs = 4 (many rows): one wave per group of 4 CONSECUTIVE rows: the loads of RB rows are issued together (one memory round trip
+    // instead of RB), and the dropout mask of the group costs one Philox call per column -- its four words are the
     // four rows' bits (common.hpp) -- instead of one per element.  gs = 1 (the decoder's B rows): one row per wave, so
     // that the few rows spread over as many waves as possible.
-    __shared__ float red[4][2][LN_MAXU * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 dg[LN_MAXU], db[LN_MAXU];
+    float4 dg[U], db[U];
 #pragma unroll
-    for (int u = 0; u < LN_MAXU; ++u) dg[u] = db[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < U; ++u) dg[u] = db[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
     const bool drop = dx_drop != nullptr && drop_p > 0.f;
     const int ngrp = (rows + gs - 1) / gs;
     for (int grp = blockIdx.x * 4 + wave; grp < ngrp; grp += gridDim.x * 4) {
         const int row0 = grp * gs;
-        float4 d[4][LN_MAXU], v[4][LN_MAXU], g[LN_MAXU];
-        float mean[4], rstd[4];
+        float4 g[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i >= gs) break;
-            const int row = row0 + i < rows ? row0 + i : rows - 1;           // clamped: the tail rows are masked below
-            mean[i] = stats[2 * row];
-            rstd[i] = stats[2 * row + 1];
-#pragma unroll
-            for (int u = 0; u < LN_MAXU; ++u) {
-                const int c = lane * 4 + u * 256;
-                if (c < E) {
-                    d[i][u] = *reinterpret_cast<const float4*>(dy + (long)row * E + c);
-                    v[i][u] = *reinterpret_cast<const float4*>(x + (long)row * E + c);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LN_MAXU; ++u)
+        for (int u = 0; u < U; ++u)
             if (lane * 4 + u * 256 < E) g[u] = *reinterpret_cast<const float4*>(gamma + lane * 4 + u * 256);
-        uint4 kb[LN_MAXU][4];
-        if (drop) {
+        for (int i0 = 0; i0 < gs; i0 += RB) {
+            float4 d[RB][U], v[RB][U];
+            float mean[RB], rstd[RB], s1[RB], s2[RB];
 #pragma unroll
-            for (int u = 0; u < LN_MAXU; ++u)
-                if (lane * 4 + u * 256 < E) {
+            for (int i = 0; i < RB; ++i) {
+                if (i0 + i >= gs) break;
+                const int row = row0 + i0 + i < rows ? row0 + i0 + i : rows - 1;   // clamped: the tail rows are masked below
+                mean[i] = stats[2 * row];
+                rstd[i] = stats[2 * row + 1];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) kb[u][e] = dropout_bits4(rng, drop_site, (unsigned)row0 >> 2, (unsigned)(lane * 4 + u * 256 + e));
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i >= gs) break;
-            const int row = row0 + i;
-            const int wsel = row & 3;                                         // which Philox word is this row's
-            const bool live = row < rows;                                     // wave-uniform
-            float s1 = 0.f, s2 = 0.f;
-            float4 gv[LN_MAXU], xh[LN_MAXU];
-#pragma unroll
-            for (int u = 0; u < LN_MAXU; ++u) {
-                if (lane * 4 + u * 256 < E) {
-                    const float4 dd = d[i][u], vv = v[i][u];
-                    xh[u] = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
-                    gv[u] = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
-                    s1 += gv[u].x + gv[u].y + gv[u].z + gv[u].w;
-                    s2 += gv[u].x * xh[u].x + gv[u].y * xh[u].y + gv[u].z * xh[u].z + gv[u].w * xh[u].w;
-                    if (live) {
-                        dg[u].x += dd.x * xh[u].x; dg[u].y += dd.y * xh[u].y; dg[u].z += dd.z * xh[u].z; dg[u].w += dd.w * xh[u].w;
-                        db[u].x += dd.x; db[u].y += dd.y; db[u].z += dd.z; db[u].w += dd.w;
+                for (int u = 0; u < U; ++u) {
+                    const int c = lane * 4 + u * 256;
+                    if (c < E) {
+                        d[i][u] = *reinterpret_cast<const float4*>(dy + (long)row * E + c);
+                        v[i][u] = *reinterpret_cast<const float4*>(x + (long)row * E + c);
                     }
                 }
             }
-            s1 = wave_sum(s1) * invE;
-            s2 = wave_sum(s2) * invE;
-            if (!live) continue;
+            // phase 1, per row: the two row sums and the (dgamma, dbeta) contributions
 #pragma unroll
-            for (int u = 0; u < LN_MAXU; ++u) {
+            for (int i = 0; i < RB; ++i) {
+                if (i0 + i >= gs) break;
+                const bool live = row0 + i0 + i < rows;                           // wave-uniform
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (lane * 4 + u * 256 < E) {
+                        const float4 dd = d[i][u], vv = v[i][u];
+                        const float4 xh = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
+                        const float4 gv = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
+                        a1 += gv.x + gv.y + gv.z + gv.w;
+                        a2 += gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w;
+                        if (live) {
+                            dg[u].x += dd.x * xh.x; dg[u].y += dd.y * xh.y; dg[u].z += dd.z * xh.z; dg[u].w += dd.w * xh.w;
+                            db[u].x += dd.x; db[u].y += dd.y; db[u].z += dd.z; db[u].w += dd.w;
+                        }
+                    }
+                }
+                s1[i] = wave_sum(a1) * invE;
+                s2[i] = wave_sum(a2) * invE;
+            }
+            // phase 2, per column slot: the dropout bits of the slot's 4 columns (one Philox call per column serves the group's
+            // four rows) live only here -- 16 registers instead of 16 U -- then every row's outputs for the slot
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 const int c = lane * 4 + u * 256;
-                if (c < E) {
+                if (c >= E) continue;
+                uint4 kb[4];
+                if (drop) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kb[e] = dropout_bits4(rng, drop_site, (unsigned)row0 >> 2, (unsigned)(c + e));
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    if (i0 + i >= gs) break;
+                    const int row = row0 + i0 + i;
+                    if (row >= rows) continue;
+                    const int wsel = row & 3;                                     // which Philox word is this row's
+                    const float4 dd = d[i][u], vv = v[i][u];
+                    const float4 xh = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
+                    const float4 gv = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
                     float4 o;
-                    o.x = rstd[i] * (gv[u].x - s1 - xh[u].x * s2); o.y = rstd[i] * (gv[u].y - s1 - xh[u].y * s2);
-                    o.z = rstd[i] * (gv[u].z - s1 - xh[u].z * s2); o.w = rstd[i] * (gv[u].w - s1 - xh[u].w * s2);
+                    o.x = rstd[i] * (gv.x - s1[i] - xh.x * s2[i]); o.y = rstd[i] * (gv.y - s1[i] - xh.y * s2[i]);
+                    o.z = rstd[i] * (gv.z - s1[i] - xh.z * s2[i]); o.w = rstd[i] * (gv.w - s1[i] - xh.w * s2[i]);
                     if (add_to_dx) {
                         const float4 a = *reinterpret_cast<const float4*>(add_to_dx + (long)row * E + c);
                         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
@@ -382,10 +394,10 @@ __device__ __forceinline__ void layernorm_bwd_body(
                     store_planes4(po_dx, (long)row * E + c, o);
                     if (dx_drop) {
                         if (drop) {
-                            o.x = pick_word(kb[u][0], wsel) >= drop_thr ? o.x * ik : 0.f;
-                            o.y = pick_word(kb[u][1], wsel) >= drop_thr ? o.y * ik : 0.f;
-                            o.z = pick_word(kb[u][2], wsel) >= drop_thr ? o.z * ik : 0.f;
-                            o.w = pick_word(kb[u][3], wsel) >= drop_thr ? o.w * ik : 0.f;
+                            o.x = pick_word(kb[0], wsel) >= drop_thr ? o.x * ik : 0.f;
+                            o.y = pick_word(kb[1], wsel) >= drop_thr ? o.y * ik : 0.f;
+                            o.z = pick_word(kb[2], wsel) >= drop_thr ? o.z * ik : 0.f;
+                            o.w = pick_word(kb[3], wsel) >= drop_thr ? o.w * ik : 0.f;
                         }
                         *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
                         store_planes4(po_drop, (long)row * E + c, o);
@@ -398,8 +410,8 @@ __device__ __forceinline__ void layernorm_bwd_body(
 #pragma unroll
     for (int u = 0; u < LN_MAXU; ++u) {
         const int c = lane * 4 + u * 256;
-        *reinterpret_cast<float4*>(&red[wave][0][c]) = dg[u];
-        *reinterpret_cast<float4*>(&red[wave][1][c]) = db[u];
+        *reinterpret_cast<float4*>(&red[wave][0][c]) = u < U ? dg[u < U ? u : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&red[wave][1][c]) = u < U ? db[u < U ? u : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
@@ -407,7 +419,25 @@ __device__ __forceinline__ void layernorm_bwd_body(
         partial[((long)blockIdx.x * 2 + 1) * E + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
     }
 }
-SLNLP_ZKERNEL(layernorm_bwd_kernel, 256, layernorm_bwd_body)
+
+// one kernel per row-length class (block-uniform would do, but a kernel's register allocation is the maximum over its branches:
+// the E <= 512 rows of the grid's configs should not pay for the E = 1024 variant's footprint)
+#define SLNLP_LN_BWD_BODY(name, U, RB)                                                                                              \
+    __device__ __forceinline__ void name(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma, \
+                                         const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx,     \
+                                         float* __restrict__ dx, float* __restrict__ dx_drop, float drop_p, unsigned drop_thr,       \
+                                         int drop_site, const unsigned long long* __restrict__ rng, float* __restrict__ partial,     \
+                                         PlaneOut po_dx, PlaneOut po_drop, int gs) {                                                  \
+        __shared__ float red[4][2][LN_MAXU * 256];                                                                                  \
+        layernorm_bwd_rows<U, RB>(dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, drop_thr, drop_site, rng, partial,  \
+                                  po_dx, po_drop, gs, red);                                                                         \
+    }
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1, 1, 4)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2, 2, 4)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4, 4, 2)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u1, 256, layernorm_bwd_body_u1)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u2, 256, layernorm_bwd_body_u2)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u4, 256, layernorm_bwd_body_u4)
 
 // grid (entry, ceil(E/64)); block = 64 columns x 4 partial-groups, combined through LDS in fixed order.
 __device__ __forceinline__ void ln_param_reduce_body(const slnlp_ln_reduce_entry* __restrict__ table) {
@@ -471,7 +501,8 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
     // blocks for smaller batches too; blocks without rows write zero partials.
     const int nblk = nblk_force ? nblk_force : ln_bwd_blocks(rows);
     if (nblk_out) *nblk_out = nblk;
-    SLNLP_TRY(zlaunch(layernorm_bwd_kernel, dim3(nblk), 256, 0, st, "layernorm_bwd",
+    auto kern = E <= 256 ? layernorm_bwd_kernel_u1 : E <= 512 ? layernorm_bwd_kernel_u2 : layernorm_bwd_kernel_u4;
+    SLNLP_TRY(zlaunch(kern, dim3(nblk), 256, 0, st, "layernorm_bwd",
                       dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop, ln_bwd_group(rows)));
     return 0;
 }

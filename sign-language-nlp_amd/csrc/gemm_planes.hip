@@ -122,8 +122,8 @@ __device__ __forceinline__ float2 ld_agent2(const float* p) {
 //                              64 x 64 x 64 products; two workgroups per CU.  Launches that need every CU for a few hundred tiles.
 //   128 x 128 x 64, 2 stages : 32 x 64 per wave -- 12 fragment reads for 24 MFMAs per 32-k, half the L2 -> LDS bytes per FLOP
 //                              (the measured wall of the 64 x 64 tile); 128 KiB, one workgroup per CU.
-//   128 x 128 x 32, 4 stages : the same tile with three K-steps in flight instead of one.
-//   256 x 128 x 32, 3 stages : 64 x 64 per wave -- 16 fragment reads for 48 MFMAs, 3/8 of the 64 x 64 tile's bytes per FLOP; 144 KiB.
+//   128 x 128 x 32, 2 stages : the same tile in 64 KiB -- two workgroups per CU again, each other's cover during prologue / epilogue.
+// (256 x 128 tiles and a four-deep 32-k ring were built and measured too: slower -- DESIGN.md, Appendix C.)
 // Split-K, the meeting point and the epilogues are the same code for all; the K partition (in units of 64) does not depend on
 // the geometry, so every geometry accumulates every output element in the same order: identical bits.
 template <int NSPLIT, bool AK, bool BK, int BM, int BN, int BKS, int NST>
@@ -649,8 +649,8 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
 
 // GEO: the launch's tile geometry (table below); every job of a launch uses it (the host picks it per launch: plane_geo_for()).
 struct GeoInfo { int bm, bn, bks, nst; };
-constexpr int NGEO = 4;
-constexpr GeoInfo GEO[NGEO] = {{64, 64, 64, 2}, {128, 128, 64, 2}, {128, 128, 32, 4}, {256, 128, 32, 3}};
+constexpr int NGEO = 3;
+constexpr GeoInfo GEO[NGEO] = {{64, 64, 64, 2}, {128, 128, 64, 2}, {128, 128, 32, 2}};
 
 template <int NSPLIT, int G>
 __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupP
     probe_kernel_end();
 }
 
-// ring bytes: stages x (A + B panels) x (hi, lo) x bks k x 2 B -- 64 KiB, 128 KiB, 128 KiB, 144 KiB; the epilogue's fp32 image of
-// the tile (bm x (bn + 4) floats) lives in the same memory and is never the larger of the two
+// ring bytes: stages x (A + B panels) x (hi, lo) x bks k x 2 B -- 64 KiB, 128 KiB, 64 KiB; the epilogue's fp32 image of the tile
+// (bm x (bn + 4) floats: 17 KiB / 66 KiB) lives in the same memory, so the 32-k geometry asks for 66 KiB
 constexpr size_t plane_lds(int geo) {
     const size_t ring = (size_t)GEO[geo].nst * 2 * (GEO[geo].bm + GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);
     const size_t image = (size_t)GEO[geo].bm * (GEO[geo].bn + 4) * sizeof(float);
@@ -688,8 +688,8 @@ constexpr int GROUP_COUNTERS = 4096;                       // ints at the head o
 
 // ---- precision 8 launches: their own kernel (all jobs of a launch are fp8 jobs), four geometries
 struct Q8GeoInfo { int bm, bn, nst; };
-constexpr int NQGEO = 4;
-constexpr Q8GeoInfo QGEO[NQGEO] = {{64, 64, 4}, {128, 128, 4}, {256, 128, 3}, {256, 256, 2}};
+constexpr int NQGEO = 2;
+constexpr Q8GeoInfo QGEO[NQGEO] = {{64, 64, 4}, {128, 128, 2}};
 
 template <int G>
 __global__ __launch_bounds__(PTHREADS) void gemm_q8_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
@@ -717,23 +717,20 @@ constexpr size_t q8_lds(int geo) {
 static const void* q8_kernel_ptr(int geo) {
     switch (geo) {
         case 1: return (const void*)gemm_q8_kernel<1>;
-        case 2: return (const void*)gemm_q8_kernel<2>;
-        case 3: return (const void*)gemm_q8_kernel<3>;
         default: return (const void*)gemm_q8_kernel<0>;
     }
 }
-static int q8_geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 256128 ? 2 : knob == 256256 ? 3 : -1; }
+static int q8_geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : -1; }
 static std::atomic<int> g_q8_geo{[] { const char* e = getenv("SLNLP_Q8_TILE"); return q8_geo_of_knob(e ? atoi(e) : 0); }()};
-// the widest tile that still gives every CU a few workgroups
+// 128 x 128 (two stages in 64 KiB: two workgroups per CU) once the launch has at least two of them per CU -- measured
+// (tools/bench_fp8_tiles.py): configs[4] in_proj 618 -> 890 TFLOP/s, a 16-fit merged launch 415 -> 589; a single cfg2 launch
+// (228 tiles) 303 -> 265.  Four-stage rings and 256-wide tiles (one workgroup per CU) were built and lost by 30-50 %.
 static int q8_geo_auto(const PlaneJob* jobs, int njobs) {
     const int forced = g_q8_geo.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
-    for (int geo = NQGEO - 1; geo > 0; --geo) {
-        long units = 0;
-        for (int i = 0; i < njobs; ++i) units += (long)ceil_div(jobs[i].a.M, QGEO[geo].bm) * ceil_div(jobs[i].a.N, QGEO[geo].bn);
-        if (units >= 512) return geo;
-    }
-    return 0;
+    long units = 0;
+    for (int i = 0; i < njobs; ++i) units += (long)ceil_div(jobs[i].a.M, 128) * ceil_div(jobs[i].a.N, 128);
+    return units >= 512 ? 1 : 0;
 }
 
 // Probe switch for the split-K meeting point (tools/probes): env SLNLP_SPLITK_MODE = 1: never split K;
@@ -745,27 +742,34 @@ static int splitk_mode() {
 }
 
 // ---- which geometry a launch uses.  -1 = automatic (plane_geo_for), 0 .. NGEO-1 = forced (slnlp_set_plane_tile: tuning, tests)
-static int geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 12832 ? 2 : knob == 256128 ? 3 : -1; }
+static int geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 12832 ? 2 : -1; }
 static std::atomic<int> g_plane_geo{[] { const char* e = getenv("SLNLP_PLANE_TILE"); return geo_of_knob(e ? atoi(e) : 0); }()};
-constexpr int BIG_TILE_MIN_UNITS = 512;    // a launch takes 128 x 128 tiles when it still has at least this many of them
+constexpr int BIG_TILE_MIN_UNITS = 200;    // a launch takes 128 x 128 tiles when it still has at least this many of them
 
-// Larger tiles move fewer operand bytes per FLOP through the L2 -> LDS path and issue fewer LDS fragment reads per MFMA, but
-// one such workgroup owns a CU: they pay once a launch has enough of them to fill the chip a few times over.
-int plane_geo_auto(long units128, bool fp8) {
-    if (fp8) return 0;                                       // the fp8 tile is built at 64 x 64
+// 128 x 128 tiles move half the operand bytes per FLOP through the L2 -> LDS path and issue half the LDS fragment reads per MFMA;
+// they pay once a launch has about a workgroup per CU (measured, tools/bench_plane_tiles.py: 220 tiles +10 %, 124 tiles -60 %).
+// Which ring: 64-k x 2 stages (128 KiB, one workgroup per CU) for short K loops -- at K = 512 a 32-k ring spends its time in
+// barriers -- and 32-k x 2 stages (64 KiB, two workgroups per CU, each the other's cover in prologue and epilogue) once every
+// job's K loop is at least 1024 long (configs[4]: +10 %).
+int plane_geo_auto(long units128, int min_k, bool fp8) {
+    if (fp8) return 0;                                       // (fp8 launches have their own geometries: q8_geo_auto)
     const int forced = g_plane_geo.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
-    return units128 >= BIG_TILE_MIN_UNITS ? 1 : 0;
+    if (units128 < BIG_TILE_MIN_UNITS) return 0;
+    return min_k >= 1024 ? 2 : 1;
 }
 long plane_units128(const slnlp_gemm_args& a, int nks) { return (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) * (nks < 1 ? 1 : nks); }
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
     long units = 0;
+    int min_k = 1 << 30;
     bool fp8 = false;
     for (int i = 0; i < njobs; ++i) {
+        const int nks = split_k && split_k[i] > 1 ? split_k[i] : 1;
         fp8 = fp8 || jobs[i].precision == 8;
-        units += plane_units128(jobs[i], split_k ? split_k[i] : 1);
+        units += plane_units128(jobs[i], nks);
+        min_k = std::min(min_k, jobs[i].K / nks);
     }
-    return plane_geo_auto(units, fp8);
+    return plane_geo_auto(units, min_k, fp8);
 }
 
 // set the kernels' LDS attribute up front (plan creation) so it never lands inside a graph capture
@@ -928,8 +932,12 @@ void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, co
     for (int geo = 0; geo < NGEO; ++geo)
         if (recorded_fn == gemm_planes_kernel_ptr(3, geo)) prec = 3;
     long units = 0;
-    for (int i = 0; i < njobs; ++i) units += plane_units128(jobs[i].a, jobs[i].nks);
-    const int geo = plane_geo_auto(units, false);
+    int min_k = 1 << 30;
+    for (int i = 0; i < njobs; ++i) {
+        units += plane_units128(jobs[i].a, jobs[i].nks);
+        min_k = std::min(min_k, jobs[i].a.K / (jobs[i].nks > 1 ? jobs[i].nks : 1));
+    }
+    const int geo = plane_geo_auto(units, min_k, false);
     for (int i = 0; i < njobs; ++i) plane_job_retile(jobs[i], geo);
     *fn = gemm_planes_kernel_ptr(prec, geo);
     *lds = plane_lds(geo);
@@ -940,7 +948,6 @@ static const void* kernel_of(int geo) {
     switch (geo) {
         case 1: return (const void*)gemm_planes_kernel<NSPLIT, 1>;
         case 2: return (const void*)gemm_planes_kernel<NSPLIT, 2>;
-        case 3: return (const void*)gemm_planes_kernel<NSPLIT, 3>;
         default: return (const void*)gemm_planes_kernel<NSPLIT, 0>;
     }
 }
@@ -1025,7 +1032,7 @@ extern "C" int slnlp_quant_rows_fp8(const float* x, int64_t ld, int R, int K, ui
 
 extern "C" int slnlp_set_plane_tile(int tile) {
     if (tile != 0 && slnlp::geo_of_knob(tile) < 0) {
-        slnlp::set_error("set_plane_tile: %d (0 = automatic, 64, 128, 12832 = 128 x 128 with 32-k stages, 256128 = 256 x 128)", tile);
+        slnlp::set_error("set_plane_tile: %d (0 = automatic, 64, 128, 12832 = 128 x 128 with 32-k stages)", tile);
         return SLNLP_ERR_INVALID_ARG;
     }
     slnlp::g_plane_geo.store(slnlp::geo_of_knob(tile), std::memory_order_relaxed);
@@ -1034,7 +1041,7 @@ extern "C" int slnlp_set_plane_tile(int tile) {
 
 extern "C" int slnlp_set_fp8_tile(int tile) {
     if (tile != 0 && slnlp::q8_geo_of_knob(tile) < 0) {
-        slnlp::set_error("set_fp8_tile: %d (0 = automatic, 64, 128, 256128 = 256 x 128, 256256 = 256 x 256)", tile);
+        slnlp::set_error("set_fp8_tile: %d (0 = automatic, 64 or 128)", tile);
         return SLNLP_ERR_INVALID_ARG;
     }
     slnlp::g_q8_geo.store(slnlp::q8_geo_of_knob(tile), std::memory_order_relaxed);

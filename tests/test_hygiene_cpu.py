@@ -242,3 +242,21 @@ def test_recipe_init_draws_the_reference_distributions(cls_name, kw):
     assert any(not torch.equal(rec[k], other[k]) for k in rec)
     p0 = next(rec_mod.parameters())
     assert p0.untyped_storage().data_ptr() == rec_mod._arena.untyped_storage().data_ptr()
+
+
+def test_no_kernel_of_the_built_library_needs_more_than_256_registers():
+    """The code object's own metadata, no compiler run: every kernel's register allocation (VGPRs + AGPRs, `.vgpr_count` on the
+    unified file) stays within 256.  layernorm_bwd once took 347 (256 + 91 AGPRs) and was the one kernel that returned wrong
+    rows whenever waves of another hardware queue shared its SIMDs (tools/probes/probe_victim.py)."""
+    import importlib.util
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "sign-language-nlp_amd", "lib", "libslnlp.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    spec = importlib.util.spec_from_file_location("kernel_registers", os.path.join(ROOT, "tools", "kernel_registers.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.library_kernels(lib)
+    assert len(ks) > 50, "no kernels found in the library's code objects"
+    over = [(v, n) for v, a, n in ks if v > 256]
+    assert not over, f"kernels above 256 registers: {over}"

@@ -416,9 +416,9 @@ def test_gemm_group_large_shapes_split_k_and_epilogue(ops):
     assert rel((hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float())[:M, :N], ref) < 1e-4
 
 
-@pytest.mark.parametrize("knob", [128, 12832, 256128])
+@pytest.mark.parametrize("knob", [128, 12832])
 def test_plane_tile_geometries_return_the_bits_of_the_64_tile(ops, knob):
-    """Every tile geometry of the plane GEMM (slnlp_set_plane_tile: 128 x 128 with 64-k or 32-k stages, 256 x 128) accumulates
+    """Every tile geometry of the plane GEMM (slnlp_set_plane_tile: 128 x 128 with 64-k or 32-k stages) accumulates
     every output element in the order of the 64 x 64 tile -- the K partition is the same -- so a launch may take whichever is
     fastest (merged lockstep launches do) without changing a bit: all three layouts, ragged edges, bias / ReLU / residual /
     output planes, split-K with the fused bias-gradient row sums."""
@@ -465,7 +465,7 @@ def test_plane_tile_geometries_return_the_bits_of_the_64_tile(ops, knob):
         assert torch.equal(a, b), f"output {i} differs between the 64 x 64 tile and geometry {knob}"
 
 
-@pytest.mark.parametrize("knob", [64, 128, 256128, 256256])
+@pytest.mark.parametrize("knob", [128])
 def test_fp8_tile_geometries(ops, knob):
     """precision 8 on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, every block scale 2^0) at each tile geometry
     (slnlp_set_fp8_tile): equals the fp64 product of the dequantised operands, the epilogue (per-column weight scale, bias, ReLU,

@@ -55,8 +55,8 @@ def case(name, Mtok, Nout, Kin, split, copies=1, check_ref=False):
     return same
 
 keep = []
-TILES = (64, 128, 12832, 256128)            # slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages), 128 x 128 (32-k x 4), 256 x 128 (32-k x 3)
-DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128), 256128: (256, 128)}
+TILES = (64, 128, 12832)                    # slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages, 128 KiB), 128 x 128 (32-k x 2, 64 KiB)
+DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 big_only = len(sys.argv) > 1 and sys.argv[1] == "big"
 ok = True

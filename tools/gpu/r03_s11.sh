@@ -1,0 +1,4 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03s11; mkdir -p $O
+timeout -k 10 300 python tools/probes/probe_lnb.py 10 2>&1 | grep -v amdgpu.ids | tee $O/lnb.txt
