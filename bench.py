@@ -28,6 +28,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "sign-language-nlp_amd")):
@@ -259,9 +260,9 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=15):
     synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
     ranks (rank 0 owns the dataset and broadcasts it; the same sample at every N: strong scaling).  Work unit =
     `lockstep` shape-compatible fits advancing through one launch sequence; `fits_per_gpu` host threads per rank each run
-    one unit at a time ON ONE STREAM (slnlp.net.device_stream: kernels of several fits on several hardware queues are not
-    safe on this stack), so one unit's host work (estimator construction, epoch metrics, scoring) hides under another's
-    kernels while the GPU runs a single kernel sequence."""
+    one unit at a time on a stream of its own (slnlp.net.device_stream), so one unit's host work (estimator construction,
+    epoch metrics, scoring) and small launches hide under another's kernels; `scores_crc32` is the checksum of every
+    candidate's mean test score -- the same in every run, stream mode and world size."""
     import warnings
     from slnlp.data import synthetic_dataset
     from slnlp.grid import ShardedGridSearchCV
@@ -285,6 +286,8 @@ def grid_folds_per_hour(dev, world, rank, fits_per_gpu=3, lockstep=15):
             "fits_per_gpu": fits_per_gpu, "lockstep": lockstep, "work_units": gs.n_units_, "ranks": world, "schedule": gs.schedule,
             "rank_seconds": [round(v, 2) for v in gs.rank_seconds_], "rank_fits": gs.rank_tasks_, "warmup_seconds": round(warm_s, 2),
             "best_index": gs.best_index_, "best_score": round(gs.best_score_, 5),
+            # every candidate's mean test score, bit for bit: the same at every N, stream mode and run (fits never influence each other)
+            "scores_crc32": "%08x" % zlib.crc32(np.asarray(gs.cv_results_["mean_test_score"], dtype=np.float64).tobytes()),
             "sample": f"{len(gs.cv_results_['params'])} candidates (lr x dropout x embedding_size x hidden_size x num_heads x num_layers of "
                       f"config-transformer.yaml) x cv {GRID_CV}, {GRID_EPOCHS} epochs, {GRID_SAMPLES} samples, 80/20 train/valid split inside each fit, "
                       "the reference's 5 epoch metrics on both; includes the dataset broadcast and the score all_gather"}

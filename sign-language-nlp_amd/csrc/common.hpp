@@ -266,6 +266,19 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
                   PlaneOut po_dx = {}, PlaneOut po_drop = {});
 int attn_init();
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st);
+// (dgamma, dbeta) chunk sums of n LayerNorms (elementwise.hip: ln_param_partial_kernel) from a device table, or of one (`single`,
+// host memory; table == nullptr).  rows_enc / rows_dec = this batch's rows, full_* = the plan's full batch (chunk geometry).
+struct LnPartialEntry {
+    const float* dy;
+    const float* x;
+    const float* stats;
+    float* partial;
+    int dec;                // 1: a decoder LayerNorm (rows = rows_dec), 0: an encoder one (rows = rows_enc)
+    int pad;
+};
+int ln_param_partial(const LnPartialEntry* table_dev, const LnPartialEntry* single_host, int n, int E, int rows_enc, int rows_dec,
+                     int full_rows_enc, int full_rows_dec, hipStream_t st);
+int ln_partial_chunk(int rows);
 int lsm_nll(const float* logits, int64_t ld_logits, const int64_t* y, int B, int V, int64_t ignore_index, float* logp,
             float* loss, float* dlogits, int64_t ld_dlogits, float* row_scratch, hipStream_t st, hipStream_t loss_st,
             float* logp2 = nullptr, const int* logp2_row = nullptr, float* loss_hist = nullptr, const int* hist_idx = nullptr);

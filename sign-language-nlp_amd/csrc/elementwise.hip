@@ -294,150 +294,177 @@ __device__ __forceinline__ void layernorm_fwd_body(const float* __restrict__ x,
 }
 SLNLP_ZKERNEL(layernorm_fwd_kernel, 256, layernorm_fwd_body)
 
-// U = float4 slots per lane that can be live (E <= 256 * U), RB = rows of a group whose loads are in flight together.
-// REGISTER BUDGET: U * RB <= 8.  The first version kept 4 rows x 4 slots live for every E: 256 VGPRs + 91 AGPRs -- the only kernel
-// of the library above 256 registers -- and exactly that kernel returned wrong rows whenever waves of another hardware queue
-// shared its SIMDs (constant inputs, 44 % of the runs differ beside two other fits, never alone; the GEMMs
-// beside it never differ).  Same rows per wave, same row order in every sum: results are bit-identical to that version.
-template <int U, int RB>
+// LayerNorm backward is TWO kernels since round 3:
+//   layernorm_bwd_rows   dx (and its dropout-masked copy, and their bf16 planes): purely row-wise, one wave per GS consecutive rows;
+//   ln_param_partial     the (dgamma, dbeta) column sums of the same (dy, x, stats), per chunk of rows, for EVERY LayerNorm of the
+//                        step in one table-driven launch at the end of backward; ln_param_reduce adds the chunks in order.
+// Why: the round-2 kernel also kept the (dgamma, dbeta) accumulators and combined them through LDS at its end.  That kernel -- and
+// only it -- returned different dx rows (64-byte pieces, whole rows) when kernels of another hardware queue ran beside it, on
+// constant and intact inputs (tools/probes/probe_victim.py: 40-85 % of the runs differ beside two other fits, never alone; the
+// GEMMs and layernorm_fwd never).  Sixteen builds of it (tools/probes/probe_victim2.py) gave an exact pattern: the row kernel is
+// immune iff the rows per wave are a compile-time constant AND no accumulators stay live across its rows -- however they are
+// written out -- and with it in that form three concurrent fits (threads or processes) are bit-identical to solo runs
+// (DESIGN.md section 6).  The mechanism below the ISA is not known; the form is what the library ships, for every row kernel.
+//
+// U = float4 slots per lane (E <= 256 * U), GS = rows per wave (4: many rows; 1: the decoder's B rows, spread over as many waves as
+// possible), RB = rows whose loads are in flight together (U * RB <= 8: every instance stays under 256 registers).
+template <int U, int GS, int RB>
 __device__ __forceinline__ void layernorm_bwd_rows(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
     float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng, float* __restrict__ partial, PlaneOut po_dx, PlaneOut po_drop, int gs, float (*red)[2][LN_MAXU * 256]) {
-    // gs = 4 (many rows): one wave per group of 4 CONSECUTIVE rows: the loads of RB rows are issued together (one memory round trip
-    // instead of RB), and the dropout mask of the group costs one Philox call per column -- its four words are the
-    // four rows' bits (common.hpp) -- instead of one per element.  gs = 1 (the decoder's B rows): one row per wave, so
-    // that the few rows spread over as many waves as possible.
+    const unsigned long long* __restrict__ rng, PlaneOut po_dx, PlaneOut po_drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 dg[U], db[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) dg[u] = db[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
     const bool drop = dx_drop != nullptr && drop_p > 0.f;
-    const int ngrp = (rows + gs - 1) / gs;
-    for (int grp = blockIdx.x * 4 + wave; grp < ngrp; grp += gridDim.x * 4) {
-        const int row0 = grp * gs;
-        float4 g[U];
+    const int row0 = (blockIdx.x * 4 + wave) * GS;                 // one group per wave: the launch covers ceil(rows / GS) waves
+    if (row0 >= rows) return;
+    float4 g[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (lane * 4 + u * 256 < E) g[u] = *reinterpret_cast<const float4*>(gamma + lane * 4 + u * 256);
-        for (int i0 = 0; i0 < gs; i0 += RB) {
-            float4 d[RB][U], v[RB][U];
-            float mean[RB], rstd[RB], s1[RB], s2[RB];
+    for (int u = 0; u < U; ++u)
+        if (lane * 4 + u * 256 < E) g[u] = *reinterpret_cast<const float4*>(gamma + lane * 4 + u * 256);
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                if (i0 + i >= gs) break;
-                const int row = row0 + i0 + i < rows ? row0 + i0 + i : rows - 1;   // clamped: the tail rows are masked below
-                mean[i] = stats[2 * row];
-                rstd[i] = stats[2 * row + 1];
+    for (int i0 = 0; i0 < GS; i0 += RB) {
+        float4 d[RB][U], v[RB][U];
+        float mean[RB], rstd[RB], s1[RB], s2[RB];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = lane * 4 + u * 256;
-                    if (c < E) {
-                        d[i][u] = *reinterpret_cast<const float4*>(dy + (long)row * E + c);
-                        v[i][u] = *reinterpret_cast<const float4*>(x + (long)row * E + c);
-                    }
-                }
-            }
-            // phase 1, per row: the two row sums and the (dgamma, dbeta) contributions
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                if (i0 + i >= gs) break;
-                const bool live = row0 + i0 + i < rows;                           // wave-uniform
-                float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (lane * 4 + u * 256 < E) {
-                        const float4 dd = d[i][u], vv = v[i][u];
-                        const float4 xh = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
-                        const float4 gv = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
-                        a1 += gv.x + gv.y + gv.z + gv.w;
-                        a2 += gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w;
-                        if (live) {
-                            dg[u].x += dd.x * xh.x; dg[u].y += dd.y * xh.y; dg[u].z += dd.z * xh.z; dg[u].w += dd.w * xh.w;
-                            db[u].x += dd.x; db[u].y += dd.y; db[u].z += dd.z; db[u].w += dd.w;
-                        }
-                    }
-                }
-                s1[i] = wave_sum(a1) * invE;
-                s2[i] = wave_sum(a2) * invE;
-            }
-            // phase 2, per column slot: the dropout bits of the slot's 4 columns (one Philox call per column serves the group's
-            // four rows) live only here -- 16 registers instead of 16 U -- then every row's outputs for the slot
+        for (int i = 0; i < RB; ++i) {
+            const int row = row0 + i0 + i < rows ? row0 + i0 + i : rows - 1;   // clamped: the tail rows are masked below
+            mean[i] = stats[2 * row];
+            rstd[i] = stats[2 * row + 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = lane * 4 + u * 256;
-                if (c >= E) continue;
-                uint4 kb[4];
-                if (drop) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) kb[e] = dropout_bits4(rng, drop_site, (unsigned)row0 >> 2, (unsigned)(c + e));
+                if (c < E) {
+                    d[i][u] = *reinterpret_cast<const float4*>(dy + (long)row * E + c);
+                    v[i][u] = *reinterpret_cast<const float4*>(x + (long)row * E + c);
                 }
+            }
+        }
+        // phase 1, per row: the two row sums
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    if (i0 + i >= gs) break;
-                    const int row = row0 + i0 + i;
-                    if (row >= rows) continue;
-                    const int wsel = row & 3;                                     // which Philox word is this row's
+        for (int i = 0; i < RB; ++i) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (lane * 4 + u * 256 < E) {
                     const float4 dd = d[i][u], vv = v[i][u];
                     const float4 xh = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
                     const float4 gv = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
-                    float4 o;
-                    o.x = rstd[i] * (gv.x - s1[i] - xh.x * s2[i]); o.y = rstd[i] * (gv.y - s1[i] - xh.y * s2[i]);
-                    o.z = rstd[i] * (gv.z - s1[i] - xh.z * s2[i]); o.w = rstd[i] * (gv.w - s1[i] - xh.w * s2[i]);
-                    if (add_to_dx) {
-                        const float4 a = *reinterpret_cast<const float4*>(add_to_dx + (long)row * E + c);
-                        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                    a1 += gv.x + gv.y + gv.z + gv.w;
+                    a2 += gv.x * xh.x + gv.y * xh.y + gv.z * xh.z + gv.w * xh.w;
+                }
+            }
+            s1[i] = wave_sum(a1) * invE;
+            s2[i] = wave_sum(a2) * invE;
+        }
+        // phase 2, per column slot: the dropout bits of the slot's 4 columns (one Philox call per column serves the group's
+        // four rows -- its four words are the four rows' bits, common.hpp) live only here, then every row's outputs for the slot
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane * 4 + u * 256;
+            if (c >= E) continue;
+            uint4 kb[4];
+            if (drop) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kb[e] = dropout_bits4(rng, drop_site, (unsigned)(row0 + i0) >> 2, (unsigned)(c + e));
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int row = row0 + i0 + i;
+                if (row >= rows) continue;
+                const int wsel = row & 3;                                     // which Philox word is this row's
+                const float4 dd = d[i][u], vv = v[i][u];
+                const float4 xh = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
+                const float4 gv = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
+                float4 o;
+                o.x = rstd[i] * (gv.x - s1[i] - xh.x * s2[i]); o.y = rstd[i] * (gv.y - s1[i] - xh.y * s2[i]);
+                o.z = rstd[i] * (gv.z - s1[i] - xh.z * s2[i]); o.w = rstd[i] * (gv.w - s1[i] - xh.w * s2[i]);
+                if (add_to_dx) {
+                    const float4 a = *reinterpret_cast<const float4*>(add_to_dx + (long)row * E + c);
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
+                *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
+                store_planes4(po_dx, (long)row * E + c, o);
+                if (dx_drop) {
+                    if (drop) {
+                        o.x = pick_word(kb[0], wsel) >= drop_thr ? o.x * ik : 0.f;
+                        o.y = pick_word(kb[1], wsel) >= drop_thr ? o.y * ik : 0.f;
+                        o.z = pick_word(kb[2], wsel) >= drop_thr ? o.z * ik : 0.f;
+                        o.w = pick_word(kb[3], wsel) >= drop_thr ? o.w * ik : 0.f;
                     }
-                    *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
-                    store_planes4(po_dx, (long)row * E + c, o);
-                    if (dx_drop) {
-                        if (drop) {
-                            o.x = pick_word(kb[0], wsel) >= drop_thr ? o.x * ik : 0.f;
-                            o.y = pick_word(kb[1], wsel) >= drop_thr ? o.y * ik : 0.f;
-                            o.z = pick_word(kb[2], wsel) >= drop_thr ? o.z * ik : 0.f;
-                            o.w = pick_word(kb[3], wsel) >= drop_thr ? o.w * ik : 0.f;
-                        }
-                        *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
-                        store_planes4(po_drop, (long)row * E + c, o);
-                    }
+                    *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
+                    store_planes4(po_drop, (long)row * E + c, o);
                 }
             }
         }
     }
-    // combine the block's 4 waves, write this block's partial (dgamma | dbeta)
-#pragma unroll
-    for (int u = 0; u < LN_MAXU; ++u) {
-        const int c = lane * 4 + u * 256;
-        *reinterpret_cast<float4*>(&red[wave][0][c]) = u < U ? dg[u < U ? u : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&red[wave][1][c]) = u < U ? db[u < U ? u : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < E; c += 256) {
-        partial[((long)blockIdx.x * 2 + 0) * E + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-        partial[((long)blockIdx.x * 2 + 1) * E + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
-    }
 }
 
-// one kernel per row-length class (block-uniform would do, but a kernel's register allocation is the maximum over its branches:
-// the E <= 512 rows of the grid's configs should not pay for the E = 1024 variant's footprint)
-#define SLNLP_LN_BWD_BODY(name, U, RB)                                                                                              \
+// one kernel per (row-length class, rows per wave): a kernel's register allocation is the maximum over its branches
+#define SLNLP_LN_BWD_BODY(name, U, GS, RB)                                                                                          \
     __device__ __forceinline__ void name(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma, \
                                          const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx,     \
                                          float* __restrict__ dx, float* __restrict__ dx_drop, float drop_p, unsigned drop_thr,       \
-                                         int drop_site, const unsigned long long* __restrict__ rng, float* __restrict__ partial,     \
-                                         PlaneOut po_dx, PlaneOut po_drop, int gs) {                                                  \
-        __shared__ float red[4][2][LN_MAXU * 256];                                                                                  \
-        layernorm_bwd_rows<U, RB>(dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, drop_thr, drop_site, rng, partial,  \
-                                  po_dx, po_drop, gs, red);                                                                         \
+                                         int drop_site, const unsigned long long* __restrict__ rng, PlaneOut po_dx,                  \
+                                         PlaneOut po_drop) {                                                                         \
+        layernorm_bwd_rows<U, GS, RB>(dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, drop_thr, drop_site, rng,       \
+                                      po_dx, po_drop);                                                                              \
     }
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1, 1, 4)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2, 2, 4)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4, 4, 2)
-SLNLP_ZKERNEL(layernorm_bwd_kernel_u1, 256, layernorm_bwd_body_u1)
-SLNLP_ZKERNEL(layernorm_bwd_kernel_u2, 256, layernorm_bwd_body_u2)
-SLNLP_ZKERNEL(layernorm_bwd_kernel_u4, 256, layernorm_bwd_body_u4)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g4, 1, 4, 4)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g4, 2, 4, 4)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g4, 4, 4, 2)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g1, 1, 1, 1)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g1, 2, 1, 1)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g1, 4, 1, 1)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u1g4, 256, layernorm_bwd_body_u1g4)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u2g4, 256, layernorm_bwd_body_u2g4)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u4g4, 256, layernorm_bwd_body_u4g4)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u1g1, 256, layernorm_bwd_body_u1g1)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u2g1, 256, layernorm_bwd_body_u2g1)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u4g1, 256, layernorm_bwd_body_u4g1)
+
+// (dgamma, dbeta) partial sums of one LayerNorm per chunk of rows: partial[chunk][0][c] = sum_r dy[r, c] xhat[r, c],
+// partial[chunk][1][c] = sum_r dy[r, c] over the chunk's rows in increasing order.  grid (chunks, entries); a thread owns 4
+// columns (blockDim = E / 4 rounded up to a wave) and walks its chunk's rows: coalesced 16-byte loads, no LDS, no barrier.  A chunk
+// past the batch's last row writes zeros, so the reduce table can stay the full batch's (ln_param_reduce adds `nblk` chunks).
+__device__ __forceinline__ void ln_param_partial_body(const LnPartialEntry* __restrict__ table, LnPartialEntry single, int E, int rows_enc,
+                                                      int rows_dec, int chunk_enc, int chunk_dec, int nchunk_enc, int nchunk_dec) {
+    LnPartialEntry e = table ? table[blockIdx.y] : single;
+    const float* __restrict__ dy = as_global(e.dy);
+    const float* __restrict__ x = as_global(e.x);
+    const float* __restrict__ stats = as_global(e.stats);
+    float* __restrict__ partial = as_global(e.partial);
+    const int rows = e.dec ? rows_dec : rows_enc, chunk = e.dec ? chunk_dec : chunk_enc;
+    const int c = threadIdx.x * 4;
+    if (c >= E || (int)blockIdx.x >= (e.dec ? nchunk_dec : nchunk_enc)) return;   // the grid is the larger class's chunk count
+    const int r0 = blockIdx.x * chunk;
+    const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4& dd, const float4& vv, float mean, float rstd) {
+        ag.x += dd.x * ((vv.x - mean) * rstd); ag.y += dd.y * ((vv.y - mean) * rstd);
+        ag.z += dd.z * ((vv.z - mean) * rstd); ag.w += dd.w * ((vv.w - mean) * rstd);
+        ab.x += dd.x; ab.y += dd.y; ab.z += dd.z; ab.w += dd.w;
+    };
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {                    // 8 rows' loads in flight, added in row order
+        float4 dd[8], vv[8];
+        float2 ms[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dd[i] = *reinterpret_cast<const float4*>(dy + (long)(r + i) * E + c);
+            vv[i] = *reinterpret_cast<const float4*>(x + (long)(r + i) * E + c);
+            ms[i] = *reinterpret_cast<const float2*>(stats + 2 * (r + i));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) add(dd[i], vv[i], ms[i].x, ms[i].y);
+    }
+    for (; r < r1; ++r)
+        add(*reinterpret_cast<const float4*>(dy + (long)r * E + c), *reinterpret_cast<const float4*>(x + (long)r * E + c), stats[2 * r], stats[2 * r + 1]);
+    *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 0) * E + c) = ag;
+    *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * 2 + 1) * E + c) = ab;
+}
+SLNLP_ZKERNEL(ln_param_partial_kernel, 256, ln_param_partial_body)
 
 // grid (entry, ceil(E/64)); block = 64 columns x 4 partial-groups, combined through LDS in fixed order.
 __device__ __forceinline__ void ln_param_reduce_body(const slnlp_ln_reduce_entry* __restrict__ table) {
@@ -484,27 +511,50 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, int row
 
 static int ln_bwd_group(int rows) { return rows >= 1024 ? 4 : 1; }   // rows per wave
 
-int ln_bwd_blocks(int rows) {
-    int n = ceil_div(rows, 4 * ln_bwd_group(rows));   // a block is 4 waves
-    return n > SLNLP_LN_MAX_PARTIALS ? SLNLP_LN_MAX_PARTIALS : n;
+// rows per chunk of the (dgamma, dbeta) partial sums: 64, more when that would exceed SLNLP_LN_MAX_PARTIALS chunks
+int ln_partial_chunk(int rows) {
+    int c = 64;
+    while (ceil_div(rows, c) > SLNLP_LN_MAX_PARTIALS) c *= 2;
+    return c;
+}
+int ln_bwd_blocks(int rows) { return ceil_div(rows, ln_partial_chunk(rows)); }   // chunks = entries ln_param_reduce adds
+
+// the (dgamma, dbeta) chunk sums of `n` LayerNorms (device table) or of one (table == nullptr: `single`), one launch
+int ln_param_partial(const LnPartialEntry* table_dev, const LnPartialEntry* single_host, int n, int E, int rows_enc, int rows_dec, int full_rows_enc,
+                     int full_rows_dec, hipStream_t st) {
+    SLNLP_CHECK_ARG(n > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "ln_param_partial: bad args");
+    LnPartialEntry single;
+    memset(&single, 0, sizeof(single));
+    if (single_host) single = *single_host;
+    // chunk sizes (and so the chunk count every entry writes) follow the FULL batch: smaller batches leave zero chunks
+    const int ce = ln_partial_chunk(full_rows_enc > 0 ? full_rows_enc : 1), cd = ln_partial_chunk(full_rows_dec > 0 ? full_rows_dec : 1);
+    const int ne = full_rows_enc > 0 ? ceil_div(full_rows_enc, ce) : 0, nd = full_rows_dec > 0 ? ceil_div(full_rows_dec, cd) : 0;
+    const int nb = std::max(ne, nd);
+    const int threads = (ceil_div(E, 4) + 63) / 64 * 64;
+    return zlaunch(ln_param_partial_kernel, dim3(nb, n), threads, 0, st, "ln_param_partial", table_dev, single, E,
+                   rows_enc, rows_dec, ce, cd, ne, nd);
 }
 
 int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
                   const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
                   const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st,
                   PlaneOut po_dx, PlaneOut po_drop) {
-    SLNLP_CHECK_ARG(dy && x && gamma && stats && dx && partial, "layernorm_bwd: null pointer");
-    SLNLP_CHECK_ARG(nblk_force >= 0 && nblk_force <= SLNLP_LN_MAX_PARTIALS, "layernorm_bwd: nblk_force %d", nblk_force);
+    SLNLP_CHECK_ARG(dy && x && gamma && stats && dx, "layernorm_bwd: null pointer");
     SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "layernorm_bwd: need E %% 4 == 0 and E <= %d, got %d", LN_MAXU * 256, E);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "layernorm_bwd: bad dropout args");
-    // nblk_force: a plan whose reduce table was built for the full batch launches that many
-    // blocks for smaller batches too; blocks without rows write zero partials.
-    const int nblk = nblk_force ? nblk_force : ln_bwd_blocks(rows);
-    if (nblk_out) *nblk_out = nblk;
-    auto kern = E <= 256 ? layernorm_bwd_kernel_u1 : E <= 512 ? layernorm_bwd_kernel_u2 : layernorm_bwd_kernel_u4;
-    SLNLP_TRY(zlaunch(kern, dim3(nblk), 256, 0, st, "layernorm_bwd",
-                      dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, partial, po_dx, po_drop, ln_bwd_group(rows)));
-    return 0;
+    (void)nblk_force;
+    const int gs = ln_bwd_group(rows), u = E <= 256 ? 1 : E <= 512 ? 2 : 4;
+    auto kern = gs == 4 ? (u == 1 ? layernorm_bwd_kernel_u1g4 : u == 2 ? layernorm_bwd_kernel_u2g4 : layernorm_bwd_kernel_u4g4)
+                        : (u == 1 ? layernorm_bwd_kernel_u1g1 : u == 2 ? layernorm_bwd_kernel_u2g1 : layernorm_bwd_kernel_u4g1);
+    SLNLP_TRY(zlaunch(kern, dim3(ceil_div(rows, 4 * gs)), 256, 0, st, "layernorm_bwd",
+                      dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, po_dx, po_drop));
+    // partial != nullptr: also this LayerNorm's (dgamma, dbeta) chunk sums, for callers that reduce one LayerNorm at a time
+    // (the C API, tests); a plan passes nullptr and runs ONE table-driven ln_param_partial launch for all its LayerNorms
+    if (nblk_out) *nblk_out = ln_bwd_blocks(rows);
+    if (!partial) return 0;
+    LnPartialEntry e;
+    e.dy = dy; e.x = x; e.stats = stats; e.partial = partial; e.dec = 0; e.pad = 0;
+    return ln_param_partial(nullptr, &e, 1, E, rows, 0, rows, 0, st);
 }
 
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st) {

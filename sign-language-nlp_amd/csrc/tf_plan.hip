@@ -93,28 +93,39 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
         ok = (long)rows.size() == p->w.n_qrows &&
              hipMemcpy(p->w.qrow_table, rows.data(), rows.size() * sizeof(QuantRow), hipMemcpyHostToDevice) == hipSuccess;
     }
-    // LN (dgamma, dbeta) reduction table: one entry per LayerNorm, uploaded once.  nblk is the FULL
-    // batch's block count; smaller batches launch the same number of LN-backward blocks (nblk_force),
-    // so every slot the reduce reads is rewritten each step.
+    // LN (dgamma, dbeta) tables, one entry per LayerNorm, uploaded once: what ln_param_partial reads (the dy / x / stats of the
+    // LayerNorm's backward, all still intact at the end of backward: every gradient buffer is written once per step) and what
+    // ln_param_reduce adds.  nblk is the FULL batch's chunk count; a smaller batch's trailing chunks are written as zeros.
     std::vector<slnlp_ln_reduce_entry> tab;
+    std::vector<LnPartialEntry> ptab;
     const int nbE = p->nbE = ln_bwd_blocks(cfg->B * cfg->S), nbD = p->nbD = ln_bwd_blocks(cfg->B);
-    auto ent = [&](const float* part, long gw, long gb, int nblk) {
+    auto ent = [&](float* part, long gw, long gb, int dec, const float* dy, const float* x, const float* stats) {
         slnlp_ln_reduce_entry e;
-        e.partial = part; e.dgamma = p->G(gw); e.dbeta = p->G(gb); e.nblk = nblk; e.E = cfg->E;
+        e.partial = part; e.dgamma = p->G(gw); e.dbeta = p->G(gb); e.nblk = dec ? nbD : nbE; e.E = cfg->E;
         tab.push_back(e);
+        LnPartialEntry q;
+        q.dy = dy; q.x = x; q.stats = stats; q.partial = part; q.dec = dec; q.pad = 0;
+        ptab.push_back(q);
     };
-    for (int i = 0; i < cfg->N; ++i) {
-        ent(p->w.enc[i].lnp1, p->L.enc[i].n1_w, p->L.enc[i].n1_b, nbE);
-        ent(p->w.enc[i].lnp2, p->L.enc[i].n2_w, p->L.enc[i].n2_b, nbE);
+    {
+        const Ws& w = p->w;
+        const int N = cfg->N;
+        for (int i = 0; i < N; ++i) {
+            const EncA& a = w.enc[i];
+            ent(a.lnp1, p->L.enc[i].n1_w, p->L.enc[i].n1_b, 0, a.gx1, a.y1, a.st1);
+            ent(a.lnp2, p->L.enc[i].n2_w, p->L.enc[i].n2_b, 0, i + 1 < N ? w.enc[i + 1].gx0 : w.gxl, a.y2, a.st2);
+        }
+        ent(w.lnp_mem, p->L.encn_w, p->L.encn_b, 0, w.gmem, w.enc[N - 1].x2, w.st_mem);
+        for (int i = 0; i < N; ++i) {
+            const DecA& a = w.dec[i];
+            ent(a.lnp1, p->L.dec[i].n1_w, p->L.dec[i].n1_b, 1, a.gt1, a.y1, a.st1);
+            ent(a.lnp2, p->L.dec[i].n2_w, p->L.dec[i].n2_b, 1, a.gt2, a.y2, a.st2);
+            ent(a.lnp3, p->L.dec[i].n3_w, p->L.dec[i].n3_b, 1, i + 1 < N ? w.dec[i + 1].gt0 : w.gtl, a.y3, a.st3);
+        }
+        ent(w.lnp_fin, p->L.decn_w, p->L.decn_b, 1, w.gfin, w.dec[N - 1].t3, w.st_fin);
     }
-    ent(p->w.lnp_mem, p->L.encn_w, p->L.encn_b, nbE);
-    for (int i = 0; i < cfg->N; ++i) {
-        ent(p->w.dec[i].lnp1, p->L.dec[i].n1_w, p->L.dec[i].n1_b, nbD);
-        ent(p->w.dec[i].lnp2, p->L.dec[i].n2_w, p->L.dec[i].n2_b, nbD);
-        ent(p->w.dec[i].lnp3, p->L.dec[i].n3_w, p->L.dec[i].n3_b, nbD);
-    }
-    ent(p->w.lnp_fin, p->L.decn_w, p->L.decn_b, nbD);
     ok = ok && hipMemcpy(p->w.ln_table, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->w.ln_ptable, ptab.data(), ptab.size() * sizeof(ptab[0]), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(buf->grads, 0, p->L.total * sizeof(float)) == hipSuccess &&
          // the memset runs on the null stream, which does NOT order itself against the caller's non-blocking stream: without
          // this wait it can land after the first backward has written gradients (seen with several host threads, whose
@@ -260,14 +271,13 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     const unsigned long long* rng = pl->buf.rng;
     const int64_t *X = pl->last_X, *y = pl->last_y;
     const bool up = pl->use_planes;
-    int nb;
     // Everything runs on the caller's stream; the weight gradient of each dY shares a launch with its data gradient.
 
     // generator: logits = tfin lin_w^T + lin_b
     SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(w.dlogits, Vp, B, c.Vt, w.tfin, E, pl->G(L.lin_w), pl->G(L.lin_b)),
                              pl->dgrad_args(w.dlogits, Vp, B, c.Vt, pl->P(L.lin_w), E, w.gfin, nullptr, 0.f, nullptr), st));
     SLNLP_TRY(layernorm_bwd(w.gfin, w.dec[c.N - 1].t3, pl->P(L.decn_w), w.st_fin, B, E, nullptr, w.gtl, nullptr, 0.f, 0,
-                            rng, w.lnp_fin, &nb, pl->nbD, st));
+                            rng, nullptr, nullptr, 0, st));
     const float* dt = w.gtl;  // gradient w.r.t. the current decoder layer's output
     for (int l = c.N - 1; l >= 0; --l) {
         const DecP& q = L.dec[l];
@@ -275,7 +285,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         const float* t_in = l > 0 ? w.dec[l - 1].t3 : w.t0;
         // norm3 / FFN
         SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, a.gA3, p > 0.f ? a.gB3 : nullptr, p,
-                                pl->dec_site(l, 5), rng, a.lnp3, &nb, pl->nbD, st));
+                                pl->dec_site(l, 5), rng, nullptr, nullptr, 0, st));
         const float* d3 = p > 0.f ? a.gB3 : a.gA3;
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d3, E, B, E, a.h, F, pl->G(q.l2_w), pl->G(q.l2_b)),
                                  pl->dgrad_args(d3, E, B, E, pl->P(q.l2_w), F, a.gh, a.h, ik, nullptr), st));
@@ -283,7 +293,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                  pl->dgrad_args(a.gh, F, B, F, pl->P(q.l1_w), E, a.gt2, nullptr, 0.f, a.gA3), st));
         // norm2 / cross-attention
         SLNLP_TRY(layernorm_bwd(a.gt2, a.y2, pl->P(q.n2_w), a.st2, B, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
-                                pl->dec_site(l, 3), rng, a.lnp2, &nb, pl->nbD, st));
+                                pl->dec_site(l, 3), rng, nullptr, nullptr, 0, st));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
         SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(d2, E, B, E, a.xctx, E, pl->G(q.cout_w), pl->G(q.cout_b)),
                                  pl->dgrad_args(d2, E, B, E, pl->P(q.cout_w), E, a.gxctx, nullptr, 0.f, nullptr), st));
@@ -306,7 +316,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         // norm1 / self-attention (single key)
         hipStream_t sb = st;
         SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
-                                pl->dec_site(l, 1), rng, a.lnp1, &nb, pl->nbD, sb));
+                                pl->dec_site(l, 1), rng, nullptr, nullptr, 0, sb));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
         {
             slnlp_gemm_args dg = pl->dgrad_args(d1, E, B, E, pl->P(q.sout_w), E, a.gv, nullptr, 0.f, nullptr);
@@ -323,7 +333,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
 
     // encoder: needs the complete d memory
     SLNLP_TRY(layernorm_bwd(w.gmem, w.enc[c.N - 1].x2, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.gxl, nullptr, 0.f, 0,
-                            rng, w.lnp_mem, &nb, pl->nbE, st));
+                            rng, nullptr, nullptr, 0, st));
     const float* dx = w.gxl;
     for (int l = c.N - 1; l >= 0; --l) {
         const EncP& q = L.enc[l];
@@ -334,7 +344,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         // LayerNorm backward also emits the bf16 planes of the gradient that feeds the sub-layer's GEMMs
         // (the dropout-masked copy when dropout is on, else dx itself)
         SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
-                                pl->enc_site(l, 3), rng, a.lnp2, &nb, pl->nbE, st, (up && p == 0.f) ? a.d2p.out() : none,
+                                pl->enc_site(l, 3), rng, nullptr, nullptr, 0, st, (up && p == 0.f) ? a.d2p.out() : none,
                                 (up && p > 0.f) ? a.d2p.out() : none));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
         if (up) {
@@ -349,7 +359,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                      pl->dgrad_args(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2), st));
         }
         SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
-                                pl->enc_site(l, 1), rng, a.lnp1, &nb, pl->nbE, st, (up && p == 0.f) ? a.d1p.out() : none,
+                                pl->enc_site(l, 1), rng, nullptr, nullptr, 0, st, (up && p == 0.f) ? a.d1p.out() : none,
                                 (up && p > 0.f) ? a.d1p.out() : none));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
         if (up) {
@@ -368,6 +378,8 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         dx = a.gx0;
     }
     SLNLP_TRY(embed_bwd(X, S, B, S, E, c.Vs, dx, pl->G(L.src_emb), sqrtf((float)E), -1, p, SITE_SRC_EMB, rng, w.emb_scratch_src, st, w.emb_keep));
+    // every LayerNorm's (dgamma, dbeta): chunk sums in one launch, then the chunks added in order
+    SLNLP_TRY(ln_param_partial(w.ln_ptable, nullptr, 5 * c.N + 2, E, M, B, c.B * c.S, c.B, st));
     SLNLP_TRY(ln_param_reduce(w.ln_table, 5 * c.N + 2, E, st));
     return 0;
 }

@@ -174,6 +174,7 @@ struct Ws {
     char* gscr[1];          // split-K scratch of the grouped GEMM launches (one stream: one scratch)
     size_t gscr_bytes;
     slnlp_ln_reduce_entry* ln_table;
+    LnPartialEntry* ln_ptable;   // the same LayerNorms' (dy, x, stats, partial) for the one ln_param_partial launch of a backward
     size_t bytes;
 };
 
@@ -277,6 +278,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     w.opt_partials = b.take<float>(1024);
     w.attn_scratch = c.S > 64 ? (float*)b.take<char>(attn_long_scratch_bytes(c.B, c.S, c.H)) : nullptr;
     w.ln_table = b.take<slnlp_ln_reduce_entry>(5 * c.N + 2);
+    w.ln_ptable = b.take<LnPartialEntry>(5 * c.N + 2);
     // ---- bf16 operand planes (only used when E and F are multiples of 64)
     const size_t Mp = (M + 63) / 64 * 64;
     const bool q8 = c.precision == 8;
@@ -333,7 +335,7 @@ struct slnlp_tf_plan {
     const int64_t* last_X = nullptr;
     const int64_t* last_y = nullptr;
     std::map<int, hipGraphExec_t> graphs;   // one captured train step per batch size, kept until destroy
-    int nbE = 0, nbD = 0;  // LN-backward block counts of the FULL batch (fixed: the reduce table is static)
+    int nbE = 0, nbD = 0;  // (dgamma, dbeta) chunk counts of the FULL batch (fixed: the reduce table is static)
     int destroy_sync = 1;  // slnlp_tf_set_destroy_sync: wait for the device before the plan goes away (launch.hpp)
     // Lockstep (lockstep.hip): where this fit's per-step outputs go while it advances as one of K fits -- an epoch-long
     // log-prob buffer and a per-batch loss history, indexed through two device scalars the driver updates per step

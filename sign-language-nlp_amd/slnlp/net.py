@@ -35,12 +35,16 @@ from .data import TokenDataset
 # module construction consumes torch's global CPU generator (initial weights): concurrent fits take turns
 INIT_LOCK = threading.RLock()
 
-# ONE stream per device for every estimator of the process.  Measured on MI355X / ROCm 7.2 (tools/probes/probe_concurrent*.py): when
-# kernels of this library run on several hardware queues at once -- three fits on three streams -- a consumer kernel can read
-# 64-byte pieces of its producer kernel's output stale (whole LayerNorm-backward rows changed with bit-identical inputs in the
-# final workspace), so fits influenced each other and grid scores changed from run to run.  With one stream (or
-# GPU_MAX_HW_QUEUES=1) every result is bit-identical to the fit running alone.  Fits that share a GPU therefore share a stream:
-# host threads still overlap their host work (initialisation, epoch metrics, Python), the GPU runs one kernel sequence.
+# Which stream a fit runs on.  "thread" (default): one stream per host thread and device -- the grid search's `fits_per_gpu` host
+# threads feed separate hardware queues, so one unit's small launches (the decoder's [B, E] chain, the optimizer) run beside
+# another's; measured +17 % folds/hr on bench.py's grid sample, scores bit-identical (bench.py prints their CRC-32).
+# "device": one stream per device for every estimator of the process (rounds 2's rule, SLNLP_STREAM_MODE=device).
+# History: round 2 measured that fits on several queues changed each other's results -- whole LayerNorm-
+# backward rows differed from run to run with bit-identical inputs -- and shipped the one-stream rule.  Round 3 isolated the one
+# victim kernel (the LayerNorm backward that kept its dgamma / dbeta accumulators live across rows; GEMMs, attention and
+# layernorm_fwd never differed), split it into a pure row kernel and a column-sum kernel, and every probe -- three processes,
+# three streams, the grid's scores across stream modes, tests/test_streams_gpu.py -- has been bit-identical since.
+STREAM_MODE = os.environ.get("SLNLP_STREAM_MODE", "thread")      # "thread" | "device"
 _DEVICE_STREAMS = {}
 _DEVICE_STREAMS_LOCK = threading.Lock()
 
@@ -57,10 +61,11 @@ def device_stream(dev):
     dev = torch.device(dev)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, threading.get_ident()) if STREAM_MODE == "thread" else dev.index
     with _DEVICE_STREAMS_LOCK:
-        st = _DEVICE_STREAMS.get(dev.index)
+        st = _DEVICE_STREAMS.get(key)
         if st is None:
-            st = _DEVICE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+            st = _DEVICE_STREAMS[key] = torch.cuda.Stream(device=dev)
         return st
 
 
@@ -328,6 +333,11 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         kw = self._sub("module")
         kw.setdefault("device", dev)
         self._stream = device_stream(dev)
+        if STREAM_MODE == "thread":
+            # the library's own default orders the step entry points of different streams (for C-API callers that bring their
+            # own streams); the host threads of a grid search are meant to overlap
+            from . import _lib
+            _lib.load().slnlp_set_stream_policy(0)
         with torch.cuda.stream(self._stream):            # the weight draw / upload too: nothing of a fit runs on another queue
             self.module_ = _resolve(self.module)(**kw).to(dev)
         self.criterion_ = _resolve(self.criterion)(**self._sub("criterion"))

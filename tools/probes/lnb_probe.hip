@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void lnb_kernel(const float* __restrict__ dy, 
         int cb = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float4 back = *reinterpret_cast<const volatile float4*>(dx + (long)row * E + lane * 4 + u * 256);
+            const volatile float* bp = dx + (long)row * E + lane * 4 + u * 256;
+            const float4 back = make_float4(bp[0], bp[1], bp[2], bp[3]);
             cb ^= bits4(back) * (u + 1);
         }
         cb = wave_xor(cb * (2 * lane + 1));

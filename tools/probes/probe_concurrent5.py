@@ -27,7 +27,7 @@ buf = C.create_string_buffer(1 << 16)
 _lib.check(_lib.load().slnlp_tf_debug_layout(C.byref(engs[1].cfg), buf, len(buf)), "layout")
 lay = [(l.split()[0], int(l.split()[1])) for l in buf.value.decode().strip().split("\n")]
 names, offs = [n for n, _ in lay], [o for _, o in lay]
-act_end = dict(lay)["wp.hi"]
+act_end = dict(lay)["opt_partials"]     # activations and gradients only: the device tables behind them stay
 E, F, M, B = c["E"], c["F"], c["B"] * c["S"], c["B"]
 
 def width(name):          # row length (floats) of a buffer, for row / column reporting
