@@ -113,6 +113,16 @@ __device__ __forceinline__ float2 ld_agent2(const float* p) {
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
+#if SLNLP_PROBE_FENCES == 128
+// timeline probe build (tools/probes/probe_tile_timeline.py): every workgroup records 100 MHz timestamps of its phases
+constexpr int TS_MAX = 1 << 16;
+__device__ unsigned long long g_ts[TS_MAX][6];
+__device__ unsigned g_ts_n;
+#define TS_MARK(slot) do { if (threadIdx.x == 0) ts[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TS_MARK(slot) do { } while (0)
+#endif
+
 // One block's work: output tile (bx, by) of the job, K-tiles [kt0, kt1).
 //
 // Tile geometry (template): BM x BN output tile, 8 waves as 4 (M) x 2 (N), each wave a (BM/4) x (BN/2) sub-tile = MT x NT MFMA
@@ -128,6 +138,24 @@ __device__ __forceinline__ float2 ld_agent2(const float* p) {
 // the geometry, so every geometry accumulates every output element in the same order: identical bits.
 template <int NSPLIT, bool AK, bool BK, int BM, int BN, int BKS, int NST>
 __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
+#if SLNLP_PROBE_FENCES == 128
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    struct TsFlush {
+        unsigned long long* t;
+        __device__ ~TsFlush() {
+            if (threadIdx.x == 0) {
+                t[4] = __builtin_amdgcn_s_memrealtime();
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+                t[5] = ((unsigned long long)hw << 32) | blockIdx.x;
+                const unsigned i = atomicAdd(&g_ts_n, 1u);
+                if (i < (unsigned)TS_MAX)
+                    for (int k = 0; k < 6; ++k) g_ts[i][k] = t[k];
+            }
+        }
+    } ts_flush{ts};
+    TS_MARK(0);
+#endif
     constexpr int NP = NSPLIT == 3 ? 2 : 1;
     constexpr int SUBM = BM / PT, SUBN = BN / PT;            // 64-row plane images per operand panel
     constexpr int MT = BM / 64, NT = BN / 32;                // 16 x 16 MFMA tiles per wave: (BM/4)/16 x (BN/2)/16
@@ -219,6 +247,9 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NST - 2) * PIECES) : "memory");
         __builtin_amdgcn_s_barrier();                      // ... and so has every other wave's part
         asm volatile("" ::: "memory");
+#if SLNLP_PROBE_FENCES == 128
+        if (kt == kt0) TS_MARK(1);
+#endif
         issue(kt + NST - 1, (it + NST - 1) % NST);
         const unsigned short* s = smem + (it % NST) * STAGE;
 #pragma unroll
@@ -280,6 +311,7 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
             }
         }
     }
+    TS_MARK(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the dummy prefetches before LDS is reused / freed
     __builtin_amdgcn_s_barrier();
     float* rs = reinterpret_cast<float*>(smem);
@@ -359,6 +391,7 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         if (tid == 0) __hip_atomic_store(job.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     if (do_rowsum && tid < BM && bm0 + tid < M) g.rowsum_a[bm0 + tid] = rs_row;
+    TS_MARK(3);
 
     // ---- epilogue: +bias -> activation -> gate -> dropout -> +resid ; fp32 store (+ optional bf16 planes)
     const int crow = (lane >> 4) << 2, ccol = lane & 15;
@@ -748,15 +781,21 @@ constexpr int BIG_TILE_MIN_UNITS = 200;    // a launch takes 128 x 128 tiles whe
 
 // 128 x 128 tiles move half the operand bytes per FLOP through the L2 -> LDS path and issue half the LDS fragment reads per MFMA;
 // they pay once a launch has about a workgroup per CU (measured, tools/bench_plane_tiles.py: 220 tiles +10 %, 124 tiles -60 %).
-// Which ring: 64-k x 2 stages (128 KiB, one workgroup per CU) for short K loops -- at K = 512 a 32-k ring spends its time in
-// barriers -- and 32-k x 2 stages (64 KiB, two workgroups per CU, each the other's cover in prologue and epilogue) once every
-// job's K loop is at least 1024 long (configs[4]: +10 %).
+// Which ring (per-workgroup timelines, tools/probes/probe_tile_timeline.py: a 128 x 128 x 64 workgroup spends 1.6 us filling the
+// ring, 11 us in the K loop of K = 512 and 6 us in its epilogue -- with one workgroup per CU nothing covers the first and the last):
+//   * 32-k x 2 stages (64 KiB, two workgroups per CU, each the other's cover) once every K loop is at least 1024 long
+//     (configs[4] gradient groups: +10 %), and from two workgroups per CU up whatever K: forward launches (15 merged fits
+//     [36000 x 512] x [512 x 512] 88 -> 74 us, configs[4] in_proj 342 -> 293 us) and the merged gradient groups of a lockstep
+//     unit (a 15-fit cfg2 step 20.2 -> 19.5 ms with every launch on this ring; 21.3 on the 64-k ring, 21.8 on 64 x 64 tiles);
+//   * 64-k x 2 stages (128 KiB, one workgroup per CU) for launches of about one tile per CU (cfg2 in_proj, 228 tiles: 20.6 against
+//     21.3 us; at K = 512 the 32-k ring pays twice the barriers and has no second workgroup to hide them behind).
+constexpr int TWO_PER_CU_UNITS = 512;
 int plane_geo_auto(long units128, int min_k, bool fp8) {
     if (fp8) return 0;                                       // (fp8 launches have their own geometries: q8_geo_auto)
     const int forced = g_plane_geo.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
     if (units128 < BIG_TILE_MIN_UNITS) return 0;
-    return min_k >= 1024 ? 2 : 1;
+    return (min_k >= 1024 || units128 >= TWO_PER_CU_UNITS) ? 2 : 1;
 }
 long plane_units128(const slnlp_gemm_args& a, int nks) { return (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) * (nks < 1 ? 1 : nks); }
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
@@ -1063,3 +1102,18 @@ extern "C" int slnlp_split_planes(const float* x, int64_t ld, int R, int C, uint
                                   void* stream) {
     return slnlp::split_planes(x, ld, R, C, hi, lo, ldp, (hipStream_t)stream);
 }
+
+#if SLNLP_PROBE_FENCES == 128
+// probe build only: copy the recorded workgroup timelines to the host and reset the recorder; returns the number recorded
+extern "C" int slnlp_probe_ts(unsigned long long* dst, int max_entries) {
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(slnlp::g_ts_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > (unsigned)slnlp::TS_MAX) n = slnlp::TS_MAX;
+    if ((int)n > max_entries) n = max_entries;
+    if (n && hipMemcpyFromSymbol(dst, HIP_SYMBOL(slnlp::g_ts), (size_t)n * 6 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(slnlp::g_ts_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif

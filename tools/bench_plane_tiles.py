@@ -54,12 +54,48 @@ def case(name, Mtok, Nout, Kin, split, copies=1, check_ref=False):
     check(load().slnlp_set_plane_tile(0), "set_plane_tile")
     return same
 
+def fwd_case(name, Mtok, Nout, Kin, planes=False):
+    """Y = X W^T alone (the forward launches); planes=True: with bias, residual and the bf16 planes of Y, as in a train step."""
+    g = torch.Generator().manual_seed(0)
+    X, W = [torch.randn(*s, generator=g).cuda() for s in ((Mtok, Kin), (Nout, Kin))]
+    Xp, Wp = ops.split_planes(X), ops.split_planes(W)
+    kw = {}
+    if planes:
+        kw = dict(bias=torch.randn(Nout, generator=g).cuda(), resid=torch.randn(Mtok, Nout, generator=g).cuda())
+    j, Y = ops.plane_job(Xp, Wp, M=Mtok, N=Nout, K=Kin, a_kmajor=True, b_kmajor=True, **kw)
+    if planes:
+        Yp = ops.split_planes(torch.zeros(Mtok, Nout).cuda())
+        j.C_hi, j.C_lo, j.ldc_p = Yp[0].data_ptr(), Yp[1].data_ptr(), Yp[0].stride(0)
+        keep.append((Yp, kw))
+    scr = ops.gemm_group([j], [1])
+    res = {}
+    for tile in TILES:
+        check(load().slnlp_set_plane_tile(tile), "set_plane_tile")
+        Y.fill_(float("nan")); ops.gemm_group([j], [1], scr); torch.cuda.synchronize()
+        res[tile] = Y.clone()
+        t = timeit(lambda: ops.gemm_group([j], [1], scr))
+        print(f"{name:34s} tile {tile:6d}: {t:8.1f} us  {2.0 * Mtok * Nout * Kin / t / 1e6:7.1f} TFLOP/s", flush=True)
+    same = all(torch.equal(res[TILES[0]], res[t]) for t in TILES[1:])
+    print(f"{'':34s} tiles bit-identical: {same}", flush=True)
+    check(load().slnlp_set_plane_tile(0), "set_plane_tile")
+    return same
+
 keep = []
 TILES = (64, 128, 12832)                    # slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages, 128 KiB), 128 x 128 (32-k x 2, 64 KiB)
 DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 big_only = len(sys.argv) > 1 and sys.argv[1] == "big"
 ok = True
+if len(sys.argv) > 1 and sys.argv[1] == "fwd":      # forward launches (no split-K): which ring pays
+    for pl in (False, True):
+        tag = " +planes" if pl else ""
+        ok &= fwd_case("cfg2 in_proj 2400x1536x512" + tag, 2400, 1536, 512, pl)
+        ok &= fwd_case("15 fits 36000x512x512" + tag, 36000, 512, 512, pl)
+        ok &= fwd_case("15 fits in_proj 36000x1536x512" + tag, 36000, 1536, 512, pl)
+        ok &= fwd_case("configs[4] FFN 16384x512x1024" + tag, 16384, 512, 1024, pl)
+        ok &= fwd_case("configs[4] in_proj 16384x3072x1024" + tag, 16384, 3072, 1024, pl)
+    print("ALL TILES BIT-IDENTICAL" if ok else "TILE MISMATCH")
+    sys.exit(0 if ok else 1)
 if not big_only:
     ok &= case("cfg2 dgrad+wgrad E512", 2400, 512, 512, 3, check_ref=True)
     ok &= case("cfg2 x2 fits (one launch)", 2400, 512, 512, 3, copies=2)

@@ -1,0 +1,62 @@
+"""Where a plane-GEMM workgroup spends its time: per-workgroup timestamps (100 MHz) of kernel entry, first K-step landed, K loop
+done, split-K meeting done, epilogue done -- from the timeline probe build (make PROBE=128 in sign-language-nlp_amd/).
+
+    SLNLP_PROBE_LIB=128 python tools/probes/probe_tile_timeline.py
+"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sign-language-nlp_amd")]
+os.environ.setdefault("SLNLP_PROBE_LIB", "128")
+import numpy as np, torch
+from slnlp import ops
+from slnlp._lib import load, check
+lib = load()
+lib.slnlp_probe_ts.restype = C.c_int
+lib.slnlp_probe_ts.argtypes = [C.c_void_p, C.c_int]
+buf = np.zeros((1 << 16, 6), dtype=np.uint64)
+
+def read():
+    n = lib.slnlp_probe_ts(buf.ctypes.data, buf.shape[0])
+    assert n >= 0
+    return buf[:n].astype(np.int64).copy()
+
+def report(name, launch, tile):
+    check(lib.slnlp_set_plane_tile(tile), "tile")
+    for _ in range(3): launch()
+    read()
+    launch()
+    t = read()
+    check(lib.slnlp_set_plane_tile(0), "tile")
+    t0 = t[:, 0].min()
+    us = lambda a: a / 100.0
+    fill, loop, meet, epi, tot = [us(t[:, i + 1] - t[:, i]) for i in range(4)] + [us(t[:, 4] - t[:, 0])]
+    start = us(t[:, 0] - t0)
+    q = lambda a: "%6.2f %6.2f %6.2f" % tuple(np.percentile(a, [10, 50, 90]))
+    print(f"{name} tile {tile}: {len(t)} workgroups, launch span {us(t[:, 4].max() - t0):7.2f} us")
+    print(f"    p10/p50/p90 us: first K-step landed {q(fill)} | K loop {q(loop)} | drain+meeting {q(meet)} | epilogue {q(epi)} | total {q(tot)}")
+    print(f"    workgroup start times: p10/p50/p90 {q(start)}; started within 2 us of the first: {(start < 2).sum()}")
+
+g = torch.Generator().manual_seed(0)
+def fwd(M, N, K):
+    X, W = [torch.randn(*s, generator=g).cuda() for s in ((M, K), (N, K))]
+    Xp, Wp = ops.split_planes(X), ops.split_planes(W)
+    j, Y = ops.plane_job(Xp, Wp, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True)
+    scr = ops.gemm_group([j], [1])
+    return lambda: ops.gemm_group([j], [1], scr)
+
+def grads(M, N, K, split):
+    dY, X, W = [torch.randn(*s, generator=g).cuda() for s in ((M, N), (M, K), (N, K))]
+    dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+    rs = torch.empty(N, device="cuda")
+    jw, dW = ops.plane_job(dYp, Xp, M=N, N=K, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
+    jd, dX = ops.plane_job(dYp, Wp, M=M, N=K, K=N, a_kmajor=True, b_kmajor=False)
+    scr = ops.gemm_group([jw, jd], [split, 1])
+    return lambda: ops.gemm_group([jw, jd], [split, 1], scr)
+
+report("cfg2 forward 2400x512x512        ", fwd(2400, 512, 512), 64)
+report("cfg2 dgrad+wgrad (split 3)       ", grads(2400, 512, 512, 3), 64)
+report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 128)
+report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 64)
+report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 12832)
+report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 128)
+report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 12832)
