@@ -115,9 +115,13 @@ def dominant_kernel_roofline(c, precision, dev, workload):
     flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the 3 split-bf16 MFMA passes are not counted)
     tf = flops / (us * 1e-6) / 1e12
     blocks = tw * split + td
-    return {"kernel": f"gemm_planes_kernel<{precision}, 64x64> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {blocks} workgroups",
+    # the launch geometry the library picks for this group (csrc/gemm_planes.hip plane_geo_auto): 64 x 64 tiles under 200 tiles of
+    # 128 x 128, else 128 x 128 on the 32-k ring (two workgroups per CU) from 512 tiles or K loops >= 1024, else on the 64-k ring
+    u128 = cd(E, 128) * cd(F, 128) * split + cd(M, 128) * cd(F, 128)
+    geo, wgs = ("64x64", blocks) if u128 < 200 else ("128x128 32-k ring" if (min(M // split, E) >= 1024 or u128 >= 512) else "128x128 64-k ring", u128)
+    return {"kernel": f"gemm_planes_kernel<{precision}, {geo}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {wgs} workgroups",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}> x{blocks}"),
+            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}, 0> x{blocks}"),
             "us_per_launch_hip_events": round(us, 2), "us_per_launch_rocprof": rocprof_kernel_times(workload), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * (M * E + M * F + E * F) + 4.0 * (M * F + E * F) + 4.0 * M * F,
             "note": "back-to-back launches on one stream (includes launch gaps); flops = 2 GEMMs x 2mnk, the 3 split-bf16 "
@@ -308,7 +312,7 @@ def rocprof_kernel_times(workload):
     """The committed rocprofv3 --kernel-trace view of the same kernel (tools/roofline_kernel_stats.py): its back-to-back
     launches (what the HIP events above time) and its launches inside train steps, or None."""
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", f"r02_bench_{workload}_roofline_kernel.json")))
+        e = json.load(open(os.path.join(ROOT, "profiles", f"r03_bench_{workload}_roofline_kernel.json")))
         return {"back_to_back_avg_us": e["back_to_back"]["avg_us"], "in_step_avg_us": e["in_step"]["avg_us"], "min_us": e["min_us"]}
     except Exception:
         return None
@@ -316,7 +320,7 @@ def rocprof_kernel_times(workload):
 
 def pmc_kernel_traffic(workload, shape):
     """HBM bytes of one launch of `shape` ("kernel xWORKGROUPS") from the same committed PMC passes, or None."""
-    f = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}_step_traffic.json")
+    f = os.path.join(ROOT, "profiles", f"r03_pmc_{workload}_step_traffic.json")
     try:
         e = json.load(open(f))["per_launch"][shape]
         return float(e["fetch_bytes"] + e["write_bytes"])
@@ -326,7 +330,7 @@ def pmc_kernel_traffic(workload, shape):
 
 def pmc_traffic(workload):
     """HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), or None."""
-    f = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}_step_traffic.json")
+    f = os.path.join(ROOT, "profiles", f"r03_pmc_{workload}_step_traffic.json")
     try:
         return float(json.load(open(f))["hbm_bytes_per_step"])
     except Exception:

@@ -317,7 +317,7 @@ __device__ __forceinline__ void layernorm_bwd_rows(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
     const bool drop = dx_drop != nullptr && drop_p > 0.f;
-    const int row0 = (blockIdx.x * 4 + wave) * GS;                 // one group per wave: the launch covers ceil(rows / GS) waves
+    const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * GS;   // one group per wave: the launch covers ceil(rows / GS) waves
     if (row0 >= rows) return;
     float4 g[U];
 #pragma unroll
@@ -546,7 +546,10 @@ int layernorm_bwd(const float* dy, const float* x, const float* gamma, const flo
     const int gs = ln_bwd_group(rows), u = E <= 256 ? 1 : E <= 512 ? 2 : 4;
     auto kern = gs == 4 ? (u == 1 ? layernorm_bwd_kernel_u1g4 : u == 2 ? layernorm_bwd_kernel_u2g4 : layernorm_bwd_kernel_u4g4)
                         : (u == 1 ? layernorm_bwd_kernel_u1g1 : u == 2 ? layernorm_bwd_kernel_u2g1 : layernorm_bwd_kernel_u4g1);
-    SLNLP_TRY(zlaunch(kern, dim3(ceil_div(rows, 4 * gs)), 256, 0, st, "layernorm_bwd",
+    // 4-row groups: ONE wave per workgroup -- 2400 rows are 600 waves, which 150 workgroups of four would park on 150 of the 256
+    // CUs; single-wave workgroups spread over all of them (the kernel is a stream of 16-byte loads and stores per wave)
+    const int wpb = gs == 4 ? 1 : 4;
+    SLNLP_TRY(zlaunch(kern, dim3(ceil_div(rows, wpb * gs)), 64 * wpb, 0, st, "layernorm_bwd",
                       dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, po_dx, po_drop));
     // partial != nullptr: also this LayerNorm's (dgamma, dbeta) chunk sums, for callers that reduce one LayerNorm at a time
     // (the C API, tests); a plan passes nullptr and runs ONE table-driven ln_param_partial launch for all its LayerNorms
