@@ -91,13 +91,6 @@ typedef struct slnlp_gemm_args {
      * e.g. the per-head products of the decoder's cross-attention (attention_mem.hip).  0 or 1: a single GEMM. */
     int32_t batch;
     int64_t batch_stride_a, batch_stride_b, batch_stride_c;
-    /* ln_gamma != NULL (fp32-operand jobs with at most 64 rows, both operands k-major, K a multiple of 64): A is the INPUT of a
-     * LayerNorm over its K columns (torch.nn.LayerNorm, biased variance + ln_eps) and the product runs on the normalised rows
-     * -- the post-LN blocks of nn.Transformer's decoder (transformer.py:82-87 -> torch) without a launch of their own: every
-     * workgroup needs all of A anyway, computes the row statistics itself and normalises on the way into LDS.  The normalised
-     * rows go to ln_y [M, K] (row stride K) and (mean, rstd) to ln_stats [M, 2]: what the residual of a later GEMM and the
-     * LayerNorm backward read. */
-    const float* ln_gamma; const float* ln_beta; float* ln_y; float* ln_stats; float ln_eps;
 } slnlp_gemm_args;
 
 int slnlp_gemm(const slnlp_gemm_args* args, void* stream);

@@ -184,8 +184,6 @@ constexpr int tile_lds_elems() {
     return (NSPLIT == 3 ? 2 : 1) * (TileIO<AK, BM>::PLANE + TileIO<BK, BNT>::PLANE) + 4 * BM * 2;
 }
 
-constexpr int LN_LDS_ELEMS = 64 * 4;     // (mean, rstd) of 64 rows as float2, in unsigned shorts (the LayerNorm prologue)
-
 // One workgroup's tile: block (bid_x, bid_y) of a (grid_x, grid_y) grid over C.
 // KS = 2: the workgroup has two groups of 256 threads; group g runs the K loop over its own half of the K tiles with its own
 // stage images (all loads of both halves are in flight together, the dependent chain of K steps is half as long), group 1 hands
@@ -246,66 +244,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     TA::template fetch<VEC>(g.A, g.lda, bm0, M, (k0 + 1) * BKT, K, tid, ra1);
     TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (k0 + 1) * BKT, K, tid, rb1);
 
-    // ---- LayerNorm prologue (g.ln_gamma; the decoder's post-LN blocks): A is the LayerNorm's INPUT.  Every workgroup of a
-    // narrow launch reads all of A, so each computes the row statistics itself -- thread (row = t / NSEG, segment = t % NSEG)
-    // sums its K / NSEG columns, the NSEG lanes of a row meet by DPP -- in ONE pass over values shifted by the row's first
-    // element (sum and sum of squares of x - x0: no cancellation, x0 is a sample of the row), keeps (mean, rstd) in LDS and
-    // normalises each K tile on its way into the bf16 images.  Column-block 0 also writes the normalised rows and the
-    // statistics out (the residual of a later GEMM and the LayerNorm backward read them).
-    constexpr bool CAN_LN = AK && BK && BNT == 16 && VEC;
-    float2* ln_st = reinterpret_cast<float2*>(smem_base + KS * tile_lds_elems<NSPLIT, AK, BK, BNT>());   // [64] behind the tile images
-    const bool ln = CAN_LN && g.ln_gamma != nullptr;
-    float4 lg0 = make_float4(0.f, 0.f, 0.f, 0.f), lb0 = lg0, lg1 = lg0, lb1 = lg0;
-    if constexpr (CAN_LN) {
-        if (ln) {
-            constexpr int NSEG = 4 * KS;                           // lanes per row: 256 KS threads over 64 rows
-            const int t = threadIdx.x, row = t / NSEG, seg = t % NSEG, len = K / NSEG;   // K % 64 == 0: len is a multiple of 8
-            const float* __restrict__ xr = g.A + (long)min(bm0 + row, M - 1) * g.lda;
-            const float x0 = xr[0];
-            float s1 = 0.f, s2 = 0.f;
-            for (int c = seg * len; c < (seg + 1) * len; c += 8) {
-                const float4 u = *reinterpret_cast<const float4*>(xr + c), v = *reinterpret_cast<const float4*>(xr + c + 4);
-                const float d[8] = {u.x - x0, u.y - x0, u.z - x0, u.w - x0, v.x - x0, v.y - x0, v.z - x0, v.w - x0};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s1 += d[e]; s2 += d[e] * d[e]; }
-            }
-            s1 += dpp_mov<DPP_XOR1>(s1); s2 += dpp_mov<DPP_XOR1>(s2);
-            s1 += dpp_mov<DPP_XOR2>(s1); s2 += dpp_mov<DPP_XOR2>(s2);
-            if (NSEG == 8) { s1 += dpp_mov<DPP_HALF_MIRROR>(s1); s2 += dpp_mov<DPP_HALF_MIRROR>(s2); }
-            const float invK = 1.f / (float)K, m1 = s1 * invK;
-            const float mean = x0 + m1, rstd = rsqrtf(fmaxf(s2 * invK - m1 * m1, 0.f) + g.ln_eps);
-            if (seg == 0) {
-                ln_st[row] = make_float2(mean, rstd);
-                if (bx == 0 && bm0 + row < M) *reinterpret_cast<float2*>(g.ln_stats + 2L * (bm0 + row)) = make_float2(mean, rstd);
-            }
-            const int k0c = min(k0, ktiles - 1) * BKT + ((tid & 15) << 2);
-            lg0 = *reinterpret_cast<const float4*>(g.ln_gamma + k0c);
-            lb0 = *reinterpret_cast<const float4*>(g.ln_beta + k0c);
-            const int k1c = min(k0 + 1, ktiles - 1) * BKT + ((tid & 15) << 2);
-            lg1 = *reinterpret_cast<const float4*>(g.ln_gamma + k1c);
-            lb1 = *reinterpret_cast<const float4*>(g.ln_beta + k1c);
-            __syncthreads();
-        }
-    }
-    // normalise the prefetched A tile `kt` in registers (a thread's NV pieces share their 4 columns: one gamma / beta float4)
-    auto ln_apply = [&](float4 (&ra)[TA::NV], int kt, const float4& gm, const float4& bt) {
-#pragma unroll
-        for (int u = 0; u < TA::NV; ++u) {
-            const int row = (tid >> 4) + 16 * u;
-            const float2 st = ln_st[row];
-            float4 v = ra[u];
-            v.x = (v.x - st.x) * st.y * gm.x + bt.x; v.y = (v.y - st.x) * st.y * gm.y + bt.y;
-            v.z = (v.z - st.x) * st.y * gm.z + bt.z; v.w = (v.w - st.x) * st.y * gm.w + bt.w;
-            ra[u] = v;
-            if (bx == 0 && bm0 + row < M) *reinterpret_cast<float4*>(g.ln_y + (long)(bm0 + row) * K + kt * BKT + ((tid & 15) << 2)) = v;
-        }
-    };
-    auto ln_fetch = [&](int kt, float4& gm, float4& bt) {
-        const int kc = min(kt, ktiles - 1) * BKT + ((tid & 15) << 2);
-        gm = *reinterpret_cast<const float4*>(g.ln_gamma + kc);
-        bt = *reinterpret_cast<const float4*>(g.ln_beta + kc);
-    };
-
     auto consume = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -347,26 +285,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
             const int kt = k0 + it;
             lds_barrier();
             if (KS == 1 || kt < k1) {
-                if constexpr (CAN_LN) { if (ln) ln_apply(ra0, kt, lg0, lb0); }
                 TA::template stash<NSPLIT, EDGE>(As, tid, ra0, bm0, M, kt * BKT, K);
                 TB::template stash<NSPLIT, EDGE>(Bs, tid, rb0, bn0, N, kt * BKT, K);
             }
             lds_barrier();
             TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 2) * BKT, K, tid, ra0);
             TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 2) * BKT, K, tid, rb0);
-            if constexpr (CAN_LN) { if (ln) ln_fetch(kt + 2, lg0, lb0); }
             if (KS == 1 || kt < k1) consume();
             if (it + 1 >= trips) break;
             lds_barrier();
             if (KS == 1 || kt + 1 < k1) {
-                if constexpr (CAN_LN) { if (ln) ln_apply(ra1, kt + 1, lg1, lb1); }
                 TA::template stash<NSPLIT, EDGE>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
                 TB::template stash<NSPLIT, EDGE>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
             }
             lds_barrier();
             TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 3) * BKT, K, tid, ra1);
             TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 3) * BKT, K, tid, rb1);
-            if constexpr (CAN_LN) { if (ln) ln_fetch(kt + 3, lg1, lb1); }
             if (KS == 1 || kt + 1 < k1) consume();
         }
     };
@@ -445,7 +379,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
 
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
 __global__ __launch_bounds__(256 * KS) void gemm_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, AK, BK, BNT>() + LN_LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, AK, BK, BNT>()];
     probe_kernel_begin();
     gemm_tile<NSPLIT, AK, BK, BNT, VEC, KS>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
     probe_kernel_end();
@@ -457,7 +391,7 @@ __global__ __launch_bounds__(256 * KS) void gemm_kernel(const GemmParams p) {
 template <int NSPLIT, int KS>
 __global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupParams P, const GemmJob* __restrict__ tab,
                                                               const int* __restrict__ blockmap) {
-    __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, false, false, 64>() + LN_LDS_ELEMS];   // the largest variant
+    __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, false, false, 64>()];   // the largest variant
     GemmParams p;
     int variant, gx, gy, lid;
     if (tab) {
@@ -545,10 +479,6 @@ static int fill_params(const slnlp_gemm_args& a, GemmParams& p) {
     SLNLP_CHECK_ARG(!(a.a_kmajor == 0 && a.b_kmajor != 0), "gemm: layout (A m-major, B k-major) not built");
     SLNLP_CHECK_ARG(a.drop_head_dim >= 0 && (a.drop_head_dim == 0 || a.N % a.drop_head_dim == 0),
                     "gemm: drop_head_dim %d does not divide N %d", a.drop_head_dim, a.N);
-    SLNLP_CHECK_ARG(!a.ln_gamma || (a.ln_beta && a.ln_y && a.ln_stats && a.a_kmajor && a.b_kmajor && a.M <= BM && !a.rowsum_a &&
-                                    a.K % BKT == 0 && a.lda == a.K && vec_ok(a.A, a.lda) && vec_ok(a.B, a.ldb) && vec_ok(a.ln_gamma, 4) &&
-                                    vec_ok(a.ln_beta, 4) && vec_ok(a.ln_y, a.K) && a.batch <= 1),
-                    "gemm: the LayerNorm prologue needs <= 64 rows, k-major 16-byte aligned operands with lda == K, K %% 64 == 0");
     p.a = a;
     p.drop_thr = dropout_threshold(a.drop_p);
     p.drop_scale = 1.f / (1.f - a.drop_p);

@@ -57,7 +57,6 @@ __device__ __forceinline__ void launder(slnlp_gemm_args& a) {
     a.A_hi = as_global(a.A_hi); a.A_lo = as_global(a.A_lo); a.B_hi = as_global(a.B_hi); a.B_lo = as_global(a.B_lo);
     a.C_hi = as_global(a.C_hi); a.C_lo = as_global(a.C_lo);
     a.col_scale = as_global(a.col_scale); a.C_q8 = as_global(a.C_q8);
-    a.ln_gamma = as_global(a.ln_gamma); a.ln_beta = as_global(a.ln_beta); a.ln_y = as_global(a.ln_y); a.ln_stats = as_global(a.ln_stats);
 }
 
 // kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)

@@ -145,21 +145,17 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
 // Decoder layer l up to its cross-attention query: self-attention over ONE key (softmax == 1 -> out_proj(v_proj(t));
 // the q/k rows of in_proj are dead; in train mode the weight-1 "attention" is still dropped per (row, head) -- fused into
 // the V projection), residual + norm1, then q = in_proj_q(t1) (transformer.py:82-87).
-// t_ln != nullptr: `t` is the output of a LayerNorm that has not run yet -- the first product normalises it (LnIn)
-int slnlp_tf_plan::dec_self_block(int l, const float* t, int B, float p, hipStream_t st, const LnIn* t_ln) const {
+int slnlp_tf_plan::dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const {
     const slnlp_tf_plan* pl = this;
     const int E = cfg.E, dh = E / cfg.H;
+    const unsigned long long* rng = buf.rng;
+    (void)rng;
     const DecP& q = L.dec[l];
     const DecA& a = w.dec[l];
-    SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, st, dh, t_ln));
+    SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, st, dh));
     SLNLP_TRY(pl->linear(a.v, B, E, pl->P(q.sout_w), E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, st));
-    if (ln_fusable(B, E)) {     // norm1 inside the query projection's launch
-        const LnIn n1{a.y1, pl->P(q.n1_w), pl->P(q.n1_b), a.t1, a.st1};
-        SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st, 0, &n1));
-    } else {
-        SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
-        SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st));
-    }
+    SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
+    SLNLP_TRY(pl->linear(a.t1, B, E, pl->P(q.cin_w), E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, st));
     return 0;
 }
 

@@ -380,20 +380,11 @@ struct slnlp_tf_plan {
     int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
     int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
 
-    int dec_self_block(int l, const float* t, int B, float p, hipStream_t st, const LnIn* t_ln = nullptr) const;
+    int dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const;
 
     // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
-    // A LayerNorm whose output first feeds a B-row product: the product's launch normalises its input itself (gemm.hip, the
-    // LayerNorm prologue), writes the normalised rows to `y` and (mean, rstd) to `stats` -- no launch of its own.
-    struct LnIn {
-        const float* x_pre;     // the LayerNorm's input [M, K]
-        const float* gamma;
-        const float* beta;
-        float* y;               // normalised rows [M, K]: the product's A operand, written by the product's launch
-        float* stats;           // [M, 2]
-    };
     int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
-               float p, int site, const float* resid, hipStream_t st, int drop_head_dim = 0, const LnIn* ln = nullptr) const {
+               float p, int site, const float* resid, hipStream_t st, int drop_head_dim = 0) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = x; a.lda = K; a.a_kmajor = 1;
@@ -404,14 +395,8 @@ struct slnlp_tf_plan {
         a.resid = resid; a.ldr = ldy;
         a.precision = prec3();
         a.drop_head_dim = drop_head_dim;
-        if (ln) {
-            a.A = ln->x_pre;
-            a.ln_gamma = ln->gamma; a.ln_beta = ln->beta; a.ln_y = ln->y; a.ln_stats = ln->stats; a.ln_eps = 1e-5f;
-        }
         return gemm(a, st);
     }
-    // the fused form needs K % 64 == 0 and at most 64 rows (gemm.hip); otherwise the LayerNorm runs as its own launch
-    bool ln_fusable(int M, int K) const { return M <= 64 && K % 64 == 0; }
     // dx[M,Kin] = dy[M,Nout] W[Nout,Kin]  (*gate) (+resid)
     slnlp_gemm_args dgrad_args(const float* dy, long ldy, int M, int Nout, const float* W, int Kin, float* dx,
                                const float* gate, float gate_scale, const float* resid) const {

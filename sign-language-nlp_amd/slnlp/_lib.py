@@ -29,8 +29,7 @@ class GemmArgs(C.Structure):
                 ("A_hi", vp), ("A_lo", vp), ("lda_p", i64), ("B_hi", vp), ("B_lo", vp), ("ldb_p", i64),
                 ("C_hi", vp), ("C_lo", vp), ("ldc_p", i64), ("drop_head_dim", i32),
                 ("col_scale", vp), ("C_q8", vp),
-                ("batch", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64),
-                ("ln_gamma", vp), ("ln_beta", vp), ("ln_y", vp), ("ln_stats", vp), ("ln_eps", f32)]
+                ("batch", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64)]
 
 
 class TfConfig(C.Structure):
