@@ -148,3 +148,28 @@ def test_grid_scores_do_not_depend_on_the_stream_mode(monkeypatch):
         scores.setdefault(mode, []).append(np.asarray(gs.cv_results_["mean_test_score"], dtype=np.float64).tobytes())
     load().slnlp_set_stream_policy(1)
     assert scores["device"][0] == scores["thread"][0] == scores["thread"][1]
+
+
+@pytest.mark.parametrize("module", ["model.EncoderDecoderLSTMAttn", "model.EncoderDecoderGRUAttn"])
+def test_rnn_grid_scores_do_not_depend_on_the_stream_mode(monkeypatch, module):
+    """The same for the encoder-decoder RNN estimators at working sizes (E 256, hidden 256, 2 layers, batch 50, len 48): three
+    host threads on a stream each against one shared stream, twice."""
+    import numpy as np
+    from slnlp import net
+    from slnlp.data import synthetic_dataset
+    from slnlp.grid import ShardedGridSearchCV
+    from slnlp.net import NeuralNetClassifier
+    ds = synthetic_dataset(300, seq_len=48, src_vocab=3000, n_labels=50, seed=3, min_len=8)
+    factory = lambda: NeuralNetClassifier(
+        module=module, module__dropout=0.1, module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y, module__batch_first=True,
+        module__embedding_size=256, module__hidden_size=256, module__num_layers=2, criterion="torch.nn.CrossEntropyLoss",
+        criterion__ignore_index=1, optimizer="torch.optim.SGD", optimizer__momentum=0.9, lr=0.05, max_epochs=2, batch_size=50,
+        device="cuda:0", gradient_clipping={"gradient_clip_value": 0.5}, scoring=["neg_log_loss"], use_graph=False)
+    grid = {"lr": [0.05, 0.02, 0.01], "module__dropout": [0.1, 0.3]}
+    scores = {}
+    for mode in ("device", "thread", "thread"):
+        monkeypatch.setattr(net, "STREAM_MODE", mode)
+        gs = ShardedGridSearchCV(factory, grid, cv=3, refit=False, device="cuda:0", fits_per_gpu=3, lockstep=2).fit(ds)
+        scores.setdefault(mode, []).append(np.asarray(gs.cv_results_["mean_test_score"], dtype=np.float64).tobytes())
+    load().slnlp_set_stream_policy(1)
+    assert scores["device"][0] == scores["thread"][0] == scores["thread"][1]
