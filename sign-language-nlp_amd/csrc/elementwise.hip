@@ -298,13 +298,11 @@ SLNLP_ZKERNEL(layernorm_fwd_kernel, 256, layernorm_fwd_body)
 //   layernorm_bwd_rows   dx (and its dropout-masked copy, and their bf16 planes): purely row-wise, one wave per GS consecutive rows;
 //   ln_param_partial     the (dgamma, dbeta) column sums of the same (dy, x, stats), per chunk of rows, for EVERY LayerNorm of the
 //                        step in one table-driven launch at the end of backward; ln_param_reduce adds the chunks in order.
-// Why: the round-2 kernel also kept the (dgamma, dbeta) accumulators and combined them through LDS at its end.  That kernel -- and
-// only it -- returned different dx rows (64-byte pieces, whole rows) when kernels of another hardware queue ran beside it, on
-// constant and intact inputs (tools/probes/probe_victim.py: 40-85 % of the runs differ beside two other fits, never alone; the
-// GEMMs and layernorm_fwd never).  Sixteen builds of it (tools/probes/probe_victim2.py) gave an exact pattern: the row kernel is
-// immune iff the rows per wave are a compile-time constant AND no accumulators stay live across its rows -- however they are
-// written out -- and with it in that form three concurrent fits (threads or processes) are bit-identical to solo runs
-// (DESIGN.md section 6).  The mechanism below the ISA is not known; the form is what the library ships, for every row kernel.
+// History: the round-2 kernel also kept the (dgamma, dbeta) accumulators and combined them through LDS at its end, and was the
+// kernel in which the multi-queue nondeterminism of DESIGN.md section 6 first showed (40-85 % of its runs differed beside two
+// other fits).  The cause turned out to be the packed fp32 instructions its arithmetic compiled to (the library is built without
+// them now, see the Makefile), not its structure; the split stayed because it is faster (15.0 -> 12.8 us per launch at cfg2, one
+// 32 us column-sum launch per step) and keeps every instance under 256 registers.
 //
 // U = float4 slots per lane (E <= 256 * U), GS = rows per wave (4: many rows; 1: the decoder's B rows, spread over as many waves as
 // possible), RB = rows whose loads are in flight together (U * RB <= 8: every instance stays under 256 registers).

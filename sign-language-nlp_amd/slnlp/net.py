@@ -39,11 +39,10 @@ INIT_LOCK = threading.RLock()
 # threads feed separate hardware queues, so one unit's small launches (the decoder's [B, E] chain, the optimizer) run beside
 # another's; measured +17 % folds/hr on bench.py's grid sample, scores bit-identical (bench.py prints their CRC-32).
 # "device": one stream per device for every estimator of the process (rounds 2's rule, SLNLP_STREAM_MODE=device).
-# History: round 2 measured that fits on several queues changed each other's results -- whole LayerNorm-
-# backward rows differed from run to run with bit-identical inputs -- and shipped the one-stream rule.  Round 3 isolated the one
-# victim kernel (the LayerNorm backward that kept its dgamma / dbeta accumulators live across rows; GEMMs, attention and
-# layernorm_fwd never differed), split it into a pure row kernel and a column-sum kernel, and every probe -- three processes,
-# three streams, the grid's scores across stream modes, tests/test_streams_gpu.py -- has been bit-identical since.
+# History: round 2 measured that fits on several queues changed each other's results and shipped the
+# one-stream rule.  Round 3 found the cause -- packed fp32 VALU instructions compute wrongly when a workgroup of another kernel
+# shares the CU -- and builds the library without them; every probe (three processes, three streams, the grid's scores across
+# stream modes, tests/test_streams_gpu.py) has been bit-identical since.
 STREAM_MODE = os.environ.get("SLNLP_STREAM_MODE", "thread")      # "thread" | "device"
 _DEVICE_STREAMS = {}
 _DEVICE_STREAMS_LOCK = threading.Lock()

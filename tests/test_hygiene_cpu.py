@@ -246,8 +246,7 @@ def test_recipe_init_draws_the_reference_distributions(cls_name, kw):
 
 def test_no_kernel_of_the_built_library_needs_more_than_256_registers():
     """The code object's own metadata, no compiler run: every kernel's register allocation (VGPRs + AGPRs, `.vgpr_count` on the
-    unified file) stays within 256.  layernorm_bwd once took 347 (256 + 91 AGPRs) and was the one kernel that returned wrong
-    rows whenever waves of another hardware queue shared its SIMDs (tools/probes/probe_victim.py)."""
+    unified file) stays within 256 (spill-free occupancy; layernorm_bwd once took 347 = 256 + 91 AGPRs)."""
     import importlib.util
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(ROOT, "sign-language-nlp_amd", "lib", "libslnlp.so")
@@ -260,3 +259,29 @@ def test_no_kernel_of_the_built_library_needs_more_than_256_registers():
     assert len(ks) > 50, "no kernels found in the library's code objects"
     over = [(v, n) for v, a, n in ks if v > 256]
     assert not over, f"kernels above 256 registers: {over}"
+
+
+def test_the_built_library_contains_no_packed_fp32_instructions():
+    """v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 return wrong values in 16-lane pieces
+    of a wave when a workgroup of another kernel shares the CU (MI355X / ROCm 7.2; DESIGN.md section 6: two independent victim
+    kernels, each flipped from nondeterministic to bit-stable by compiling without them).  The Makefile builds with
+    -target-feature -packed-fp32-ops; this disassembles every code object of the built library and holds it to that."""
+    import importlib.util, re, subprocess, tempfile
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "sign-language-nlp_amd", "lib", "libslnlp.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(lib) or not os.path.exists(objdump):
+        pytest.skip("library or llvm-objdump not present")
+    spec = importlib.util.spec_from_file_location("kernel_registers", os.path.join(ROOT, "tools", "kernel_registers.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    lines, hits = 0, []
+    for _, elf in kr.code_objects(open(lib, "rb").read()):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(elf)
+            f.flush()
+            out = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
+        lines += out.count("\n")
+        hits += re.findall(r"v_pk_(?:add|mul|fma)_f32", out)      # (v_pk_mov_b32, a move, stays: the builds that pass the probes have it)
+    assert lines > 100000, "disassembly looks empty"
+    assert not hits, f"{len(hits)} packed fp32 instructions in the built library (first: {hits[0]})"

@@ -1,11 +1,11 @@
 """Fits on several streams (hardware queues) of one GPU get the bits of a fit running alone.
 
 Round 2 measured that they did not (three fits on three streams: backward results changed from run to run) and shipped a
-one-queue rule.  Round 3 isolated the victim -- the LayerNorm-backward kernel that kept (dgamma, dbeta) accumulators live across
-its rows -- and split it (csrc/elementwise.hip); since then every probe is bit-identical with the queues
-overlapping freely.  Both modes are tested: the library's default (slnlp_set_stream_policy(1): step entry points of different
-streams are ordered, for callers of the C API that bring their own streams) and the overlapping mode slnlp.net uses for the host
-threads of a grid search (one stream per thread, policy 0)."""
+one-queue rule.  Round 3 found the cause -- packed fp32 VALU instructions return wrong values when a workgroup of another kernel
+shares the CU -- and builds the library without them; these tests are the canaries that hold every shipped
+kernel to it.  Both modes are tested: the library's default (slnlp_set_stream_policy(1): step entry points of different streams
+are ordered, for callers of the C API that bring their own streams) and the overlapping mode slnlp.net uses for the host threads
+of a grid search (one stream per thread, policy 0)."""
 import threading
 
 import pytest

@@ -13,8 +13,10 @@ import bench
 from slnlp import synth, tf_engine as te, _lib
 dev = torch.device("cuda", 0)
 _lib.load().slnlp_set_stream_policy(0)
-c = dict(E=512, H=8, N=2, F=512, Vs=3000, Vt=202, B=50, S=48, dropout=float(sys.argv[1]) if len(sys.argv) > 1 else 0.1, precision=3)
+c = dict(E=512, H=8, N=int(sys.argv[4]) if len(sys.argv) > 4 else 2, F=512, Vs=3000, Vt=202, B=50, S=48,
+         dropout=float(sys.argv[1]) if len(sys.argv) > 1 else 0.1, precision=3)
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # > 0: that many whole train steps (with the optimizer) instead of one forward + backward
 engs, data, sds = {}, {}, {}
 for s in (1, 2, 3):
     cfg, sd = bench.build_sd(c, seed=s)
@@ -42,7 +44,10 @@ def work(s, out, bar=None):
     e, (X, y) = engs[s], data[s]
     if bar: bar.wait()
     with torch.cuda.stream(streams[s]):
-        e.forward(X, y, train=True); e.backward()
+        if STEPS:
+            for _ in range(STEPS): e.train_step(X, y)
+        else:
+            e.forward(X, y, train=True); e.backward()
         streams[s].synchronize()
     out[s] = (e.workspace[:act_end].clone(), e.grads.clone())
 
