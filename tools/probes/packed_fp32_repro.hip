@@ -1,0 +1,165 @@
+// packed_fp32_repro.hip -- library-free reproducer attempt for DESIGN.md section 6: packed fp32 VALU instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) returning wrong values when a workgroup of ANOTHER kernel shares the CU.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/packed_fp32_repro.hip -o tools/probes/packed_fp32_repro
+//   tools/probes/packed_fp32_repro <aggressor mask> <seconds>
+//
+// victim (stream 0): the instruction sequence of the library kernel in which the wrong bits were pinned down -- three 16-byte
+//   global loads + one LDS read, then v_pk_add_f32 x2, v_pk_mul_f32 x2, v_pk_fma_f32 x2 (inline asm, so the packed forms are
+//   there whatever the compiler would choose) -- and the SAME arithmetic with scalar v_sub / v_mul / v_fma in the same lane;
+//   both are IEEE operations on the same inputs, so their results must be bit-identical.  Every mismatch is counted, with the
+//   lane it happened in.
+// aggressors (streams 1, 2), bit mask:  1 = MFMA loop (v_mfma_f32_16x16x32_bf16)   2 = LDS-DMA ring (global_load_lds into 64 KiB)
+//   4 = streaming global loads / stores   8 = a second packed-fp32 kernel   0 = none
+// Exit code 1 when the victim saw a mismatch.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
+
+#define CK(x)                                                                                          \
+    do {                                                                                               \
+        hipError_t e__ = (x);                                                                          \
+        if (e__ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); exit(2); } \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef __attribute__((address_space(1))) const void* glb_vp;
+
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, float m) {      // a - m, both halves: v_pk_add_f32 with a negated broadcast operand
+    f32x2 r, mm = {m, m};
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(mm));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, float s) {
+    f32x2 r, ss = {s, s};
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(ss));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float s_sub(float a, float m) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(m)); return r; }
+__device__ __forceinline__ float s_mul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// rows x 512 floats; a 512-thread workgroup handles 64 rows x 16 columns like the library kernel's write-out
+__global__ __launch_bounds__(512) void victim(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float* __restrict__ y, int rows, int iters, unsigned* __restrict__ bad, unsigned* __restrict__ bad_lane) {
+    __shared__ float2 st[64];
+    if (threadIdx.x < 64) st[threadIdx.x] = make_float2(0.01f * threadIdx.x, 1.f + 0.001f * threadIdx.x);
+    __syncthreads();
+    const int c0 = blockIdx.x * 16;
+    for (int it = 0; it < iters; ++it) {
+        for (int idx = threadIdx.x; idx < 64 * 4; idx += 512) {
+            const int row = idx >> 2, c = c0 + ((idx & 3) << 2);
+            if (row >= rows) continue;
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (long)row * 512 + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+            const float2 s = st[row];
+            f32x2 lo = {x4.x, x4.y}, hi = {x4.z, x4.w};
+            lo = pk_sub(lo, s.x); hi = pk_sub(hi, s.x);
+            lo = pk_mul(lo, s.y); hi = pk_mul(hi, s.y);
+            lo = pk_fma(f32x2{gm.x, gm.y}, lo, f32x2{bt.x, bt.y});
+            hi = pk_fma(f32x2{gm.z, gm.w}, hi, f32x2{bt.z, bt.w});
+            const float r0 = s_fma(gm.x, s_mul(s_sub(x4.x, s.x), s.y), bt.x), r1 = s_fma(gm.y, s_mul(s_sub(x4.y, s.x), s.y), bt.y);
+            const float r2 = s_fma(gm.z, s_mul(s_sub(x4.z, s.x), s.y), bt.z), r3 = s_fma(gm.w, s_mul(s_sub(x4.w, s.x), s.y), bt.w);
+            const bool ok = __float_as_uint(lo.x) == __float_as_uint(r0) && __float_as_uint(lo.y) == __float_as_uint(r1) &&
+                            __float_as_uint(hi.x) == __float_as_uint(r2) && __float_as_uint(hi.y) == __float_as_uint(r3);
+            if (!ok) { atomicAdd(bad, 1u); atomicAdd(bad_lane + (threadIdx.x & 63), 1u); }
+            *reinterpret_cast<f32x4*>(y + (long)row * 512 + c) = f32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void agg_mfma(float* __restrict__ out, int steps) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    f4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.01f * (threadIdx.x & 15) + i); b[i] = (__bf16)(0.02f * i); }
+    for (int s = 0; s < steps; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == -1.f) out[0] = 1.f;
+}
+__global__ __launch_bounds__(512) void agg_dma(const unsigned short* __restrict__ src, float* __restrict__ out, int steps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc = 0.f;
+    for (int s = 0; s < steps; ++s) {
+        for (int p = 0; p < 4; ++p) {
+            const unsigned short* g = src + ((((long)blockIdx.x * 37 + s) * 16384 + (p * 8 + wave) * 512 + lane * 8) & 0xFFFF8);
+            __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)(smem + (s & 1) * 16384 + (p * 8 + wave) * 512), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        acc += (float)smem[(s & 1) * 16384 + ((tid * 33) & 16383)];
+    }
+    if (acc == -1.f) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void agg_stream(const float4* __restrict__ src, float4* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float4 v = src[i];
+        v.x += 1.f;
+        dst[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void agg_pk(float* __restrict__ out, int steps) {
+    f32x2 a = {0.5f + threadIdx.x, 1.5f}, b = {1.0001f, 0.9999f}, c = {0.f, 0.f};
+    for (int s = 0; s < steps; ++s) c = pk_fma(a, b, c);
+    if (c.x + c.y == -1.f) out[0] = c.x;
+}
+
+int main(int argc, char** argv) {
+    const int mask = argc > 1 ? atoi(argv[1]) : 15;
+    const double seconds = argc > 2 ? atof(argv[2]) : 5.0;
+    hipStream_t sv, s1, s2;
+    CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    const int rows = 50;
+    float *x, *gm, *bt, *y, *sink;
+    float4 *big0, *big1;
+    unsigned short* src;
+    unsigned *bad, *bad_lane;
+    const long nbig = 16L << 20;      // 256 MiB per streaming buffer
+    CK(hipMalloc(&x, 64 * 512 * 4)); CK(hipMalloc(&gm, 512 * 4)); CK(hipMalloc(&bt, 512 * 4)); CK(hipMalloc(&y, 64 * 512 * 4));
+    CK(hipMalloc(&sink, 64)); CK(hipMalloc(&src, 2 << 20)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&bad_lane, 64 * 4));
+    CK(hipMalloc(&big0, nbig * 16)); CK(hipMalloc(&big1, nbig * 16));
+    float* h = (float*)malloc(64 * 512 * 4);
+    for (int i = 0; i < 64 * 512; ++i) h[i] = 0.001f * (float)((i * 2654435761u >> 12) & 0xFFF) - 2.f;
+    CK(hipMemcpy(x, h, 64 * 512 * 4, hipMemcpyHostToDevice));
+    for (int i = 0; i < 512; ++i) h[i] = 1.f + 0.0007f * i;
+    CK(hipMemcpy(gm, h, 512 * 4, hipMemcpyHostToDevice));
+    for (int i = 0; i < 512; ++i) h[i] = 0.1f - 0.0003f * i;
+    CK(hipMemcpy(bt, h, 512 * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(src, 1, 2 << 20)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(bad_lane, 0, 256)); CK(hipMemset(big0, 0, nbig * 16));
+    CK(hipFuncSetAttribute((const void*)agg_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    long launches = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        for (int k = 0; k < 50; ++k) {
+            hipLaunchKernelGGL(victim, dim3(32), dim3(512), 0, sv, x, gm, bt, y, rows, 4, bad, bad_lane);
+            if (mask & 1) hipLaunchKernelGGL(agg_mfma, dim3(512), dim3(512), 0, s1, sink, 400);
+            if (mask & 2) hipLaunchKernelGGL(agg_dma, dim3(496), dim3(512), 65536, s2, src, sink, 24);
+            if (mask & 4) hipLaunchKernelGGL(agg_stream, dim3(2048), dim3(256), 0, s1, big0, big1, nbig / 16);
+            if (mask & 8) hipLaunchKernelGGL(agg_pk, dim3(1024), dim3(256), 0, s2, sink, 2000);
+            ++launches;
+        }
+        CK(hipStreamSynchronize(sv)); CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2));
+    }
+    unsigned b = 0, lanes[64];
+    CK(hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(lanes, bad_lane, 256, hipMemcpyDeviceToHost));
+    printf("aggressors %2d: %ld victim launches (32 workgroups x 4 passes x 200 float4): packed != scalar in %u float4", mask, launches, b);
+    if (b) {
+        printf("; by 16-lane group:");
+        for (int q = 0; q < 4; ++q) { unsigned t = 0; for (int l = 0; l < 16; ++l) t += lanes[q * 16 + l]; printf(" %u", t); }
+    }
+    printf("\n");
+    return b ? 1 : 0;
+}
