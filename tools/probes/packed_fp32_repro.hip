@@ -8,9 +8,10 @@
 //   global loads + one LDS read, then v_pk_add_f32 x2, v_pk_mul_f32 x2, v_pk_fma_f32 x2 (inline asm, so the packed forms are
 //   there whatever the compiler would choose) -- and the SAME arithmetic with scalar v_sub / v_mul / v_fma in the same lane;
 //   both are IEEE operations on the same inputs, so their results must be bit-identical.  Every mismatch is counted, with the
-//   lane it happened in.
+//   lane it happened in (a second kernel on the victim's stream does the scalar recomputation on what reached memory).
 // aggressors (streams 1, 2), bit mask:  1 = MFMA loop (v_mfma_f32_16x16x32_bf16)   2 = LDS-DMA ring (global_load_lds into 64 KiB)
-//   4 = streaming global loads / stores   8 = a second packed-fp32 kernel   0 = none
+//   4 = streaming global loads / stores   8 = a second packed-fp32 kernel   16 = transposing LDS reads (ds_read_b64_tr_b16), the
+//   instruction the library kernels that trigger the effect have in common (tools/probes/probe_aggressor.py)   0 = none
 // Exit code 1 when the victim saw a mismatch.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -48,9 +49,11 @@ __device__ __forceinline__ float s_sub(float a, float m) { float r; asm volatile
 __device__ __forceinline__ float s_mul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// rows x 512 floats; a 512-thread workgroup handles 64 rows x 16 columns like the library kernel's write-out
+// rows x 512 floats; a 512-thread workgroup handles 64 rows x 16 columns like the library kernel's write-out.  The packed results
+// go STRAIGHT into the 16-byte store (as in the library kernel's ISA: v_pk_fma_f32 x2, global_store_dwordx4), nothing in between;
+// a second kernel on the same stream recomputes every element with scalar instructions and compares what is in memory.
 __global__ __launch_bounds__(512) void victim(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                              float* __restrict__ y, int rows, int iters, unsigned* __restrict__ bad, unsigned* __restrict__ bad_lane) {
+                                              float* __restrict__ y, int rows, int iters) {
     __shared__ float2 st[64];
     if (threadIdx.x < 64) st[threadIdx.x] = make_float2(0.01f * threadIdx.x, 1.f + 0.001f * threadIdx.x);
     __syncthreads();
@@ -67,14 +70,27 @@ __global__ __launch_bounds__(512) void victim(const float* __restrict__ x, const
             lo = pk_mul(lo, s.y); hi = pk_mul(hi, s.y);
             lo = pk_fma(f32x2{gm.x, gm.y}, lo, f32x2{bt.x, bt.y});
             hi = pk_fma(f32x2{gm.z, gm.w}, hi, f32x2{bt.z, bt.w});
-            const float r0 = s_fma(gm.x, s_mul(s_sub(x4.x, s.x), s.y), bt.x), r1 = s_fma(gm.y, s_mul(s_sub(x4.y, s.x), s.y), bt.y);
-            const float r2 = s_fma(gm.z, s_mul(s_sub(x4.z, s.x), s.y), bt.z), r3 = s_fma(gm.w, s_mul(s_sub(x4.w, s.x), s.y), bt.w);
-            const bool ok = __float_as_uint(lo.x) == __float_as_uint(r0) && __float_as_uint(lo.y) == __float_as_uint(r1) &&
-                            __float_as_uint(hi.x) == __float_as_uint(r2) && __float_as_uint(hi.y) == __float_as_uint(r3);
-            if (!ok) { atomicAdd(bad, 1u); atomicAdd(bad_lane + (threadIdx.x & 63), 1u); }
-            *reinterpret_cast<f32x4*>(y + (long)row * 512 + c) = f32x4{lo.x, lo.y, hi.x, hi.y};
+            *reinterpret_cast<f32x4*>(y + ((long)it * 64 + row) * 512 + c) = f32x4{lo.x, lo.y, hi.x, hi.y};
         }
     }
+}
+__global__ __launch_bounds__(512) void check(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             const float* __restrict__ y, int rows, int iters, unsigned* __restrict__ bad, unsigned* __restrict__ bad_lane) {
+    const int c0 = blockIdx.x * 16;
+    for (int it = 0; it < iters; ++it)
+        for (int idx = threadIdx.x; idx < 64 * 4; idx += 512) {
+            const int row = idx >> 2, c = c0 + ((idx & 3) << 2);
+            if (row >= rows) continue;
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (long)row * 512 + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+            const float sx = 0.01f * row, sy = 1.f + 0.001f * row;
+            const f32x4 got = *reinterpret_cast<const f32x4*>(y + ((long)it * 64 + row) * 512 + c);
+            const float r0 = s_fma(gm.x, s_mul(s_sub(x4.x, sx), sy), bt.x), r1 = s_fma(gm.y, s_mul(s_sub(x4.y, sx), sy), bt.y);
+            const float r2 = s_fma(gm.z, s_mul(s_sub(x4.z, sx), sy), bt.z), r3 = s_fma(gm.w, s_mul(s_sub(x4.w, sx), sy), bt.w);
+            const bool ok = __float_as_uint(got.x) == __float_as_uint(r0) && __float_as_uint(got.y) == __float_as_uint(r1) &&
+                            __float_as_uint(got.z) == __float_as_uint(r2) && __float_as_uint(got.w) == __float_as_uint(r3);
+            if (!ok) { atomicAdd(bad, 1u); atomicAdd(bad_lane + (threadIdx.x & 63), 1u); }
+        }
 }
 
 __global__ __launch_bounds__(512) void agg_mfma(float* __restrict__ out, int steps) {
@@ -109,6 +125,23 @@ __global__ __launch_bounds__(256) void agg_stream(const float4* __restrict__ src
         dst[i] = v;
     }
 }
+__global__ __launch_bounds__(512) void agg_tr(float* __restrict__ out, int steps) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    __shared__ __attribute__((aligned(16))) unsigned short img[64 * 72];       // a [k][row] bf16 image like the library's m-major tiles
+    for (int i = threadIdx.x; i < 64 * 72; i += 512) img[i] = (unsigned short)(0x3f80 + (i & 63));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    int acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        const int kb = ((s & 1) * 32) + ((lane >> 4) << 3) + (i >> 2);
+        const unsigned short* p0 = img + kb * 72 + ((s >> 1) & 3) * 16 + ((i & 3) << 2);
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + 4 * 72));
+        acc += v0[0] + v0[3] + v1[1] + v1[2];
+    }
+    if (acc == -1) out[0] = 1.f;
+}
 __global__ __launch_bounds__(256) void agg_pk(float* __restrict__ out, int steps) {
     f32x2 a = {0.5f + threadIdx.x, 1.5f}, b = {1.0001f, 0.9999f}, c = {0.f, 0.f};
     for (int s = 0; s < steps; ++s) c = pk_fma(a, b, c);
@@ -128,7 +161,7 @@ int main(int argc, char** argv) {
     unsigned short* src;
     unsigned *bad, *bad_lane;
     const long nbig = 16L << 20;      // 256 MiB per streaming buffer
-    CK(hipMalloc(&x, 64 * 512 * 4)); CK(hipMalloc(&gm, 512 * 4)); CK(hipMalloc(&bt, 512 * 4)); CK(hipMalloc(&y, 64 * 512 * 4));
+    CK(hipMalloc(&x, 64 * 512 * 4)); CK(hipMalloc(&gm, 512 * 4)); CK(hipMalloc(&bt, 512 * 4)); CK(hipMalloc(&y, 4 * 64 * 512 * 4));
     CK(hipMalloc(&sink, 64)); CK(hipMalloc(&src, 2 << 20)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&bad_lane, 64 * 4));
     CK(hipMalloc(&big0, nbig * 16)); CK(hipMalloc(&big1, nbig * 16));
     float* h = (float*)malloc(64 * 512 * 4);
@@ -144,11 +177,14 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         for (int k = 0; k < 50; ++k) {
-            hipLaunchKernelGGL(victim, dim3(32), dim3(512), 0, sv, x, gm, bt, y, rows, 4, bad, bad_lane);
+            CK(hipMemsetAsync(y, 0xff, 4 * 64 * 512 * 4, sv));
+            hipLaunchKernelGGL(victim, dim3(32), dim3(512), 0, sv, x, gm, bt, y, rows, 4);
+            hipLaunchKernelGGL(check, dim3(32), dim3(512), 0, sv, x, gm, bt, y, rows, 4, bad, bad_lane);
             if (mask & 1) hipLaunchKernelGGL(agg_mfma, dim3(512), dim3(512), 0, s1, sink, 400);
             if (mask & 2) hipLaunchKernelGGL(agg_dma, dim3(496), dim3(512), 65536, s2, src, sink, 24);
             if (mask & 4) hipLaunchKernelGGL(agg_stream, dim3(2048), dim3(256), 0, s1, big0, big1, nbig / 16);
             if (mask & 8) hipLaunchKernelGGL(agg_pk, dim3(1024), dim3(256), 0, s2, sink, 2000);
+            if (mask & 16) hipLaunchKernelGGL(agg_tr, dim3(512), dim3(512), 0, s1, sink, 2000);
             ++launches;
         }
         CK(hipStreamSynchronize(sv)); CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2));
