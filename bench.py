@@ -116,9 +116,9 @@ def dominant_kernel_roofline(c, precision, dev, workload):
     tf = flops / (us * 1e-6) / 1e12
     blocks = tw * split + td
     # the launch geometry the library picks for this group (csrc/gemm_planes.hip plane_geo_auto): 64 x 64 tiles under 200 tiles of
-    # 128 x 128, else 128 x 128 on the 32-k ring (two workgroups per CU) from 512 tiles or K loops >= 1024, else on the 64-k ring
+    # 128 x 128, else 128 x 128 on the 32-k ring (two workgroups per CU) from 300 tiles or K loops >= 1024, else on the 64-k ring
     u128 = cd(E, 128) * cd(F, 128) * split + cd(M, 128) * cd(F, 128)
-    geo, wgs = ("64x64", blocks) if u128 < 200 else ("128x128 32-k ring" if (min(M // split, E) >= 1024 or u128 >= 512) else "128x128 64-k ring", u128)
+    geo, wgs = ("64x64", blocks) if u128 < 200 else ("128x128 32-k ring" if (min(M // split, E) >= 1024 or u128 >= 300) else "128x128 64-k ring", u128)
     return {"kernel": f"gemm_planes_kernel<{precision}, {geo}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {wgs} workgroups",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}, 0> x{blocks}"),

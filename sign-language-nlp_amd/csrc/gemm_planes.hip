@@ -784,12 +784,12 @@ constexpr int BIG_TILE_MIN_UNITS = 200;    // a launch takes 128 x 128 tiles whe
 // Which ring (per-workgroup timelines, tools/probes/probe_tile_timeline.py: a 128 x 128 x 64 workgroup spends 1.6 us filling the
 // ring, 11 us in the K loop of K = 512 and 6 us in its epilogue -- with one workgroup per CU nothing covers the first and the last):
 //   * 32-k x 2 stages (64 KiB, two workgroups per CU, each the other's cover) once every K loop is at least 1024 long
-//     (configs[4] gradient groups: +10 %), and from two workgroups per CU up whatever K: forward launches (15 merged fits
+//     (configs[4] gradient groups: +10 %), and from about 300 tiles up whatever K: forward launches (15 merged fits
 //     [36000 x 512] x [512 x 512] 88 -> 74 us, configs[4] in_proj 342 -> 293 us) and the merged gradient groups of a lockstep
 //     unit (a 15-fit cfg2 step 20.2 -> 19.5 ms with every launch on this ring; 21.3 on the 64-k ring, 21.8 on 64 x 64 tiles);
 //   * 64-k x 2 stages (128 KiB, one workgroup per CU) for launches of about one tile per CU (cfg2 in_proj, 228 tiles: 20.6 against
 //     21.3 us; at K = 512 the 32-k ring pays twice the barriers and has no second workgroup to hide them behind).
-constexpr int TWO_PER_CU_UNITS = 512;
+constexpr int TWO_PER_CU_UNITS = 300;    // (a 4-fit lockstep step, 496- and 320-tile launches: 6.83 -> 6.36 ms on the 32-k ring; 2 fits, 248 tiles: equal)
 int plane_geo_auto(long units128, int min_k, bool fp8) {
     if (fp8) return 0;                                       // (fp8 launches have their own geometries: q8_geo_auto)
     const int forced = g_plane_geo.load(std::memory_order_relaxed);
