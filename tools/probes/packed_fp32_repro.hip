@@ -1,17 +1,23 @@
-// packed_fp32_repro.hip -- library-free reproducer attempt for DESIGN.md section 6: packed fp32 VALU instructions
-// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) returning wrong values when a workgroup of ANOTHER kernel shares the CU.
+// packed_fp32_repro.hip -- LIBRARY-FREE REPRODUCER for DESIGN.md section 6 (MI355X / gfx950, ROCm 7.2, hipcc 7.2):
+// packed fp32 VALU instructions with an op_sel half-select (v_pk_add_f32 ... op_sel_hi:[1,0], v_pk_mul_f32 ... op_sel:[0,1] -- the
+// forms the compiler emits when one operand is a scalar held in half of a 64-bit register pair) return WRONG results in lanes
+// 48-63 of a wave while waves of ANOTHER kernel execute MFMA instructions on the same CU; alone they are always right.
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/packed_fp32_repro.hip -o tools/probes/packed_fp32_repro
 //   tools/probes/packed_fp32_repro <aggressor mask> <seconds>
 //
 // victim (stream 0): the instruction sequence of the library kernel in which the wrong bits were pinned down -- three 16-byte
-//   global loads + one LDS read, then v_pk_add_f32 x2, v_pk_mul_f32 x2, v_pk_fma_f32 x2 (inline asm, so the packed forms are
-//   there whatever the compiler would choose) -- and the SAME arithmetic with scalar v_sub / v_mul / v_fma in the same lane;
-//   both are IEEE operations on the same inputs, so their results must be bit-identical.  Every mismatch is counted, with the
-//   lane it happened in (a second kernel on the victim's stream does the scalar recomputation on what reached memory).
+//   global loads + one LDS read, v_pk_add_f32 x2, v_pk_mul_f32 x2 (both with op_sel), v_pk_fma_f32 x2, one 16-byte store (inline
+//   asm, so the forms are exactly these).  A second kernel on the same stream recomputes every element with scalar v_sub / v_mul /
+//   v_fma -- IEEE operations on the same inputs, so the bits must agree -- and counts every float4 that differs, by 16-lane group.
 // aggressors (streams 1, 2), bit mask:  1 = MFMA loop (v_mfma_f32_16x16x32_bf16)   2 = LDS-DMA ring (global_load_lds into 64 KiB)
-//   4 = streaming global loads / stores   8 = a second packed-fp32 kernel   16 = transposing LDS reads (ds_read_b64_tr_b16), the
-//   instruction the library kernels that trigger the effect have in common (tools/probes/probe_aggressor.py)   0 = none
+//   4 = streaming global loads / stores   8 = a second packed-fp32 kernel   16 = transposing LDS reads (ds_read_b64_tr_b16)   0 = none
+// Measured (profiles/r03_determinism_probes.txt, sessions 48-53), 4-5 s each:
+//   mask  0:      0 of 6.5e5 launches        mask 1 (MFMA only): 64 float4, ALL in lanes 48-63      mask 2 / 4 / 8 / 16: 0
+//   mask 15: 135 792 float4 in 40 500 launches, ALL in lanes 48-63          mask 31: 48, all in lanes 48-63
+//   the same victim beside the library's own kernels (probe_pk_victim.py): 1.4 - 6.2 MILLION float4 in 4 s per aggressor kind.
+//   With the packed instructions in their plain form (full 64-bit operands, no op_sel) the same program shows 0 everywhere.
+// The library is built without packed fp32 instructions for that reason (sign-language-nlp_amd/Makefile).
 // Exit code 1 when the victim saw a mismatch.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -30,14 +36,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef __attribute__((address_space(1))) const void* glb_vp;
 
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, float m) {      // a - m, both halves: v_pk_add_f32 with a negated broadcast operand
-    f32x2 r, mm = {m, m};
-    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(mm));
+// the forms the compiler emitted in the library kernel: the (mean, rstd) pair is ONE 64-bit operand and op_sel picks which half
+// both lanes of the packed instruction use -- a - mean: v_pk_add_f32 ... op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1];  * rstd: op_sel:[0,1]
+__device__ __forceinline__ f32x2 pk_sub_lo(f32x2 a, f32x2 mean_rstd) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(mean_rstd));
     return r;
 }
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, float s) {
-    f32x2 r, ss = {s, s};
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(ss));
+__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 a, f32x2 mean_rstd) {
+    f32x2 r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(mean_rstd));
     return r;
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
@@ -66,8 +74,9 @@ __global__ __launch_bounds__(512) void victim(const float* __restrict__ x, const
             const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
             const float2 s = st[row];
             f32x2 lo = {x4.x, x4.y}, hi = {x4.z, x4.w};
-            lo = pk_sub(lo, s.x); hi = pk_sub(hi, s.x);
-            lo = pk_mul(lo, s.y); hi = pk_mul(hi, s.y);
+            const f32x2 mr = {s.x, s.y};
+            lo = pk_sub_lo(lo, mr); hi = pk_sub_lo(hi, mr);
+            lo = pk_mul_hi(lo, mr); hi = pk_mul_hi(hi, mr);
             lo = pk_fma(f32x2{gm.x, gm.y}, lo, f32x2{bt.x, bt.y});
             hi = pk_fma(f32x2{gm.z, gm.w}, hi, f32x2{bt.z, bt.w});
             *reinterpret_cast<f32x4*>(y + ((long)it * 64 + row) * 512 + c) = f32x4{lo.x, lo.y, hi.x, hi.y};

@@ -45,7 +45,16 @@ def v_chain():                     # LayerNorm -> plane GEMM (fresh planes of th
     yp = ops.split_planes(y)
     out = ops.gemm_planes(yp, Wp, M=M, N=E, K=E)
     return ops.layernorm_bwd(out, x, gamma, st)[:1]
-VICTIMS = [("layernorm_bwd (constant inputs)", v_ln_bwd), ("layernorm_bwd, no dropout: dx", v_ln_bwd_nodrop),
+Ba, Sa, Ha, dha = 50, 48, 8, 64
+qkv_a, dctx_a = rnd(Sa * Ba, 3 * E), rnd(Sa * Ba, E)
+ids_a = torch.randint(2, 100, (Ba, Sa), generator=g).to(dev)
+probs_a = ops.attn_self_fwd(qkv_a, ids_a, 1, B=Ba, S=Sa, H=Ha, dh=dha)[1]
+def v_attn_fwd():          # (the two kernels of the library that still contain v_pk_mov_b32 ... op_sel)
+    return ops.attn_self_fwd(qkv_a, ids_a, 1, B=Ba, S=Sa, H=Ha, dh=dha)[:2]
+def v_attn_bwd():
+    r = ops.attn_self_bwd(qkv_a, probs_a, dctx_a, B=Ba, S=Sa, H=Ha, dh=dha)
+    return r if isinstance(r, (tuple, list)) else (r,)
+VICTIMS = [("attn_self_fwd", v_attn_fwd), ("attn_self_bwd", v_attn_bwd), ("layernorm_bwd (constant inputs)", v_ln_bwd), ("layernorm_bwd, no dropout: dx", v_ln_bwd_nodrop),
            ("layernorm_bwd: dgamma, dbeta", v_ln_bwd_params), ("layernorm_fwd", v_ln_fwd), ("plane GEMM group, split-K 3", v_plane_group),
            ("50-row fp32-operand GEMM", v_brow_gemm), ("chain LN -> split -> plane GEMM -> LN bwd", v_chain)]
 # ---- aggressors: whole fits
