@@ -204,6 +204,71 @@ __device__ __forceinline__ void embed_bwd_combine_body(const int* __restrict__ p
 }
 SLNLP_ZKERNEL(embed_bwd_combine_kernel, 256, embed_bwd_combine_body)
 
+// The whole scatter-add in ONE launch when the batch has at most EMB_CHUNK tokens (the target side: one token per sequence):
+// grid max(M, V).  Workgroup i < V zero-fills table row i if no token carries id i; workgroup m < M, if token m is the first of
+// its id, sums that id's rows with the same fixed tree as embed_bwd_chunk (wave w adds chunk positions [16w, 16w + 16) in order,
+// then the wave sums in wave order) and writes sum * scale -- the bits of chunk + combine with a single chunk, without the
+// fill_zero and combine launches.
+__device__ __forceinline__ void embed_bwd_small_body(const long* __restrict__ ids, long ld_ids, int B, int S, int E, int V,
+                                                     const float* __restrict__ dx, float* __restrict__ dtable, float scale,
+                                                     float drop_p, unsigned drop_thr, int drop_site,
+                                                     const unsigned long long* __restrict__ rng) {
+    const int M = B * S, lane = threadIdx.x & 63, m = blockIdx.x;
+    int my_id = -1;                        // lane l holds the id of token l (or -1)
+    if (lane < M) {
+        const long v = ids[(long)(lane % B) * ld_ids + (lane / B)];
+        my_id = (v < 0 || v >= V) ? -1 : (int)v;
+    }
+    if (m < V && __ballot(my_id == m) == 0ull) {          // nobody carries id m: the row's gradient is zero
+        for (int c = threadIdx.x * 4; c < E; c += 1024) *reinterpret_cast<float4*>(dtable + (long)m * E + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (m >= M) return;
+    const float ik = 1.f / (1.f - drop_p);
+    const int id = __builtin_amdgcn_readlane(my_id, __builtin_amdgcn_readfirstlane(m));   // m is block-uniform
+    const unsigned long long mask = __ballot(my_id == id && id >= 0);
+    const bool first = id >= 0 && (mask & ((1ull << m) - 1ull)) == 0ull;
+    if (!first) return;
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long wmask = mask & (0xFFFFull << (16 * wave));
+    for (int c0 = 0; c0 < E; c0 += 256) {
+        const int c = c0 + lane * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < E) {
+            unsigned long long bits = wmask;
+            while (bits) {
+                int k[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    k[u] = bits ? __ffsll((long long)bits) - 1 : -1;
+                    bits &= bits - 1;
+                }
+                float4 g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    g[u] = k[u] >= 0 ? load_dx_row(dx, k[u], E, c, drop_p, ik, drop_thr, drop_site, rng, nullptr)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+            }
+        }
+        if (c0 > 0) __syncthreads();
+        *reinterpret_cast<float4*>(&red[wave][lane * 4]) = acc;
+        __syncthreads();
+        if (wave == 0 && c < E) {
+            float4 r = *reinterpret_cast<const float4*>(&red[0][lane * 4]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 q = *reinterpret_cast<const float4*>(&red[w][lane * 4]);
+                r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+            }
+            r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+            *reinterpret_cast<float4*>(dtable + (long)id * E + c) = r;
+        }
+    }
+}
+SLNLP_ZKERNEL(embed_bwd_small_kernel, 256, embed_bwd_small_body)
+
 int embed_fwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, const float* table, const float* pe,
               float* out, float scale, float drop_p, int drop_site, const unsigned long long* rng, int64_t nan_idx,
               hipStream_t st, PlaneOut po, unsigned char* keep_mask) {
@@ -229,8 +294,14 @@ int embed_bwd(const int64_t* ids, int64_t ld_ids, int B, int S, int E, int V, co
     SLNLP_CHECK_ARG(B > 0 && S > 0 && V > 0 && E > 0 && E % 4 == 0, "embed_bwd: bad shape");
     SLNLP_CHECK_ARG((long)B * S <= 65536, "embed_bwd: more than 65536 tokens per batch");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "embed_bwd: bad dropout args");
-    SLNLP_TRY(fill_zero(dtable, (size_t)V * E * sizeof(float), st));    // rows of ids that do not occur (our kernel: recordable)
     const int M = B * S;
+    if (M <= EMB_CHUNK && !keep_mask) {      // one chunk: zero-fill, sum and scale in one launch
+        SLNLP_TRY(zlaunch(embed_bwd_small_kernel, dim3(M > V ? M : V), 256, 0, st, "embed_bwd_small",
+                          (const long*)ids, (long)ld_ids, B, S, E, V, dx, dtable, scale, drop_p, dropout_threshold(drop_p), drop_site, rng));
+        if (zero_row >= 0 && zero_row < V) SLNLP_TRY(fill_zero(dtable + zero_row * E, (size_t)E * sizeof(float), st));
+        return 0;
+    }
+    SLNLP_TRY(fill_zero(dtable, (size_t)V * E * sizeof(float), st));    // rows of ids that do not occur (our kernel: recordable)
     float* partial = (float*)scratch;
     int* pid = (int*)(partial + (size_t)M * E);
     SLNLP_TRY(zlaunch(embed_bwd_chunk_kernel, dim3(M), 256, 0, st, "embed_bwd_chunk",

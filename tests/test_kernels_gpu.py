@@ -223,6 +223,34 @@ def test_embed(ops):
     assert torch.isnan(t0[1]).all() and not torch.isnan(t0[[0, 2]]).any()
 
 
+@pytest.mark.parametrize("B,S,V,E,hi", [(50, 1, 202, 512, 30), (64, 1, 40, 128, 40), (7, 3, 300, 64, 5), (1, 1, 9, 256, 9), (33, 1, 20, 1024, 3)])
+def test_embed_bwd_single_launch_for_small_batches(ops, B, S, V, E, hi):
+    """At most 64 tokens (the target side: one token per sequence) take the one-launch scatter-add: against autograd in fp64,
+    rows nobody indexes exactly zero (over a NaN-filled table), duplicates summed, the zero_row cleared, the dropout path equal
+    to the masked reference, run-to-run identical."""
+    g = torch.Generator().manual_seed(B + V)
+    ids = torch.randint(0, hi, (B, S), generator=g)
+    table = rnd(V, E, seed=1).double().requires_grad_(True)
+    dx = rnd(S * B, E, seed=3)
+    (table[ids.T] * math.sqrt(E)).reshape(S * B, E).backward(dx.double())
+    dt = ops.embed_bwd(ids.cuda(), dx.cuda(), B=B, S=S, V=V)
+    assert rel(dt, table.grad) < 1e-5
+    unused = torch.ones(V, dtype=torch.bool)
+    unused[ids.flatten()] = False
+    assert float(dt.cpu()[unused].abs().max() if unused.any() else 0.0) == 0.0
+    assert torch.equal(dt, ops.embed_bwd(ids.cuda(), dx.cuda(), B=B, S=S, V=V))
+    z = int(ids[0, 0])
+    dz = ops.embed_bwd(ids.cuda(), dx.cuda(), B=B, S=S, V=V, zero_row=z)
+    assert float(dz[z].abs().max()) == 0.0
+    rng = ops.make_rng(seed=4, step=0)
+    p = 0.2
+    mask = ops.dropout_mask(S * B, E, p, 7, rng).cpu().double()
+    table.grad = None
+    (table[ids.T] * math.sqrt(E)).reshape(S * B, E).backward(dx.double() * mask / (1 - p))
+    dd = ops.embed_bwd(ids.cuda(), dx.cuda(), B=B, S=S, V=V, drop_p=p, drop_site=7, rng=rng)
+    assert rel(dd, table.grad) < 1e-5
+
+
 def test_lsm_nll(ops):
     from oracle import train_ref
     B, V = 50, 202
