@@ -169,7 +169,7 @@ def test_graph_replay_equals_eager():
 @pytest.mark.parametrize("name,reps", [("cfg1", 2), ("cfg2", 8)])
 def test_train_is_deterministic(name, reps):
     """Identical fresh engines, identical steps -> bit-identical weights, every time.  (cfg2 x 8: in round 1 the backward
-    forked work to side streams and 7 of 16 such steps differed at cfg2 -- tf_plan.hpp, side_mode.)"""
+    forked work to side streams and 7 of 16 such steps differed at cfg2; the forks were deleted in round 3)"""
     g, c, sd, X, L, y = gold.tf_case(name)
     outs = []
     st = torch.cuda.Stream()
