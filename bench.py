@@ -159,7 +159,8 @@ def large_launch_roofline(precision, dev):
     tf = flops / (us * 1e-6) / 1e12
     return {"kernel": f"gemm_planes_kernel<{precision}, 128x128> dgrad+wgrad group [{M}x{Nout}]x[{Nout}x{Kin}], wgrad split-K {split} (configs[4] in_proj)",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
-            "traffic": None, "us_per_launch_hip_events": round(us, 1), "flops_per_launch": flops,
+            "traffic": pmc_large_launch_traffic(), "us_per_launch_hip_events": round(us, 1), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * (M * Nout + M * Kin + Nout * Kin) + 4.0 * (M * Kin + Nout * Kin) + 4.0 * M * Kin,
             "mfma_pipe_frac": round(3 * tf / BF16_DENSE_PEAK_TFLOPS, 3),
             "note": "algorithmic FLOPs (the 3 split-bf16 MFMA passes are not counted: the MFMA pipe itself is busy 3x this fraction)"}
 
@@ -324,6 +325,14 @@ def pmc_kernel_traffic(workload, shape):
     try:
         e = json.load(open(f))["per_launch"][shape]
         return float(e["fetch_bytes"] + e["write_bytes"])
+    except Exception:
+        return None
+
+
+def pmc_large_launch_traffic():
+    """HBM bytes of one launch of the configs[4] in_proj gradient group from the committed PMC passes, or None."""
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_large_launch_traffic.json")))["hbm_bytes"])
     except Exception:
         return None
 
