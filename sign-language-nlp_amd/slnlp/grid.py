@@ -187,8 +187,10 @@ class WorkCounter:
     * the first ``world`` units -- the longest: the list is sorted longest first -- are dealt one per rank (unit r to rank r);
     * after that a rank with nothing in flight always gets the next unit from the shared counter (``store.add`` on the process
       group's rendezvous store; a locked integer inside one process);
-    * a rank that already runs k units gets another one only while more than ``world * k`` units are left (every other rank
-      can still be given as many) AND the unit would keep the rank's estimated load -- the sum of ``unit_costs`` of what it
+    * a rank that already runs k units gets another one only while more than ``world * (k - 1)`` units are left (for every unit
+      it runs beyond its first, every rank can still be given one: with 32 units on 8 ranks three run side by side per GPU,
+      the fourth host thread joins as units finish -- round 3 started with ``world * k``, which kept it at two: measured on one
+      GPU, two units side by side do 23.2 k folds/hr, three 26.7 k, four 27.4 k) AND the unit would keep the rank's estimated load -- the sum of ``unit_costs`` of what it
       has taken -- within its fair share ``sum(unit_costs) / world``: prefetching for the host threads never takes what the
       longest-first deal would give to a less loaded rank.  Otherwise its extra threads wait; they leave when the list is
       exhausted.
@@ -280,7 +282,7 @@ class WorkCounter:
             left = self.n_units - nxt
             if left <= 0:
                 return None
-            if left > self.world * k and self._load + self._costs[nxt] <= self._fair * (1 + 1e-9):
+            if left > self.world * (k - 1) and self._load + self._costs[nxt] <= self._fair * (1 + 1e-9):
                 with self._lock:
                     if self._in_flight != k:
                         continue                    # another thread of this rank moved meanwhile: look again

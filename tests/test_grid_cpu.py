@@ -211,7 +211,8 @@ def test_work_counter_admission_single_process():
 def test_admission_prefetch_stays_within_the_fair_share_of_estimated_work(monkeypatch):
     """8 ranks, 32 units of estimated cost 2 / 1 / .15 / .08 (8 each, longest first -- the shape of bench.py's grid sample):
     a rank's extra host threads may take ONE medium unit next to the dealt long one (3.0 <= the fair share 3.23) but not a
-    second one, whatever the number of units still left."""
+    second one, whatever the number of units still left; then one light unit each (more than 8 x (2 - 1) left), and nothing more
+    while three are in flight (8 left, not more than 8 x 2)."""
     class Store(dict):
         def add(self, k, v):
             self[k] = self.get(k, 0) + v
@@ -228,9 +229,10 @@ def test_admission_prefetch_stays_within_the_fair_share_of_estimated_work(monkey
     assert counters[0].try_acquire() == 8                                       # prefetch: 2 + 1 <= 25.84 / 8
     assert counters[0].try_acquire() is grid.WorkCounter.WAIT                   # a third unit would exceed the share
     assert [c.try_acquire() for c in counters[1:]] == list(range(9, 16))
-    assert all(c.try_acquire() is grid.WorkCounter.WAIT for c in counters)      # 16 left, but not > 8 x 2 in flight
-    counters[3].release(); counters[3].release()                                # rank 3 falls idle: it always pulls
-    assert counters[3].try_acquire() == 16
+    assert [c.try_acquire() for c in counters] == list(range(16, 24))           # 16 ... 9 left > 8 x (2 - 1), 3.15 <= 3.23
+    assert all(c.try_acquire() is grid.WorkCounter.WAIT for c in counters)      # 8 left, not > 8 x (3 - 1)
+    counters[3].release(); counters[3].release(); counters[3].release()         # rank 3 falls idle: it always pulls
+    assert counters[3].try_acquire() == 24
 
 
 def test_bench_grid_sample_has_four_units_per_gpu_at_eight_gpus():
