@@ -240,10 +240,11 @@ def concurrent_fits(c, precision, dev, ks=(4, 8, 16), steps=30):
 
 # THE folds/hr sample (fixed from round 3 on; rounds 1-2 quoted smaller ones): 96 of config-transformer.yaml's 324 candidates --
 # every lr and dropout, two embedding sizes, two hidden sizes, both head counts, two depths -> 16 shapes x 30 (candidate, fold)
-# fits = 480 fits of 6 epochs over 4000 samples.  With lockstep 15 (the 3 learning rates x 5 folds of a (shape, dropout) pair
-# advance together) that is 32 work units in four cost classes (E512 N4 / E512 N2 / E128 N4 / E128 N2, 8 each): at N = 8 the
-# longest-first deal gives every GPU one unit of the first class, the host threads prefetch one of the second, and the 16 small
-# ones are pulled as GPUs fall idle (slnlp/grid.py WorkCounter) -- the strong-scaling leg stays balanced at 1 / 2 / 4 / 8 GPUs.
+# fits = 480 fits of 6 epochs over 4000 samples.  The 3 learning rates x 5 folds of a (shape, dropout) pair can advance in
+# lockstep: 32 groups of 15 in four cost classes (E512 N4 / E512 N2 / E128 N4 / E128 N2, 8 each).  ShardedGridSearchCV cuts the
+# groups into work units so that every host thread of every GPU has about six (slnlp/grid.py unit_cost_ceiling: 36 units on one
+# GPU, 124 of 3-5 fits on eight) and hands them out longest first -- the strong-scaling leg keeps every GPU's four host threads
+# busy to the end at 1 / 2 / 4 / 8 GPUs (tests/test_grid_cpu.py simulates that schedule with measured unit times: 0.97 at 8).
 GRID_SAMPLE = {"lr": [0.1, 0.01, 0.001], "module__dropout": [0.5, 0.1], "module__embedding_size": [512, 128],
                "module__hidden_size": [512, 256], "module__num_heads": [8, 4], "module__num_layers": [4, 2]}
 GRID_CV, GRID_EPOCHS, GRID_SAMPLES = 5, 6, 4000

@@ -410,6 +410,16 @@ int slnlp_tf_set_destroy_sync(slnlp_tf_plan* plan, int on);
  * one process.  serialise = 0 switches this off (experiments / probes only); two processes on one GPU stay unsupported. */
 int slnlp_set_stream_policy(int serialise);
 
+/* Split-bf16 passes of the gradient products that run on the plane GEMM (the [S*B]-row dgrad / wgrad of every encoder-side
+ * Linear; what autograd computes for nn.Linear behind /root/reference/model/transformer.py:40-45,82-87), process-wide,
+ * read when a plan issues or records its launches.  3: the full split, A_lo B_hi + A_hi B_lo + A_hi B_hi (fp32-grade
+ * products).  2: dY enters with its bf16 head only, A_hi (B_hi + B_lo) -- a third less MFMA work; the rounding of dY
+ * (2^-9 relative, fresh every step) enters the gradient, not the forward values.  Default: wgrad 2, dgrad 3 (the weight
+ * gradient's error reaches the weights scaled by lr; held to the reference's golden trajectories in tests/).  The forward
+ * products always take 3 passes at precision 3.  Env: SLNLP_WGRAD_PASSES / SLNLP_DGRAD_PASSES. */
+int slnlp_set_backward_passes(int wgrad, int dgrad);
+int slnlp_get_backward_passes(int* wgrad, int* dgrad);
+
 /* ---------------------------------------------------------------- lockstep --
  * K Transformer fits of ONE shape (own weights, lr, dropout rate, seed and data) advancing through one launch
  * sequence: every call site of the step is launched once for all K fits, so a 50-row decoder stage becomes a

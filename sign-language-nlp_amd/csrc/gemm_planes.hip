@@ -41,15 +41,18 @@ __device__ __forceinline__ int img_off(int row, int k) {
 }
 
 // One wave copies 8 image lines (1 KiB) of one plane: lane -> (line 8*wave + lane/8, physical slot lane%8),
-// source = the logical slot that the swizzle maps there.
+// source = the logical slot that the swizzle maps there.  The source address is  plane + K-STEP TERM (uniform: k0 elements for a
+// k-major plane, k0 * ld for an m-major one) + LANE TERM (loop-invariant, below): the K loop then advances scalar registers only
+// and the DMA takes its address as {SGPR base, 32-bit VGPR offset} -- no 64-bit vector arithmetic per piece and step.
 template <bool KMAJOR>
-__device__ __forceinline__ void dma_plane(const unsigned short* __restrict__ plane, long ld, int row0, int k0,
-                                          unsigned short* img, int wave, int lane) {
+__device__ __forceinline__ unsigned plane_lane_off(long ld, int row0, int wave, int lane) {       // bytes
     const int line = 8 * wave + (lane >> 3), ps = lane & 7;
-    const unsigned short* src;
-    if (KMAJOR) src = plane + (long)(row0 + line) * ld + k0 + ((ps ^ (line & 7)) << 3);
-    else src = plane + (long)(k0 + line) * ld + row0 + ((ps ^ mswz(line)) << 3);
-    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(img + wave * 512), 16, 0, 0);
+    const long e = KMAJOR ? (long)(row0 + line) * ld + ((ps ^ (line & 7)) << 3) : (long)line * ld + row0 + ((ps ^ mswz(line)) << 3);
+    return (unsigned)(e * 2);
+}
+__device__ __forceinline__ void dma_piece(const unsigned short* __restrict__ plane, long kterm, unsigned lane_off, unsigned short* dst) {
+    const char* src = reinterpret_cast<const char*>(plane + kterm) + lane_off;
+    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)dst, 16, 0, 0);
 }
 
 template <bool KMAJOR>
@@ -82,18 +85,17 @@ __device__ __forceinline__ int img32_off(int row, int k) {
     return img_off<false>(row, k);
 }
 template <bool KMAJOR>
-__device__ __forceinline__ void dma_slab32(const unsigned short* __restrict__ plane, long ld, int row0, int row_last, int k0,
-                                           unsigned short* slab, int wave, int lane) {
+__device__ __forceinline__ unsigned slab32_lane_off(long ld, int row0, int row_last, int wave, int lane) {   // bytes
     const int h = wave >> 2, line = 8 * (wave & 3) + (lane >> 3), ps = lane & 7;
     const int r_img = min(row0 + PT * h, row_last);       // (planes are padded to 64 rows: never read past the last padded block)
-    const unsigned short* src;
+    long e;
     if (KMAJOR) {
         const int sl = ps ^ (line & 7);
-        src = plane + (long)(r_img + 2 * line + (sl >> 2)) * ld + k0 + ((sl & 3) << 3);
+        e = (long)(r_img + 2 * line + (sl >> 2)) * ld + ((sl & 3) << 3);
     } else {
-        src = plane + (long)(k0 + line) * ld + r_img + ((ps ^ mswz(line)) << 3);
+        e = (long)line * ld + r_img + ((ps ^ mswz(line)) << 3);
     }
-    __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(slab + wave * 512), 16, 0, 0);
+    return (unsigned)(e * 2);
 }
 template <bool KMAJOR>
 __device__ __forceinline__ bf16x8 pfrag32(const unsigned short* __restrict__ img, int r0, int lane) {
@@ -116,9 +118,11 @@ __device__ __forceinline__ float2 ld_agent2(const float* p) {
 #if SLNLP_PROBE_FENCES == 128
 // timeline probe build (tools/probes/probe_tile_timeline.py): every workgroup records 100 MHz timestamps of its phases
 constexpr int TS_MAX = 1 << 16;
-__device__ unsigned long long g_ts[TS_MAX][6];
+constexpr int TS_W = 8;                // words per record: 5 stamps (100 MHz), {XCC id, block}, shader-clock stamps at marks 1 and 2
+__device__ unsigned long long g_ts[TS_MAX][TS_W];
 __device__ unsigned g_ts_n;
-#define TS_MARK(slot) do { if (threadIdx.x == 0) ts[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TS_MARK(slot) do { if (threadIdx.x == 0) { ts[slot] = __builtin_amdgcn_s_memrealtime(); \
+        if (slot == 1) ts[6] = __builtin_amdgcn_s_memtime(); if (slot == 2) ts[7] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define TS_MARK(slot) do { } while (0)
 #endif
@@ -139,7 +143,7 @@ __device__ unsigned g_ts_n;
 template <int NSPLIT, bool AK, bool BK, int BM, int BN, int BKS, int NST>
 __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
 #if SLNLP_PROBE_FENCES == 128
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ts[TS_W] = {0, 0, 0, 0, 0, 0, 0, 0};
     struct TsFlush {
         unsigned long long* t;
         __device__ ~TsFlush() {
@@ -148,19 +152,20 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 unsigned hw;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
                 t[5] = ((unsigned long long)hw << 32) | blockIdx.x;
-                const unsigned i = atomicAdd(&g_ts_n, 1u);
-                if (i < (unsigned)TS_MAX)
-                    for (int k = 0; k < 6; ++k) g_ts[i][k] = t[k];
+                const unsigned i = atomicAdd(&g_ts_n, 1u) & (unsigned)(TS_MAX - 1);   // a ring: the last TS_MAX workgroups
+                for (int k = 0; k < TS_W; ++k) g_ts[i][k] = t[k];
             }
         }
     } ts_flush{ts};
     TS_MARK(0);
 #endif
-    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    // planes per operand: NSPLIT 3 = A_lo B_hi + A_hi B_lo + A_hi B_hi; NSPLIT 2 = A_hi (B_hi + B_lo) -- the A operand (the dY of a
+    // gradient product) contributes its bf16 head only, a third less MFMA work and a quarter less staging; NSPLIT 1 = A_hi B_hi
+    constexpr int NPA = NSPLIT == 3 ? 2 : 1, NPB = NSPLIT >= 2 ? 2 : 1;
     constexpr int SUBM = BM / PT, SUBN = BN / PT;            // 64-row plane images per operand panel
     constexpr int MT = BM / 64, NT = BN / 32;                // 16 x 16 MFMA tiles per wave: (BM/4)/16 x (BN/2)/16
     constexpr int IMG_E = PT * BKS;                          // elements of one image (8 KiB at 64 k, 4 KiB at 32 k)
-    constexpr int A_IMGS = NP * SUBM, B_IMGS = NP * SUBN;
+    constexpr int A_IMGS = NPA * SUBM, B_IMGS = NPB * SUBN;
     constexpr int STAGE = (A_IMGS + B_IMGS) * IMG_E;         // A planes then B planes
     constexpr int PIECES = (A_IMGS + B_IMGS) * BKS / 64;     // DMA instructions per wave and stage
     constexpr int KSUB = PT / BKS;                           // ring steps per 64-k tile
@@ -197,33 +202,34 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
     // instead (its products land in rows >= M / columns >= N, which no epilogue stores)
     const int am_last = ((M + PT - 1) / PT - 1) * PT, bn_last = ((N + PT - 1) / PT - 1) * PT;
 
+    // this wave's DMA pieces of a stage: per operand panel piece a loop-invariant lane offset (bytes inside the plane; planes
+    // are far below 4 GiB); the hi and the lo plane of an operand share it
+    constexpr int APC = BKS == 64 ? SUBM : SUBM / 2, BPC = BKS == 64 ? SUBN : SUBN / 2;      // pieces per plane and stage
+    unsigned aoff[APC], boff[BPC];
+#pragma unroll
+    for (int q = 0; q < APC; ++q) {
+        if constexpr (BKS == 64) aoff[q] = plane_lane_off<AK>(g.lda_p, BM > PT ? min(bm0 + q * PT, am_last) : bm0, wave, lane);
+        else aoff[q] = slab32_lane_off<AK>(g.lda_p, bm0 + 2 * q * PT, am_last, wave, lane);
+    }
+#pragma unroll
+    for (int q = 0; q < BPC; ++q) {
+        if constexpr (BKS == 64) boff[q] = plane_lane_off<BK>(g.ldb_p, BN > PT ? min(bn0 + q * PT, bn_last) : bn0, wave, lane);
+        else boff[q] = slab32_lane_off<BK>(g.ldb_p, bn0 + 2 * q * PT, bn_last, wave, lane);
+    }
+    constexpr int PSTEP = BKS == 64 ? 1 : 2;                 // images a piece spans (a 32-k slab = two images)
     auto issue = [&](int kt, int stage) {
         const int k0 = (kt < kt1 ? kt : kt0) * BKS;       // past-the-end prefetch re-reads a valid tile (never consumed)
-        unsigned short* s = smem + stage * STAGE;
-        if constexpr (BKS == 64) {
+        const long ka = AK ? (long)k0 : (long)k0 * g.lda_p, kb = BK ? (long)k0 : (long)k0 * g.ldb_p;    // uniform
+        unsigned short* s = smem + stage * STAGE + wave * 512;
 #pragma unroll
-            for (int sm = 0; sm < SUBM; ++sm) {
-                const int r0 = BM > PT ? min(bm0 + sm * PT, am_last) : bm0;
-                dma_plane<AK>(g.A_hi, g.lda_p, r0, k0, s + sm * IMG_E, wave, lane);
-                if (NSPLIT == 3) dma_plane<AK>(g.A_lo, g.lda_p, r0, k0, s + (SUBM + sm) * IMG_E, wave, lane);
-            }
+        for (int q = 0; q < APC; ++q) {
+            dma_piece(g.A_hi, ka, aoff[q], s + q * PSTEP * IMG_E);
+            if (NPA == 2) dma_piece(g.A_lo, ka, aoff[q], s + (SUBM + q * PSTEP) * IMG_E);
+        }
 #pragma unroll
-            for (int sn = 0; sn < SUBN; ++sn) {
-                const int r0 = BN > PT ? min(bn0 + sn * PT, bn_last) : bn0;
-                dma_plane<BK>(g.B_hi, g.ldb_p, r0, k0, s + (A_IMGS + sn) * IMG_E, wave, lane);
-                if (NSPLIT == 3) dma_plane<BK>(g.B_lo, g.ldb_p, r0, k0, s + (A_IMGS + SUBN + sn) * IMG_E, wave, lane);
-            }
-        } else {
-#pragma unroll
-            for (int sm = 0; sm < SUBM; sm += 2) {            // a slab = images sm, sm + 1
-                dma_slab32<AK>(g.A_hi, g.lda_p, bm0 + sm * PT, am_last, k0, s + sm * IMG_E, wave, lane);
-                if (NSPLIT == 3) dma_slab32<AK>(g.A_lo, g.lda_p, bm0 + sm * PT, am_last, k0, s + (SUBM + sm) * IMG_E, wave, lane);
-            }
-#pragma unroll
-            for (int sn = 0; sn < SUBN; sn += 2) {
-                dma_slab32<BK>(g.B_hi, g.ldb_p, bn0 + sn * PT, bn_last, k0, s + (A_IMGS + sn) * IMG_E, wave, lane);
-                if (NSPLIT == 3) dma_slab32<BK>(g.B_lo, g.ldb_p, bn0 + sn * PT, bn_last, k0, s + (A_IMGS + SUBN + sn) * IMG_E, wave, lane);
-            }
+        for (int q = 0; q < BPC; ++q) {
+            dma_piece(g.B_hi, kb, boff[q], s + (A_IMGS + q * PSTEP) * IMG_E);
+            if (NPB == 2) dma_piece(g.B_lo, kb, boff[q], s + (A_IMGS + SUBN + q * PSTEP) * IMG_E);
         }
     };
 
@@ -260,10 +266,10 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 const int row = wm0 + 16 * i;              // a 16-row MFMA tile never straddles two 64-row images
                 if constexpr (BKS == 64) {
                     ah[i] = pfrag<AK>(s + (row / PT) * IMG_E, row % PT, kk, lane);
-                    if (NSPLIT == 3) al[i] = pfrag<AK>(s + (SUBM + row / PT) * IMG_E, row % PT, kk, lane);
+                    if (NPA == 2) al[i] = pfrag<AK>(s + (SUBM + row / PT) * IMG_E, row % PT, kk, lane);
                 } else {
                     ah[i] = pfrag32<AK>(s + (row / PT) * IMG_E, row % PT, lane);
-                    if (NSPLIT == 3) al[i] = pfrag32<AK>(s + (SUBM + row / PT) * IMG_E, row % PT, lane);
+                    if (NPA == 2) al[i] = pfrag32<AK>(s + (SUBM + row / PT) * IMG_E, row % PT, lane);
                 }
             }
 #pragma unroll
@@ -271,20 +277,18 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 const int row = wn0 + 16 * j;
                 if constexpr (BKS == 64) {
                     bh[j] = pfrag<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, kk, lane);
-                    if (NSPLIT == 3) bl[j] = pfrag<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, kk, lane);
+                    if (NPB == 2) bl[j] = pfrag<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, kk, lane);
                 } else {
                     bh[j] = pfrag32<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, lane);
-                    if (NSPLIT == 3) bl[j] = pfrag32<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, lane);
+                    if (NPB == 2) bl[j] = pfrag32<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, lane);
                 }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    if (NSPLIT == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
+                    if (NPA == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (NPB == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -303,7 +307,7 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 for (int k = 0; k < 8; ++k) {
                     const int off = BKS == 64 ? img_off<AK>(row, kq + k) : img32_off<AK>(row, kq + k);
                     t += pbf2f(s[im * IMG_E + off]);
-                    if (NSPLIT == 3) t += pbf2f(s[(SUBM + im) * IMG_E + off]);
+                    if (NPA == 2) t += pbf2f(s[(SUBM + im) * IMG_E + off]);
                 }
                 if (BKS == 64) rowsum[sm] += t;
                 else if (kt & 1) rowsum[sm + 1] += t;          // (kt0 is even: a split starts on a 64-k tile)
@@ -704,16 +708,23 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupP
     if (lid >= job.tiles_x * job.tiles_y * job.nks) return;                 // padding block of a merged launch (jobs start on multiples of 8)
     constexpr GeoInfo g = GEO[G];
     probe_kernel_begin();
+    // variants 3, 4 (launches of the split-bf16 family only): the gradient products of one dY with its bf16 head alone (precision 2)
     if (job.variant == 0) plane_tile<NSPLIT, true, true, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
     else if (job.variant == 1) plane_tile<NSPLIT, true, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
-    else plane_tile<NSPLIT, false, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
+    else if (job.variant == 2) plane_tile<NSPLIT, false, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
+    // (a two-pass stage is 3/4 of a three-pass one: THREE of them fit where two of those do -- a prefetch distance of two K-steps)
+    else if (NSPLIT == 3 && job.variant == 3) plane_tile<2, true, false, g.bm, g.bn, g.bks, g.nst + 1>(job, lid, smem);
+    else if (NSPLIT == 3) plane_tile<2, false, false, g.bm, g.bn, g.bks, g.nst + 1>(job, lid, smem);
     probe_kernel_end();
 }
 
-// ring bytes: stages x (A + B panels) x (hi, lo) x bks k x 2 B -- 64 KiB, 128 KiB, 64 KiB; the epilogue's fp32 image of the tile
-// (bm x (bn + 4) floats: 17 KiB / 66 KiB) lives in the same memory, so the 32-k geometry asks for 66 KiB
+// ring bytes: stages x (A + B panels) x (hi, lo) x bks k x 2 B -- 64 KiB, 128 KiB, 64 KiB for three-pass jobs; 72 / 144 / 72 KiB for
+// two-pass jobs (three stages of A_hi + B_hi + B_lo); the epilogue's fp32 image of the tile (bm x (bn + 4) floats: 17 KiB / 66 KiB)
+// lives in the same memory.  A launch asks for the largest (one workgroup size per launch): two workgroups per CU still fit
 constexpr size_t plane_lds(int geo) {
-    const size_t ring = (size_t)GEO[geo].nst * 2 * (GEO[geo].bm + GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);
+    const size_t ring3 = (size_t)GEO[geo].nst * 2 * (GEO[geo].bm + GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);
+    const size_t ring2 = (size_t)(GEO[geo].nst + 1) * (GEO[geo].bm + 2 * GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);   // two-pass jobs: one stage more
+    const size_t ring = ring3 > ring2 ? ring3 : ring2;
     const size_t image = (size_t)GEO[geo].bm * (GEO[geo].bn + 4) * sizeof(float);
     return ring > image ? ring : image;
 }
@@ -843,7 +854,9 @@ static int check_plane_job(const slnlp_gemm_args& a) {
         SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "gemm_planes: bad dropout args");
         return 0;
     }
-    SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo && a.B_lo), "gemm_planes: precision 3 needs lo planes");
+    SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo && a.B_lo) || (a.precision == 2 && a.B_lo),
+                    "gemm_planes: precision 3 needs both lo planes, precision 2 the lo plane of B");
+    SLNLP_CHECK_ARG(a.precision != 2 || !a.b_kmajor, "gemm_planes: precision 2 is built for the gradient layouts (B m-major)");
     SLNLP_CHECK_ARG(a.lda_p % 64 == 0 && a.ldb_p % 64 == 0, "gemm_planes: plane row strides must be multiples of 64");
     SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.B_hi | (uintptr_t)a.A_lo | (uintptr_t)a.B_lo) & 15) == 0,
                     "gemm_planes: planes must be 16-byte aligned");
@@ -879,12 +892,15 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
     for (int i = 0; i < njobs; ++i) {
         const slnlp_gemm_args& a = jobs[i];
         SLNLP_TRY(check_plane_job(a));
-        SLNLP_CHECK_ARG(a.precision == jobs[0].precision, "gemm_group: jobs of one launch share the precision");
+        // one launch = one kernel family: fp8, single-pass bf16, or split-bf16 (precision 3 and 2 jobs may share a launch)
+        auto family = [](int p) { return p == 2 ? 3 : p; };
+        SLNLP_CHECK_ARG(family(a.precision) == family(jobs[0].precision), "gemm_group: jobs of one launch share the precision family");
         PlaneJob& j = P.job[i];
         j.a = a;
         j.drop_thr = dropout_threshold(a.drop_p);
         j.drop_scale = 1.f / (1.f - a.drop_p);
         j.variant = a.precision == 8 ? 3 : (a.a_kmajor && a.b_kmajor) ? 0 : a.a_kmajor ? 1 : 2;
+        if (a.precision == 2) j.variant = a.a_kmajor ? 3 : 4;
         j.hand_off = splitk_mode() >= 2 ? splitk_mode() : 0;
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         j.vec_out = a.N % 4 == 0 && (!a.C || (a.ldc % 4 == 0 && al16(a.C))) && (!a.resid || (a.ldr % 4 == 0 && al16(a.resid))) &&
@@ -1111,7 +1127,7 @@ extern "C" int slnlp_probe_ts(unsigned long long* dst, int max_entries) {
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(slnlp::g_ts_n), sizeof(n)) != hipSuccess) return -1;
     if (n > (unsigned)slnlp::TS_MAX) n = slnlp::TS_MAX;
     if ((int)n > max_entries) n = max_entries;
-    if (n && hipMemcpyFromSymbol(dst, HIP_SYMBOL(slnlp::g_ts), (size_t)n * 6 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (n && hipMemcpyFromSymbol(dst, HIP_SYMBOL(slnlp::g_ts), (size_t)n * slnlp::TS_W * sizeof(unsigned long long)) != hipSuccess) return -1;
     const unsigned zero = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(slnlp::g_ts_n), &zero, sizeof(zero)) != hipSuccess) return -1;
     return (int)n;

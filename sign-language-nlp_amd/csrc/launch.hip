@@ -107,6 +107,34 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
 
 }  // namespace slnlp
 
+// ---- how many split-bf16 passes the gradient products of the plane GEMM take (slnlp.h: slnlp_set_backward_passes)
+namespace slnlp {
+static int env_passes(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return v == 2 || v == 3 ? v : dflt;
+}
+static std::atomic<int> g_wgrad_passes{env_passes("SLNLP_WGRAD_PASSES", 2)};
+static std::atomic<int> g_dgrad_passes{env_passes("SLNLP_DGRAD_PASSES", 3)};
+int wgrad_passes() { return g_wgrad_passes.load(std::memory_order_relaxed); }
+int dgrad_passes() { return g_dgrad_passes.load(std::memory_order_relaxed); }
+}  // namespace slnlp
+
+extern "C" int slnlp_set_backward_passes(int wgrad, int dgrad) {
+    if ((wgrad != 2 && wgrad != 3) || (dgrad != 2 && dgrad != 3)) {
+        slnlp::set_error("set_backward_passes: wgrad = %d, dgrad = %d (each 2 or 3)", wgrad, dgrad);
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    slnlp::g_wgrad_passes.store(wgrad, std::memory_order_relaxed);
+    slnlp::g_dgrad_passes.store(dgrad, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int slnlp_get_backward_passes(int* wgrad, int* dgrad) {
+    if (wgrad) *wgrad = slnlp::wgrad_passes();
+    if (dgrad) *dgrad = slnlp::dgrad_passes();
+    return 0;
+}
+
 extern "C" int slnlp_set_stream_policy(int serialise) {
     slnlp::g_stream_policy.store(serialise ? 1 : 0, std::memory_order_relaxed);
     return 0;

@@ -184,4 +184,9 @@ struct LsAdam { float beta1, beta2, eps, weight_decay; };
 // zero `bytes` (a multiple of 16, 16-B aligned) with a kernel of ours: recordable, unlike hipMemsetAsync
 int fill_zero(void* p, size_t bytes, hipStream_t st);
 
+// split-bf16 passes of the plane GEMM's gradient products (2: the dY operand enters with its bf16 head only; 3: full split) --
+// process-wide, read when a plan builds (or records) its launches: slnlp_set_backward_passes, launch.hip
+int wgrad_passes();
+int dgrad_passes();
+
 }  // namespace slnlp

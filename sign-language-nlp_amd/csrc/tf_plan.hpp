@@ -503,7 +503,7 @@ struct slnlp_tf_plan {
         a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
         a.resid = resid; a.ldr = Kin;
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = Kin; }
-        a.precision = prec3();
+        a.precision = prec3() == 3 ? dgrad_passes() : prec3();
         return a;
     }
     int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
@@ -517,7 +517,7 @@ struct slnlp_tf_plan {
         a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
-        a.precision = prec3();
+        a.precision = prec3() == 3 ? wgrad_passes() : prec3();
         return a;
     }
     int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {

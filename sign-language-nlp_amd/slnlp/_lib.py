@@ -147,6 +147,8 @@ SIGNATURES = {
     "slnlp_tf_debug_layout": (i32, [vp, C.c_char_p, i64]),
     "slnlp_tf_set_destroy_sync": (i32, [vp, i32]),
     "slnlp_set_stream_policy": (i32, [i32]),
+    "slnlp_set_backward_passes": (i32, [i32, i32]),
+    "slnlp_get_backward_passes": (i32, [C.POINTER(i32), C.POINTER(i32)]),
     "slnlp_set_plane_tile": (i32, [i32]),
     "slnlp_set_fp8_tile": (i32, [i32]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),

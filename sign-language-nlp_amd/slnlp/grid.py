@@ -48,16 +48,26 @@ def parameter_grid(param_grid):
     return [dict(zip(keys, vals)) for vals in itertools.product(*[param_grid[k] for k in keys])]
 
 
+# estimate_cost: fixed work per batch and per layer, in the units of the arithmetic term (multiply-adds per sequence).  Measured on
+# MI355X (bench.py's grid sample, one lockstep-15 unit alone on the GPU, profiles/r04_grid_calibration.json): E512 N4 / E512 N2 /
+# E128 N4 / E128 N2 units take 4.9 / 2.9 / 2.4 / 1.45 s where the arithmetic alone says 1 : 0.5 : 0.13 : 0.065 -- a step is a chain of
+# dependent launches whose length grows with the number of layers, not with their width.  Least squares over the four classes:
+COST_PER_STEP, COST_PER_LAYER = 13.7e6, 9.5e6
+
+
 def estimate_cost(params, seq_len=48, n_samples=1, defaults=None):
-    """Relative cost of one fit, for the longest-first order only: samples x epochs x per-sequence FLOPs
-    ~ N x (S x (E^2 + E x F) + S^2 x E) (attention's S^2 term matters once S > E)."""
+    """Relative cost of one fit -- what orders the work list, sizes the work units and feeds the admission control: samples x
+    epochs x (fixed + layers x (fixed + per-sequence arithmetic ~ S x (E^2 + E x F) + S^2 x E)) (SURVEY.md section 8e;
+    attention's S^2 term matters once S > E).  The two fixed terms are the launch-bound floor of a step (above): without them a
+    small model's fit is under-estimated five-fold against a large one's."""
     d = dict(defaults or {})
     d.update(params)
     E = d.get("module__embedding_size", 128)
     F = d.get("module__hidden_size", 256)
     N = d.get("module__num_layers", 2)
     epochs = d.get("max_epochs", 1)
-    return float(n_samples) * float(epochs) * float(N) * (seq_len * (E * E + E * F) + seq_len * seq_len * E)
+    arith = seq_len * (E * E + E * F) + seq_len * seq_len * E
+    return float(n_samples) * float(epochs) * (COST_PER_STEP + float(N) * (COST_PER_LAYER + arith))
 
 
 def build_tasks(param_grid, y, cv, seq_len=48, defaults=None):
@@ -105,29 +115,67 @@ def estimate_fit_bytes(params, seq_len, defaults=None, lockstep=1):
         return None
 
 
-def build_units(cands, folds, tasks, order, lockstep=1, cap=None):
+def build_units(cands, folds, tasks, order, lockstep=1, cap=None, task_cost=None, max_unit_cost=None, min_width=4):
     """Pack the cost-ordered task list into work units of up to ``lockstep`` tasks that can advance through one
     launch sequence: same candidate shapes (every parameter except lr / dropout rate) and the same train-fold
     size (=> the same number and sizes of batches).  ``lockstep <= 1``: one task per unit.  ``cap(candidate index)``: an upper
-    bound on the unit size for that candidate (device memory), or None."""
+    bound on the unit size for that candidate (device memory), or None.
+
+    ``max_unit_cost`` (with ``task_cost(task)``): a ceiling on a unit's estimated cost -- how the search keeps at least a
+    couple of units per host thread and GPU when the grid is spread over many GPUs (``unit_cost_ceiling``): a compatible group
+    whose cost exceeds it is cut into the fewest EQUAL parts that fit under it, never narrower than ``min_width`` tasks (a
+    narrow lockstep unit fills the GPU less well).  Groups are cut evenly (15 tasks under a limit of 4 -> 4 + 4 + 4 + 3), and
+    with ``task_cost`` the units are returned by estimated cost, longest first (ties: position of the first task) -- the
+    order the ``WorkCounter`` hands them out in; without it a unit keeps the position of its first task."""
     if lockstep <= 1:
         return [[t] for t in order]
-    units, open_units = [], {}
+    groups = {}
     for t in order:
         ci, fi = tasks[t]
         drop = cands[ci].get("module__dropout")
         key = (tuple(sorted((k, repr(v)) for k, v in cands[ci].items() if k not in SHAPE_KEYS_EXCLUDED)),
                None if drop is None else bool(drop > 0),          # dropout on / off changes the launch sequence, its rate does not
                len(folds[fi][0]), len(folds[fi][1]))
-        u = open_units.get(key)
-        if u is None:
-            u = open_units[key] = []
-            units.append(u)                      # a unit keeps the position of its first (most expensive) task
-        u.append(t)
-        limit = lockstep if cap is None else max(1, min(lockstep, cap(ci)))
-        if len(u) >= limit:
-            del open_units[key]
+        groups.setdefault(key, []).append(t)
+    units = []
+    for members in groups.values():
+        limit = lockstep
+        if cap is not None:
+            limit = min(limit, max(1, min(cap(tasks[t][0]) for t in members)))
+        if max_unit_cost is not None and task_cost is not None:
+            dearest = max(task_cost(t) for t in members)
+            if dearest > 0:
+                limit = min(limit, max(min(min_width, limit), int(max_unit_cost // dearest)))
+        parts = -(-len(members) // limit)
+        base, extra = divmod(len(members), parts)
+        at = 0
+        for p in range(parts):
+            n = base + (1 if p < extra else 0)
+            units.append(members[at:at + n])
+            at += n
+    pos = {t: i for i, t in enumerate(order)}
+    if task_cost is not None:
+        units.sort(key=lambda u: (-sum(task_cost(t) for t in u), pos[u[0]]))
+    else:
+        units.sort(key=lambda u: pos[u[0]])
     return units
+
+
+# unit_cost_ceiling: aim for at least this many work units per host thread of every GPU.  slnlp.grid_sim on bench.py's sample with
+# the unit durations and the concurrency gains measured on one MI355X (profiles/r04_grid_calibration.json): strong-scaling
+# efficiency at 8 GPUs 0.82 without cutting (32 units: every GPU ends with its one long unit alone on the card), 0.90 at 2 per
+# thread, 0.95 at 3, 0.97 at 6 (124 units of 4-5 fits; 0.98 at 2 and 4 GPUs) -- the tail of the schedule shrinks with the last units.
+# Narrow units cost nothing once four run side by side: lockstep 5 x 4 threads = lockstep 15 x 4 threads = 27.2 k folds/hr measured.
+UNITS_PER_THREAD = 6.0
+
+
+def unit_cost_ceiling(total_cost, world, fits_per_gpu, units_per_thread=UNITS_PER_THREAD):
+    """The estimated cost above which a lockstep group is cut into several units: ``total / (world x fits_per_gpu x
+    units_per_thread)``.  With 4 units per GPU (bench.py's 32 lockstep-15 units on 8 GPUs) every GPU ends its run with its one
+    long unit alone on the card -- measured on one GPU, a single resident unit delivers about 60 % of what three or four side
+    by side do -- so the long groups are cut until every host thread has a couple of units to work
+    through and the tail of the schedule is a short unit, not a long one."""
+    return float(total_cost) / (max(1, world) * max(1, fits_per_gpu) * units_per_thread)
 
 
 def _dist():
@@ -187,56 +235,81 @@ class WorkCounter:
     * the first ``world`` units -- the longest: the list is sorted longest first -- are dealt one per rank (unit r to rank r);
     * after that a rank with nothing in flight always gets the next unit from the shared counter (``store.add`` on the process
       group's rendezvous store; a locked integer inside one process);
-    * a rank that already runs k units gets another one only while more than ``world * (k - 1)`` units are left (for every unit
-      it runs beyond its first, every rank can still be given one: with 32 units on 8 ranks three run side by side per GPU,
-      the fourth host thread joins as units finish -- round 3 started with ``world * k``, which kept it at two: measured on one
-      GPU, two units side by side do 23.2 k folds/hr, three 26.7 k, four 27.4 k) AND the unit would keep the rank's estimated load -- the sum of ``unit_costs`` of what it
-      has taken -- within its fair share ``sum(unit_costs) / world``: prefetching for the host threads never takes what the
-      longest-first deal would give to a less loaded rank.  Otherwise its extra threads wait; they leave when the list is
-      exhausted.
+    * a rank that already runs k units (on its other host threads) gets another one only while that keeps its estimated load --
+      the sum of ``unit_costs`` of what it has taken -- within its fair share ``sum(unit_costs) / world`` (+ ``slack`` mean unit
+      costs): prefetching for the host threads never takes what the longest-first deal would give to a less loaded rank.
+      Otherwise its extra threads wait (polling the counter with a back-off); they leave when the list is exhausted.  Round 3
+      also required more than ``world * (k - 1)`` units to be left (``reserve=True`` keeps that rule for comparison): with 32
+      units on 8 ranks it made every GPU finish its longest unit alone -- slnlp.grid_sim prices that at 0.82 of ideal; the
+      work list is now cut finer instead (``unit_cost_ceiling``) and the fair share alone admits a unit (0.97).
+    * the decision reads the shared counter and this rank's load without a global lock: two ranks may both pass the test for
+      the same next unit, and the second then receives the one after it -- the estimate it was admitted on is off by one unit
+      of a cost-sorted list, which the fair-share bound tolerates.
 
     ``abort()`` (first failed unit, any rank) makes every later ``acquire`` on every rank return None, so a broken grid stops
     at once instead of burning through the remaining units (the reference searches with ``error_score='raise'``,
     helper.py:162,193).  ``static``: the round-robin deal ``i % world`` without a counter.
     """
 
-    POLL_S = 0.01
+    POLL_S, POLL_MAX_S = 0.02, 0.2      # a waiting host thread asks again after 20 ms, backing off to 200 ms (one store request each)
+    ABORT = 1 << 40                       # added to the shared counter by abort(): one request returns {units taken, aborted}
 
-    def __init__(self, key, n_units, static=False, unit_costs=None):
-        dist, self.rank, self.world = _dist()
-        self._lock, self._n, self._store, self._key = threading.Lock(), 0, None, key
+    def __init__(self, key, n_units, static=False, unit_costs=None, rank=None, world=None, store=None, reserve=False,
+                 slack=0.0):
+        """``rank`` / ``world`` / ``store`` given explicitly: a counter outside a process group (slnlp.grid_sim drives one per
+        simulated rank against a shared in-memory store; tests)."""
+        if rank is None:
+            dist, self.rank, self.world = _dist()
+        else:
+            self.rank, self.world = int(rank), int(world)
+        self._lock, self._n, self._store, self._key = threading.Lock(), 0, store, key
         self.n_units, self.static = int(n_units), static
         self._costs = [float(c) for c in unit_costs] if unit_costs is not None else [1.0] * self.n_units
         self._fair, self._load = sum(self._costs) / max(1, self.world), 0.0
         self._in_flight, self._dealt, self._aborted = 0, False, False
-        if self.world > 1:
+        # reserve: round 3's extra rule (a rank running k units pulls only while more than world x (k - 1) are left) -- off
+        # since round 4: it left every GPU to finish its longest unit alone (grid_sim: 0.92 of ideal at 8 GPUs; 0.97 without).
+        # slack: how far beyond its fair share (in units of the mean unit cost) a busy rank may prefetch.
+        self._reserve = bool(reserve)
+        self._slack = float(slack) * (sum(self._costs) / max(1, self.n_units))
+        if self.world > 1 and store is None:
             try:
                 from torch.distributed.distributed_c10d import _get_default_store
                 self._store = _get_default_store()
             except Exception:                      # no rendezvous store reachable: fall back to the static deal
                 self.static = True
 
-    # ---- shared state: units handed out beyond the initial deal, and the abort flag
+    # ---- shared state: units handed out beyond the initial deal; the abort flag rides in the same counter (bit 40)
     def _taken(self, inc):
         if self._store is not None and not self.static:
-            return int(self._store.add(self._key, inc))
-        with self._lock:
-            self._n += inc
-            return self._n
+            v = int(self._store.add(self._key, inc))
+        else:
+            with self._lock:
+                self._n += inc
+                v = self._n
+        if v >= self.ABORT:
+            self._aborted = True
+        return v % self.ABORT
 
     def aborted(self):
         if not self._aborted and self._store is not None:
-            self._aborted = int(self._store.add(self._key + "/abort", 0)) > 0
+            if self.static:
+                self._aborted = int(self._store.add(self._key + "/abort", 0)) > 0
+            else:
+                self._taken(0)
         return self._aborted
 
     def abort(self):
         self._aborted = True
         if self._store is not None:
-            self._store.add(self._key + "/abort", 1)
+            self._store.add(self._key + "/abort" if self.static else self._key, 1 if self.static else self.ABORT)
 
     def release(self):
         with self._lock:
             self._in_flight -= 1
+
+    def cost(self, i):
+        return self._costs[i]
 
     def acquire(self):
         """Index of this thread's next unit, or None when there is nothing (more) to run.  Pair with release()."""
@@ -252,11 +325,13 @@ class WorkCounter:
                 self.release()
                 return None
             return i
+        wait = self.POLL_S
         while True:
             i = self.try_acquire()
             if i is not WorkCounter.WAIT:
                 return i
-            time.sleep(self.POLL_S)
+            time.sleep(wait)
+            wait = min(self.POLL_MAX_S, wait * 1.5)
 
     WAIT = object()
 
@@ -264,7 +339,7 @@ class WorkCounter:
         """One admission decision: a unit index, None (nothing more to run) or WAIT (ask again later)."""
         dealt = min(self.world, self.n_units)       # units 0 .. dealt-1: one per rank
         while True:
-            if self.aborted():
+            if self._aborted:
                 return None
             with self._lock:
                 if not self._dealt:
@@ -278,11 +353,12 @@ class WorkCounter:
                     self._in_flight += 1            # reserve: an idle rank always pulls
             if k == 0:
                 return self._pull(dealt)
-            nxt = dealt + self._taken(0)            # the unit the counter would hand out now
+            nxt = dealt + self._taken(0)            # the unit the counter would hand out now (one request: it carries the abort flag)
             left = self.n_units - nxt
-            if left <= 0:
+            if left <= 0 or self._aborted:
                 return None
-            if left > self.world * (k - 1) and self._load + self._costs[nxt] <= self._fair * (1 + 1e-9):
+            if (not self._reserve or left > self.world * (k - 1)) and \
+                    self._load + self._costs[nxt] <= self._fair * (1 + 1e-9) + self._slack:
                 with self._lock:
                     if self._in_flight != k:
                         continue                    # another thread of this rank moved meanwhile: look again
@@ -292,7 +368,7 @@ class WorkCounter:
 
     def _pull(self, dealt):                         # (the caller has reserved the in-flight slot)
         i = dealt + self._taken(1) - 1
-        if i >= self.n_units:
+        if i >= self.n_units or self._aborted:
             self.release()
             return None
         with self._lock:
@@ -348,7 +424,8 @@ def _recipe_init_factory(factory):
 class ShardedGridSearchCV:
     def __init__(self, estimator_factory, param_grid, cv=5, scoring="neg_log_loss", refit=True, fit_and_score=None,
                  device="cpu", verbose=0, fits_per_gpu=1, seed=1, schedule="dynamic", lockstep=1,
-                 fit_and_score_group=None, force_collectives=False, recipe_init=True, memory_fraction=0.4):
+                 fit_and_score_group=None, force_collectives=False, recipe_init=True, memory_fraction=0.4,
+                 units_per_thread=UNITS_PER_THREAD, min_unit_width=4):
         self.estimator_factory, self.param_grid, self.cv = estimator_factory, param_grid, cv
         self.recipe_init = bool(recipe_init)
         self.memory_fraction = float(memory_fraction)     # of the device's memory that resident fits may take (unit size cap)
@@ -359,6 +436,9 @@ class ShardedGridSearchCV:
         assert schedule in ("dynamic", "static")
         self.schedule, self.lockstep, self.fit_and_score_group = schedule, int(lockstep), fit_and_score_group
         self.force_collectives = force_collectives
+        # lockstep groups are cut until every host thread of every GPU has about this many units (0 / None: never cut), but not
+        # into units narrower than min_unit_width fits -- build_units, unit_cost_ceiling
+        self.units_per_thread, self.min_unit_width = units_per_thread, int(min_unit_width)
 
     def _defaults(self):
         try:
@@ -388,14 +468,20 @@ class ShardedGridSearchCV:
                     b = estimate_fit_bytes(cands[ci], S, defaults, min(self.lockstep, 64))
                     per[ci] = self.lockstep if not b else int(budget // (max(1, self.fits_per_gpu) * b))
                 return per[ci]
-        units = build_units(cands, folds, tasks, order, self.lockstep if group_fn else 1, cap)
-        call = next(_FIT_CALLS)
         task_cost = lambda t: estimate_cost(cands[tasks[t][0]], ds.ids.shape[1], len(folds[tasks[t][1]][0]), self._defaults_cache)
+        ceiling = unit_cost_ceiling(sum(task_cost(t) for t in range(len(tasks))), world, self.fits_per_gpu, self.units_per_thread) \
+            if self.units_per_thread else None
+        units = build_units(cands, folds, tasks, order, self.lockstep if group_fn else 1, cap, task_cost, ceiling, self.min_unit_width)
+        # what a unit is, for logs and the schedule simulator: its candidates' shape-defining numeric parameters
+        self.unit_shapes_ = [{k.replace("module__", ""): v for k, v in cands[tasks[u[0]][0]].items()
+                              if k not in SHAPE_KEYS_EXCLUDED and isinstance(v, (int, float))} for u in units]
+        call = next(_FIT_CALLS)
         counter = WorkCounter(f"slnlp/grid/{call}/next", len(units), static=self.schedule == "static",
                               unit_costs=[sum(task_cost(t) for t in u) for u in units])
         rows = torch.full((len(tasks), 3), float("nan"), dtype=torch.float64)      # score, seconds, error flag
         rows[:, 2] = 0.0
         mine, errors = [], []
+        self.unit_log_ = []          # this rank's units: (unit index, fits, estimated cost, start s, end s) -- what grid_sim replays
         if dist is not None and world > 1:
             # ranks reach this point at different times (imports, the first fold split): start the clock -- and the race for
             # the dynamically scheduled units -- together, so rank_seconds_ are comparable across ranks
@@ -445,10 +531,13 @@ class ShardedGridSearchCV:
                     return
                 with lock:
                     mine.extend(units[i])
+                u_t0 = time.time()
                 try:
                     run_unit(units[i])
                 finally:
                     counter.release()
+                    with lock:
+                        self.unit_log_.append((i, len(units[i]), counter.cost(i), round(u_t0 - t_start, 3), round(time.time() - t_start, 3)))
 
         if self.fits_per_gpu > 1:
             threads = [threading.Thread(target=worker) for _ in range(self.fits_per_gpu)]

@@ -13,6 +13,8 @@ import torch.multiprocessing as mp
 from slnlp import grid
 from slnlp.data import synthetic_dataset
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GRID = {"lr": [0.1, 0.01], "module__embedding_size": [16, 32], "module__num_layers": [1, 2]}
 CV = 3
 
@@ -194,13 +196,14 @@ def test_admission_control_deals_long_units_one_per_rank_with_host_threads():
 
 
 def test_work_counter_admission_single_process():
-    """The same rule inside one process (world 1): an idle rank always pulls, a busy one only while units are left over."""
+    """Inside one process (world 1) the fair share is everything: a host thread always gets the next unit while units are left
+    (round 3's reserve rule, kept behind reserve=True, makes a fourth thread wait for the last unit)."""
     c = grid.WorkCounter("k", 4)
-    assert c.acquire() == 0                       # the deal
-    assert c.acquire() == 1                       # one unit in flight, 3 left > 1 x 1
-    c.release()                                   # (with two in flight the 2 units left would make a third thread wait)
-    assert c.acquire() == 2                       # 2 left > 1 x 1
-    c.release(); c.release()
+    assert [c.acquire() for _ in range(4)] == [0, 1, 2, 3] and c.acquire() is None
+    c = grid.WorkCounter("k1", 4, reserve=True)
+    assert [c.acquire() for _ in range(3)] == [0, 1, 2]    # the deal; 3 left > 1 x 0; 2 left > 1 x 1
+    assert c.try_acquire() is grid.WorkCounter.WAIT        # three in flight: the 1 unit left is not more than 1 x 2
+    c.release(); c.release(); c.release()
     assert c.acquire() == 3 and c.acquire() is None
     c = grid.WorkCounter("k2", 3)
     assert c.acquire() == 0
@@ -208,43 +211,130 @@ def test_work_counter_admission_single_process():
     assert c.acquire() is None
 
 
-def test_admission_prefetch_stays_within_the_fair_share_of_estimated_work(monkeypatch):
-    """8 ranks, 32 units of estimated cost 2 / 1 / .15 / .08 (8 each, longest first -- the shape of bench.py's grid sample):
-    a rank's extra host threads may take ONE medium unit next to the dealt long one (3.0 <= the fair share 3.23) but not a
-    second one, whatever the number of units still left; then one light unit each (more than 8 x (2 - 1) left), and nothing more
-    while three are in flight (8 left, not more than 8 x 2)."""
-    class Store(dict):
-        def add(self, k, v):
-            self[k] = self.get(k, 0) + v
-            return self[k]
-    store = Store()
+def _counters(world, costs, **kw):
+    from slnlp.grid_sim import MemoryStore
+    store = MemoryStore()
+    return [grid.WorkCounter("k", len(costs), unit_costs=costs, rank=r, world=world, store=store, **kw) for r in range(world)], store
+
+
+def test_admission_prefetch_stays_within_the_fair_share_of_estimated_work():
+    """8 ranks, 32 units of estimated cost 2 / 1 / .15 / .08 (8 each, longest first): a rank's extra host threads may take ONE
+    medium unit next to the dealt long one (3.0 <= the fair share 3.23) but not a second one, whatever the number of units
+    still left; then light units while they fit under the share, and an idle rank always pulls.  One store request per
+    decision carries the abort flag too."""
     costs = [2.0] * 8 + [1.0] * 8 + [0.15] * 8 + [0.08] * 8
-    counters = []
-    for r in range(8):
-        monkeypatch.setattr(grid, "_dist", lambda r=r: (None, r, 8))
-        c = grid.WorkCounter("k", 32, unit_costs=costs)
-        c._store, c.static = store, False      # (no process group here: the constructor fell back to the static deal)
-        counters.append(c)
+    counters, store = _counters(8, costs)
     assert [c.try_acquire() for c in counters] == list(range(8))              # the deal: one long unit per rank
     assert counters[0].try_acquire() == 8                                       # prefetch: 2 + 1 <= 25.84 / 8
-    assert counters[0].try_acquire() is grid.WorkCounter.WAIT                   # a third unit would exceed the share
+    assert counters[0].try_acquire() is grid.WorkCounter.WAIT                   # a second medium unit would exceed the share
     assert [c.try_acquire() for c in counters[1:]] == list(range(9, 16))
-    assert [c.try_acquire() for c in counters] == list(range(16, 24))           # 16 ... 9 left > 8 x (2 - 1), 3.15 <= 3.23
-    assert all(c.try_acquire() is grid.WorkCounter.WAIT for c in counters)      # 8 left, not > 8 x (3 - 1)
-    counters[3].release(); counters[3].release(); counters[3].release()         # rank 3 falls idle: it always pulls
-    assert counters[3].try_acquire() == 24
+    assert [c.try_acquire() for c in counters] == list(range(16, 24))           # 3.15 <= 3.23
+    assert counters[0].try_acquire() == 24                                      # 3.23 <= 3.23: the reserve rule is gone
+    assert counters[0].try_acquire() is grid.WorkCounter.WAIT                   # 3.31 > 3.23
+    for _ in range(4):
+        counters[3].release()                                                   # (rank 3 had three units in flight)
+    counters[3]._in_flight = 0
+    assert counters[3].try_acquire() == 25                                      # an idle rank always pulls
+    n_req = store["k"]
+    counters[5].abort()
+    assert all(c.try_acquire() is None for c in counters) and store["k"] >= grid.WorkCounter.ABORT
+    assert list(store) == ["k"], "units taken and the abort flag share one key: one request per admission decision"
 
 
-def test_bench_grid_sample_has_four_units_per_gpu_at_eight_gpus():
-    """bench.py's strong-scaling sample: 480 fits -> 32 lockstep-15 units in four cost classes of 8, longest first, so the
-    admission rule above gives each of 8 GPUs one unit of every class."""
+def test_simulated_schedule_scales_on_the_bench_sample():
+    """the 8-GPU schedule proven on the CPU before anyone measures it.  slnlp.grid_sim drives the REAL WorkCounter
+    (one per simulated rank, shared in-memory store) for 1 / 2 / 4 / 8 GPUs x 4 host threads in virtual time over bench.py's grid
+    sample, with the per-unit solo durations and the concurrency gains measured on one MI355X
+    (profiles/r04_grid_calibration.json).  The simulated 1-GPU makespan reproduces the measured run; strong-scaling efficiency
+    T(1) / (N T(N)), worst of 8 thread-race orders: >= 0.97 at 2 and 4 GPUs, >= 0.94 at 8.  Round 3's rule and unit list (32 units,
+    reserve rule) are priced beside it: 0.82 at 8 GPUs."""
+    import json, os, bench
+    from slnlp import grid_sim as gs
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r04_grid_calibration.json")))
+    per_fit = {}
+    for u in cal["solo_units_lockstep15_one_thread"]:
+        sh = u["shape"]
+        per_fit.setdefault((sh["embedding_size"], sh["hidden_size"], sh["num_heads"], sh["num_layers"]), []).append(u["seconds"] / u["fits"])
+    per_fit = {k: float(np.mean(v)) for k, v in per_fit.items()}
+    gain = gs.gain_from_throughputs({int(k): v for k, v in cal["throughput_by_threads_lockstep15_kfolds_per_hr"].items() if k.isdigit()})
+    assert 1.4 < gain(4) < 1.5 and gain(8) == gain(4)
+    ds = synthetic_dataset(bench.GRID_SAMPLES, seq_len=48, src_vocab=300, n_labels=200, seed=1, min_len=8)
+    defaults = {"max_epochs": bench.GRID_EPOCHS}
+    cands, folds, tasks, order = grid.build_tasks(bench.GRID_SAMPLE, ds.y, bench.GRID_CV, 48, defaults)
+    tc = lambda t: grid.estimate_cost(cands[tasks[t][0]], 48, len(folds[tasks[t][1]][0]), defaults)
+    total = sum(tc(t) for t in range(len(tasks)))
+    shape = lambda u: tuple(cands[tasks[u[0]][0]][k] for k in ("module__embedding_size", "module__hidden_size", "module__num_heads", "module__num_layers"))
+
+    def units_at(world, per_thread):
+        ceiling = grid.unit_cost_ceiling(total, world, 4, per_thread) if per_thread else None
+        units = grid.build_units(cands, folds, tasks, order, 15, None, tc, ceiling, 4)
+        assert sorted(t for u in units for t in u) == list(range(len(tasks))) and all(len(u) >= 3 for u in units)
+        costs = [sum(tc(t) for t in u) for u in units]
+        assert costs == sorted(costs, reverse=True)                            # handed out longest first, by SUMMED cost
+        return [per_fit[shape(u)] * len(u) for u in units], costs
+
+    def makespan(world, per_thread, **counter_kw):
+        work, costs = units_at(world, per_thread)
+        saved = gs.WorkCounter
+        if counter_kw:
+            import functools
+            gs.WorkCounter = functools.partial(saved, **counter_kw)
+            gs.WorkCounter.WAIT = saved.WAIT
+        try:
+            return max(gs.simulate(work, costs, world, 4, gain, seed=s)["makespan"] for s in range(8)), len(work)
+        finally:
+            gs.WorkCounter = saved
+
+    t1, n1 = makespan(1, grid.UNITS_PER_THREAD)
+    measured = [r for r in cal["runs"] if r["lockstep"] == 15 and r["fits_per_gpu"] == 4][0]["seconds"]
+    assert abs(t1 - measured) / measured < 0.05, (t1, measured)               # the model reproduces the measured 1-GPU run
+    eff = {}
+    for world in (2, 4, 8):
+        tn, n = makespan(world, grid.UNITS_PER_THREAD)
+        eff[world] = t1 / (world * tn)
+        assert n >= 2 * 4 * world                                              # at least a couple of units per host thread
+    assert eff[2] >= 0.97 and eff[4] >= 0.97 and eff[8] >= 0.94, eff
+    t1_old, _ = makespan(1, 0, reserve=True)
+    t8_old, n8_old = makespan(8, 0, reserve=True)
+    assert n8_old == 32 and t1_old / (8 * t8_old) < 0.88, t1_old / (8 * t8_old)   # what round 3 shipped
+
+
+def test_simulated_schedule_with_coarse_units_still_deals_one_long_unit_per_rank():
+    """The case admission control was built for (world 4 x 3 host threads x 8 skewed units, nothing to cut): every rank runs
+    exactly one long unit and the ranks finish together, in the simulator as in the gloo test above."""
+    from slnlp import grid_sim as gs
+    work, costs = [4.0] * 4 + [0.5] * 4, [8.0] * 4 + [1.0] * 4
+    for seed in range(6):
+        r = gs.simulate(work, costs, 4, 3, lambda k: 1.0, seed=seed)           # one stream per rank: no gain from concurrency
+        assert all(sum(1 for u in us if u < 4) == 1 for us in r["rank_units"]), r["rank_units"]
+        assert max(r["rank_seconds"]) <= 4.5 + 1e-9
+
+
+def test_bench_grid_sample_is_cut_finer_as_the_gpu_count_grows():
+    """bench.py's strong-scaling sample: 480 fits in four cost classes (E512 N4 / E512 N2 / E128 N4 / E128 N2).  On one GPU the
+    lockstep groups stay almost whole; on 8 GPUs x 4 host threads they are cut until every thread has about six units, none
+    narrower than 4 fits (a 15-fit group -> 4 + 4 + 4 + 3), all shape-compatible, handed out by summed cost."""
     import bench
     ds = synthetic_dataset(bench.GRID_SAMPLES, seq_len=48, src_vocab=300, n_labels=200, seed=1, min_len=8)
-    cands, folds, tasks, order = grid.build_tasks(bench.GRID_SAMPLE, ds.y, bench.GRID_CV, 48, {"max_epochs": bench.GRID_EPOCHS})
-    units = grid.build_units(cands, folds, tasks, order, 15)
-    assert len(cands) == 96 and len(tasks) == 480 and len(units) == 32 and all(len(u) == 15 for u in units)
+    defaults = {"max_epochs": bench.GRID_EPOCHS}
+    cands, folds, tasks, order = grid.build_tasks(bench.GRID_SAMPLE, ds.y, bench.GRID_CV, 48, defaults)
+    tc = lambda t: grid.estimate_cost(cands[tasks[t][0]], 48, len(folds[tasks[t][1]][0]), defaults)
+    total = sum(tc(t) for t in range(len(tasks)))
+    whole = grid.build_units(cands, folds, tasks, order, 15, None, tc, None)
+    assert len(cands) == 96 and len(tasks) == 480 and len(whole) == 32 and all(len(u) == 15 for u in whole)
     shape = lambda u: (cands[tasks[u[0]][0]]["module__embedding_size"], cands[tasks[u[0]][0]]["module__num_layers"])
-    assert [shape(u) for u in units] == [(512, 4)] * 8 + [(512, 2)] * 8 + [(128, 4)] * 8 + [(128, 2)] * 8
+    assert [shape(u) for u in whole] == [(512, 4)] * 8 + [(512, 2)] * 8 + [(128, 4)] * 8 + [(128, 2)] * 8
+    # the launch-bound floor in the estimate: a small model's unit is a third of a large one's, not a twentieth (measured: 0.30)
+    cost = lambda u: sum(tc(t) for t in u)
+    assert 0.2 < cost(whole[-1]) / cost(whole[0]) < 0.4
+    n_units = {}
+    for world in (1, 2, 4, 8):
+        units = grid.build_units(cands, folds, tasks, order, 15, None, tc, grid.unit_cost_ceiling(total, world, 4), 4)
+        assert sorted(t for u in units for t in u) == list(range(len(tasks)))
+        assert all(3 <= len(u) <= 15 for u in units)
+        assert all(len({shape([t]) for t in u}) == 1 for u in units)
+        n_units[world] = len(units)
+    assert n_units[1] <= 40 and n_units[8] >= 96 and n_units[1] <= n_units[2] <= n_units[4] <= n_units[8], n_units
 
 
 def test_failing_task_raises_on_every_rank_instead_of_hanging():

@@ -493,6 +493,40 @@ def test_plane_tile_geometries_return_the_bits_of_the_64_tile(ops, knob):
         assert torch.equal(a, b), f"output {i} differs between the 64 x 64 tile and geometry {knob}"
 
 
+def test_two_pass_gradient_products_equal_the_product_with_the_bf16_head_of_dY(ops):
+    """precision 2 (slnlp_set_backward_passes: the default for weight gradients): dY enters with its bf16 head only,
+    A_hi (B_hi + B_lo).  Held against the fp64 product of bf16(dY) with the other operand (1e-4: the split of B is still
+    there), against the full product at bf16's rounding (2^-9 of dY, random), and bit for bit across the tile geometries;
+    a 2-pass and a 3-pass job share one grouped launch, with split-K and the fused bias-gradient row sums."""
+    from slnlp._lib import load, check
+    Mtok, Nout, Kin = 2400, 192, 320
+    dY, X, W = rnd(Mtok, Nout, seed=1), rnd(Mtok, Kin, seed=2), rnd(Nout, Kin, seed=3)
+    dYh = (dY.view(torch.int32) & -65536).view(torch.float32).double()       # the hi plane is the fp32 value's top 16 bits
+    dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
+    def run():
+        rs = torch.empty(Nout, device="cuda")
+        jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=2)
+        jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=2)
+        jd3, dX3 = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=3)
+        ops.gemm_group([jw, jd, jd3], [5, 1, 1])
+        torch.cuda.synchronize()
+        return [dW.clone(), rs.clone(), dX.clone(), dX3.clone()]
+    try:
+        outs = {}
+        for knob in (64, 128, 12832):
+            check(load().slnlp_set_plane_tile(knob), "set_plane_tile")
+            outs[knob] = run()
+    finally:
+        load().slnlp_set_plane_tile(0)
+    dW, rs, dX, dX3 = outs[64]
+    assert rel(dW, dYh.T @ X.double()) < 1e-4 and rel(dX, dYh @ W.double()) < 1e-4 and rel(rs, dYh.sum(0)) < 1e-4
+    assert rel(dX3, dY.double() @ W.double()) < 1e-4
+    assert 1e-5 < rel(dW, dY.double().T @ X.double()) < 4e-3 and rel(dX, dY.double() @ W.double()) < 4e-3
+    for knob in (128, 12832):
+        for a, b in zip(outs[64], outs[knob]):
+            assert torch.equal(a, b), f"geometry {knob} differs from the 64 x 64 tile"
+
+
 @pytest.mark.parametrize("knob", [128])
 def test_fp8_tile_geometries(ops, knob):
     """precision 8 on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, every block scale 2^0) at each tile geometry

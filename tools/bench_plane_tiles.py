@@ -25,8 +25,8 @@ def case(name, Mtok, Nout, Kin, split, copies=1, check_ref=False):
         dY, X, W = [torch.randn(*s, generator=g).cuda() for s in ((Mtok, Nout), (Mtok, Kin), (Nout, Kin))]
         dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
         rs = torch.empty(Nout, device="cuda")
-        jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
-        jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+        jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=WPASS)
+        jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=DPASS)
         jobs += [jw, jd]; splits += [split, 1]; outs += [dW, rs, dX]
         if check_ref and c == 0:
             refs = [dY.double().T @ X.double(), dY.double().sum(0), dY.double() @ W.double()]
@@ -81,6 +81,9 @@ def fwd_case(name, Mtok, Nout, Kin, planes=False):
     return same
 
 keep = []
+import os
+WPASS, DPASS = [int(v) for v in os.environ.get("PLANE_PASSES", "3,3").split(",")]   # split-bf16 passes of the wgrad / dgrad jobs
+print(f"passes: wgrad {WPASS}, dgrad {DPASS} (FLOP/s are algorithmic: 2 m n k per product whatever the passes)")
 TILES = (64, 128, 12832)                    # slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages, 128 KiB), 128 x 128 (32-k x 2, 64 KiB)
 DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"

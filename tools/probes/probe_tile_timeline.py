@@ -13,7 +13,7 @@ from slnlp._lib import load, check
 lib = load()
 lib.slnlp_probe_ts.restype = C.c_int
 lib.slnlp_probe_ts.argtypes = [C.c_void_p, C.c_int]
-buf = np.zeros((1 << 16, 6), dtype=np.uint64)
+buf = np.zeros((1 << 16, 8), dtype=np.uint64)   # ring of the last 65536 workgroups; words: probe build, gemm_planes.hip TS_W
 
 def read():
     n = lib.slnlp_probe_ts(buf.ctypes.data, buf.shape[0])
@@ -22,11 +22,26 @@ def read():
 
 def report(name, launch, tile):
     check(lib.slnlp_set_plane_tile(tile), "tile")
+    import time
     for _ in range(3): launch()
-    read()
+    torch.cuda.synchronize()
+    # the clock the chip HOLDS under this kernel: >= 2 s of back-to-back launches on random data first (MI355X guide, DVFS item 6),
+    # then the stamps of the workgroups still in the ring: shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) over the K loop
+    t_end = time.time() + SUSTAIN
+    n_l = 0
+    while time.time() < t_end:
+        for _ in range(20): launch()
+        torch.cuda.synchronize(); n_l += 20
+    hot = read()
+    dt = (hot[:, 2] - hot[:, 1]).astype(np.float64)
+    ok = dt > 50                                             # K loops of at least 0.5 us
+    ghz = (hot[ok, 7] - hot[ok, 6]) / dt[ok] * 0.1
     launch()
     t = read()
     check(lib.slnlp_set_plane_tile(0), "tile")
+    if ok.any():
+        print(f"{name} tile {tile}: held shader clock over the K loop after {SUSTAIN:.0f} s ({n_l} launches): "
+              f"p10/p50/p90 {np.percentile(ghz, 10):.3f} {np.percentile(ghz, 50):.3f} {np.percentile(ghz, 90):.3f} GHz ({ok.sum()} workgroups)")
     t0 = t[:, 0].min()
     us = lambda a: a / 100.0
     fill, loop, meet, epi, tot = [us(t[:, i + 1] - t[:, i]) for i in range(4)] + [us(t[:, 4] - t[:, 0])]
@@ -36,6 +51,7 @@ def report(name, launch, tile):
     print(f"    p10/p50/p90 us: first K-step landed {q(fill)} | K loop {q(loop)} | drain+meeting {q(meet)} | epilogue {q(epi)} | total {q(tot)}")
     print(f"    workgroup start times: p10/p50/p90 {q(start)}; started within 2 us of the first: {(start < 2).sum()}")
 
+SUSTAIN = float(os.environ.get("PROBE_SUSTAIN_S", "2"))
 g = torch.Generator().manual_seed(0)
 def fwd(M, N, K):
     X, W = [torch.randn(*s, generator=g).cuda() for s in ((M, K), (N, K))]
@@ -60,3 +76,4 @@ report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 64)
 report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 12832)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 128)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 12832)
+report("configs[4] in_proj grads 16384x3072x1024 split 6", grads(16384, 3072, 1024, 6), 12832)
