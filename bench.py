@@ -84,20 +84,50 @@ def build_sd(c, seed):
     return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
 
 
-def dominant_kernel_roofline(c, precision, dev, workload):
-    """The step's dominant kernel on its own: one grouped plane-GEMM launch = data gradient + weight gradient of
-    one [B*S, E] dY against a [E, F] weight (FFN / out-proj pair of the encoder backward; 18 of them per cfg2 step
-    plus 6 larger in_proj ones = ~45 % of the step's GPU time).  Timed live with HIP events on the launch stream."""
+PROFILE_ROUND = "r04"           # which round's committed profiles the provenance-labelled fields are read from
+
+
+def backward_passes():
+    """(wgrad, dgrad) split-bf16 passes the plans use for their plane-GEMM gradient products (slnlp_set_backward_passes)."""
+    import ctypes as C
+    from slnlp._lib import load
+    w, d = C.c_int32(3), C.c_int32(3)
+    load().slnlp_get_backward_passes(C.byref(w), C.byref(d))
+    return int(w.value), int(d.value)
+
+
+def in_step_plane_launches(run_eager_steps, steps=12):
+    """Time every plane-GEMM group launch INSIDE train steps: `steps` eager steps with the library's launch timer on (two HIP
+    events around each launch, on the launch stream).  Returns [(workgroups, jobs, geometry, us)]; the first two steps are warm-up."""
+    import ctypes as C
+    from slnlp._lib import load, check, TimedLaunch
+    run_eager_steps(2)
+    torch.cuda.synchronize()
+    check(load().slnlp_launch_timer_start(steps * 128), "launch_timer_start")
+    run_eager_steps(steps)
+    torch.cuda.synchronize()
+    buf = (TimedLaunch * (steps * 128))()
+    n = load().slnlp_launch_timer_stop(buf, steps * 128)
+    return [(int(buf[i].blocks), int(buf[i].njobs), int(buf[i].geometry), float(buf[i].us)) for i in range(max(n, 0))]
+
+
+def dominant_kernel_roofline(c, precision, dev, workload, in_step=None):
+    """The step's dominant kernel: one grouped plane-GEMM launch = data gradient + weight gradient of one [B*S, E] dY against a
+    [E, F] weight (FFN / out-proj pair of the encoder backward; 18 of them per cfg2 step plus 6 larger in_proj ones).
+    `achieved` / `frac` price the launch WHERE IT RUNS: the average of its launches inside train steps (`in_step`: HIP events
+    around each launch on the launch stream, in_step_plane_launches) -- caches as the step leaves them, the neighbours a step
+    gives it.  The same launch back to back (warm L2, no neighbours) is reported beside it as the secondary figure."""
     from slnlp import ops
     M, E, F = c["B"] * c["S"], c["E"], c["F"]
     if E % 64 or F % 64:
         return None
+    wp, dp = backward_passes() if precision == 3 else (precision, precision)
     g = torch.Generator().manual_seed(0)
     dY, X, W = [torch.randn(*sh, generator=g).to(dev) for sh in ((M, E), (M, F), (E, F))]
     dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
     rs = torch.empty(E, device=dev)
-    jw, _ = ops.plane_job(dYp, Xp, M=E, N=F, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=precision)
-    jd, _ = ops.plane_job(dYp, Wp, M=M, N=F, K=E, a_kmajor=True, b_kmajor=False, precision=precision)
+    jw, _ = ops.plane_job(dYp, Xp, M=E, N=F, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=wp)
+    jd, _ = ops.plane_job(dYp, Wp, M=M, N=F, K=E, a_kmajor=True, b_kmajor=False, precision=dp)
     cd = lambda a, b: (a + b - 1) // b
     tw, td, kw, kd = cd(E, 64) * cd(F, 64), cd(M, 64) * cd(F, 64), cd(M, 64), cd(E, 64)
     split = min(range(1, min(8, kw) + 1), key=lambda n: cd(tw * n + td, 512) * max(cd(kw, n) + (n > 1), kd))   # tf_plan.hip wd_group
@@ -111,21 +141,56 @@ def dominant_kernel_roofline(c, precision, dev, workload):
         ops.gemm_group([jw, jd], [split, 1], scr)
     e1.record()
     e1.synchronize()
-    us = e0.elapsed_time(e1) / n * 1e3
-    flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the 3 split-bf16 MFMA passes are not counted)
-    tf = flops / (us * 1e-6) / 1e12
+    us_b2b = e0.elapsed_time(e1) / n * 1e3
+    flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the split-bf16 MFMA passes are not counted)
     blocks = tw * split + td
     # the launch geometry the library picks for this group (csrc/gemm_planes.hip plane_geo_auto): 64 x 64 tiles under 200 tiles of
     # 128 x 128, else 128 x 128 on the 32-k ring (two workgroups per CU) from 300 tiles or K loops >= 1024, else on the 64-k ring
     u128 = cd(E, 128) * cd(F, 128) * split + cd(M, 128) * cd(F, 128)
     geo, wgs = ("64x64", blocks) if u128 < 200 else ("128x128 32-k ring" if (min(M // split, E) >= 1024 or u128 >= 300) else "128x128 64-k ring", u128)
-    return {"kernel": f"gemm_planes_kernel<{precision}, {geo}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {wgs} workgroups",
+    # this launch inside train steps: the timer's records with this workgroup count and two jobs
+    mine = [us for (b, nj, _, us) in (in_step or []) if b == wgs and nj == 2]
+    us_step = sum(mine) / len(mine) if mine else None
+    us = us_step if us_step else us_b2b
+    tf = flops / (us * 1e-6) / 1e12
+    prof = rocprof_kernel_times(workload)
+    traffic, traffic_src = pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}, 0> x{blocks}")
+    return {"kernel": f"gemm_planes_kernel<{precision}, {geo}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {wgs} workgroups, "
+                      f"split-bf16 passes wgrad {wp} / dgrad {dp}",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}, 0> x{blocks}"),
-            "us_per_launch_hip_events": round(us, 2), "us_per_launch_rocprof": rocprof_kernel_times(workload), "flops_per_launch": flops,
+            "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
+            "population": (f"in-step: {len(mine)} launches inside {len(mine) // 18 if len(mine) >= 18 else '?'}+ eager train steps, HIP events around each launch on the launch stream (live)"
+                           if us_step else "back-to-back launches (live; no in-step records)"),
+            "us_per_launch": round(us, 2),
+            "us_per_launch_back_to_back": round(us_b2b, 2), "achieved_back_to_back": round(flops / (us_b2b * 1e-6) / 1e12, 1),
+            "frac_back_to_back": round(flops / (us_b2b * 1e-6) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
+            "us_per_launch_rocprof": prof,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "held_clock_ghz": held_clock(),
+            "mfma_pipe_frac": round((wp + dp) / 2.0 * tf / BF16_DENSE_PEAK_TFLOPS, 4),
+            "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * (M * E + M * F + E * F) + 4.0 * (M * F + E * F) + 4.0 * M * F,
-            "note": "back-to-back launches on one stream (includes launch gaps); flops = 2 GEMMs x 2mnk, the 3 split-bf16 "
-                    "MFMA passes are not counted; bytes = operand planes (hi+lo) read once + fp32 results + result planes"}
+            "note": "flops = 2 GEMMs x 2mnk (algorithmic: the split-bf16 MFMA passes are not counted; mfma_pipe_frac = executed passes x frac, "
+                    "at the 2.4 GHz the 2.5 PF peak assumes -- the chip holds held_clock_ghz under this kernel); bytes = operand planes (hi+lo) read "
+                    "once + fp32 results + result planes; fields with a *_source / source key are read from committed profiles of an earlier run "
+                    "of this command, everything else is measured in this run"}
+
+
+def held_clock():
+    """Shader clock the chip holds under the plane GEMM (probe build: s_memtime / s_memrealtime over the K loop after 2 s of
+    back-to-back launches on random data), from the committed probe output -- not measurable in the product build."""
+    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_plane_gemm_clock.txt")
+    try:
+        vals = {}
+        for line in open(f):
+            if "held shader clock" in line:
+                name = line.split(" tile ")[0].strip()
+                tile = line.split(" tile ")[1].split(":")[0].strip()
+                p50 = float(line.split("p10/p50/p90")[1].split()[1])
+                vals[f"{name} [tile {tile}]"] = p50
+        return {"p50_by_launch": vals, "source": os.path.relpath(f, ROOT)} if vals else None
+    except Exception:
+        return None
 
 
 FP8_DENSE_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: ~5 PF dense fp8, the rate of the block-scaled K=128 MFMA
@@ -138,12 +203,13 @@ def large_launch_roofline(precision, dev):
     What a merged lockstep launch of many fits looks like to the kernel; reported beside the cfg2 launch, never instead of it."""
     from slnlp import ops
     M, Nout, Kin, split = 16384, 3072, 1024, 6
+    wp, dp = backward_passes() if precision == 3 else (precision, precision)
     g = torch.Generator().manual_seed(0)
     dY, X, W = [torch.randn(*sh, generator=g).to(dev) for sh in ((M, Nout), (M, Kin), (Nout, Kin))]
     dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
     rs = torch.empty(Nout, device=dev)
-    jw, _ = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=precision)
-    jd, _ = ops.plane_job(dYp, Wp, M=M, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=precision)
+    jw, _ = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=wp)
+    jd, _ = ops.plane_job(dYp, Wp, M=M, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=dp)
     scr = ops.gemm_group([jw, jd], [split, 1])
     for _ in range(3):
         ops.gemm_group([jw, jd], [split, 1], scr)
@@ -157,12 +223,15 @@ def large_launch_roofline(precision, dev):
     us = e0.elapsed_time(e1) / n * 1e3
     flops = 2.0 * 2 * M * Nout * Kin
     tf = flops / (us * 1e-6) / 1e12
-    return {"kernel": f"gemm_planes_kernel<{precision}, 128x128> dgrad+wgrad group [{M}x{Nout}]x[{Nout}x{Kin}], wgrad split-K {split} (configs[4] in_proj)",
+    traffic, traffic_src = pmc_large_launch_traffic()
+    return {"kernel": f"gemm_planes_kernel<{precision}, 128x128> dgrad+wgrad group [{M}x{Nout}]x[{Nout}x{Kin}], wgrad split-K {split} (configs[4] in_proj), "
+                      f"split-bf16 passes wgrad {wp} / dgrad {dp}",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
-            "traffic": pmc_large_launch_traffic(), "us_per_launch_hip_events": round(us, 1), "flops_per_launch": flops,
+            "population": "back-to-back launches, HIP events (live)",
+            "traffic": traffic, "traffic_source": traffic_src, "us_per_launch_hip_events": round(us, 1), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * (M * Nout + M * Kin + Nout * Kin) + 4.0 * (M * Kin + Nout * Kin) + 4.0 * M * Kin,
-            "mfma_pipe_frac": round(3 * tf / BF16_DENSE_PEAK_TFLOPS, 3),
-            "note": "algorithmic FLOPs (the 3 split-bf16 MFMA passes are not counted: the MFMA pipe itself is busy 3x this fraction)"}
+            "mfma_pipe_frac": round((wp + dp) / 2.0 * tf / BF16_DENSE_PEAK_TFLOPS, 3),
+            "note": "algorithmic FLOPs (the split-bf16 MFMA passes are not counted: the MFMA pipe executes (wgrad + dgrad passes) / 2 times this)"}
 
 
 def fp8_kernel_roofline(c, dev):
@@ -312,39 +381,42 @@ def _fit_local(gs, ds):
 
 def rocprof_kernel_times(workload):
     """The committed rocprofv3 --kernel-trace view of the same kernel (tools/roofline_kernel_stats.py): its back-to-back
-    launches (what the HIP events above time) and its launches inside train steps, or None."""
+    launches and its launches inside train steps, with the file it was read from, or None."""
+    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_bench_{workload}_roofline_kernel.json")
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", f"r03_bench_{workload}_roofline_kernel.json")))
-        return {"back_to_back_avg_us": e["back_to_back"]["avg_us"], "in_step_avg_us": e["in_step"]["avg_us"], "min_us": e["min_us"]}
+        e = json.load(open(f))
+        return {"back_to_back_avg_us": e["back_to_back"]["avg_us"], "in_step_avg_us": e["in_step"]["avg_us"], "min_us": e["min_us"],
+                "source": os.path.relpath(f, ROOT)}
     except Exception:
         return None
 
 
 def pmc_kernel_traffic(workload, shape):
-    """HBM bytes of one launch of `shape` ("kernel xWORKGROUPS") from the same committed PMC passes, or None."""
-    f = os.path.join(ROOT, "profiles", f"r03_pmc_{workload}_step_traffic.json")
+    """(HBM bytes of one launch of `shape` ("kernel xWORKGROUPS") from the committed PMC passes, the file) or (None, None)."""
+    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{workload}_step_traffic.json")
     try:
         e = json.load(open(f))["per_launch"][shape]
-        return float(e["fetch_bytes"] + e["write_bytes"])
+        return float(e["fetch_bytes"] + e["write_bytes"]), os.path.relpath(f, ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def pmc_large_launch_traffic():
-    """HBM bytes of one launch of the configs[4] in_proj gradient group from the committed PMC passes, or None."""
+    """(HBM bytes of one launch of the configs[4] in_proj gradient group from the committed PMC passes, the file) or (None, None)."""
+    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_large_launch_traffic.json")
     try:
-        return float(json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_large_launch_traffic.json")))["hbm_bytes"])
+        return float(json.load(open(f))["hbm_bytes"]), os.path.relpath(f, ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def pmc_traffic(workload):
-    """HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), or None."""
-    f = os.path.join(ROOT, "profiles", f"r03_pmc_{workload}_step_traffic.json")
+    """(HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), the file) or (None, None)."""
+    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{workload}_step_traffic.json")
     try:
-        return float(json.load(open(f))["hbm_bytes_per_step"])
+        return float(json.load(open(f))["hbm_bytes_per_step"]), os.path.relpath(f, ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_parity(c, sd, Xe, ye, Le, logp_gpu):
@@ -519,6 +591,19 @@ def main():
         rank_walls = [float(v) for v in t.cpu()]
         wall = max(rank_walls)
 
+    # outside the timed region: the dominant kernel's launches timed inside eager train steps (rank 0; roofline.population)
+    in_step = None
+    if rank == 0 and "rnn" not in c:
+        def run_eager(k):
+            with torch.cuda.stream(stream):
+                for i in range(k):
+                    j = (i % n_batches) * B
+                    eng.step(Xd[j:j + B], yd[j:j + B], Ld[j:j + B], MOMENTUM, MAX_NORM, graph=False)
+        try:
+            in_step = in_step_plane_launches(run_eager)
+        except Exception as e:                    # the measurement hook must never take the bench line down
+            print(f"[bench] in-step launch timing failed: {e}", file=sys.stderr)
+
     # ---- leg 2: the sharded grid search, every rank takes part (collectives inside)
     chosen = eng._launch.mode((B, float(MOMENTUM), float(MAX_NORM))) if launch == "auto" else None
     grid = None
@@ -564,7 +649,8 @@ def main():
             "ranks": {"world": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
                       "devices_visible": ndev, "rank_wall_s": [round(v, 4) for v in rank_walls]},
             "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5), "traffic": pmc_traffic(args.workload),
+                              "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5),
+                              "traffic": pmc_traffic(args.workload)[0], "traffic_source": pmc_traffic(args.workload)[1],
                               "launch": "one train step (all its kernels)", "flops_per_launch": step_flops,
                               "ms_per_launch_hip_events": round(ms_event, 4)},
             "parity": parity, "final_loss": round(loss_end, 5),
@@ -573,7 +659,7 @@ def main():
             out["grid"] = grid
         if "rnn" not in c:
             with torch.cuda.stream(stream):
-                dk = dominant_kernel_roofline(c, 3 if args.precision == 8 else args.precision, dev, args.workload)
+                dk = dominant_kernel_roofline(c, 3 if args.precision == 8 else args.precision, dev, args.workload, in_step)
                 if args.precision == 8:
                     out["roofline_fp8"] = fp8_kernel_roofline(c, dev)
             if dk:

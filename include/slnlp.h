@@ -402,23 +402,42 @@ int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_byt
  * every other host thread's queued work each time a fit ends. */
 int slnlp_tf_set_destroy_sync(slnlp_tf_plan* plan, int on);
 
-/* One kernel sequence per device.  Kernels of this library on two hardware queues at once (two streams, or two processes on
- * one GPU) have been measured to read each other's producer output stale on MI355X / ROCm 7.2.  The
- * step entry points (slnlp_{tf,rnn}_{forward,backward,optim*,train_step,graph_launch}, slnlp_*_lockstep_{step,epoch})
- * therefore serialise per device: host threads enqueue whole steps in turn, and a step issued on another stream than the
- * device's previous step waits (event) for that stream's tail, so the library's kernels never overlap across streams inside
- * one process.  serialise = 0 switches this off (experiments / probes only); two processes on one GPU stay unsupported. */
+/* One kernel sequence per device (default).  The step entry points (slnlp_{tf,rnn}_{forward,backward,optim*,train_step,
+ * graph_launch}, slnlp_*_lockstep_{step,epoch}) serialise per device: host threads enqueue whole steps in turn, and a step issued
+ * on another stream than the device's previous step waits (event) for that stream's tail, so the library's kernels never overlap
+ * across streams inside one process.  Why: MI355X / ROCm 7.2 compute packed fp32 VALU instructions (v_pk_{add,mul,fma}_f32 with
+ * op_sel) wrongly in lanes 48-63 while another kernel's waves run MFMA on the same CU (reproducer
+ * tools/probes/packed_fp32_repro.hip).  The shipped library is built WITHOUT those instructions (and tests/ disassemble it), so
+ * its kernels are bit-stable on overlapping queues; the ordering is kept as the default because it costs nothing with one
+ * stream and protects a caller of a library rebuilt with other flags.
+ *   slnlp_set_thread_stream_policy(0): the CALLING host thread's steps skip the ordering (1: take part; -1: follow the
+ *     process-wide policy again).  For a thread that owns a stream and wants its steps to overlap other threads' -- the grid
+ *     search's worker threads (slnlp/net.py) -- never process-wide.
+ *   slnlp_set_stream_policy(0): the process-wide switch (probes). */
+int slnlp_set_thread_stream_policy(int serialise);
 int slnlp_set_stream_policy(int serialise);
 
 /* Split-bf16 passes of the gradient products that run on the plane GEMM (the [S*B]-row dgrad / wgrad of every encoder-side
  * Linear; what autograd computes for nn.Linear behind /root/reference/model/transformer.py:40-45,82-87), process-wide,
  * read when a plan issues or records its launches.  3: the full split, A_lo B_hi + A_hi B_lo + A_hi B_hi (fp32-grade
- * products).  2: dY enters with its bf16 head only, A_hi (B_hi + B_lo) -- a third less MFMA work; the rounding of dY
- * (2^-9 relative, fresh every step) enters the gradient, not the forward values.  Default: wgrad 2, dgrad 3 (the weight
- * gradient's error reaches the weights scaled by lr; held to the reference's golden trajectories in tests/).  The forward
- * products always take 3 passes at precision 3.  Env: SLNLP_WGRAD_PASSES / SLNLP_DGRAD_PASSES. */
+ * products).  2: dY enters with its bf16 head only (rounded to nearest: unbiased), A_hi (B_hi + B_lo) -- a third less MFMA work,
+ * a quarter less operand staging, a three-stage ring in the same LDS.  Default since round 4: wgrad 2, dgrad 2.  Measured against
+ * the reference's golden training trajectories (tools/backward_pass_errors.py, profiles/r04_backward_pass_errors.jsonl; cfg2, five
+ * steps): worst per-tensor gradient-norm error 2.3e-3 at (2, 2) against 2.6e-3 at (3, 3), loss 6e-5 against 3e-5 (bar 1e-3),
+ * pre-clip gradient norm 4.3e-3 against 4.2e-3 (bar 5e-3), weights after five steps 2e-7 either way -- the gradient's distance to
+ * the fp32 reference is set by ReLU gates that sit within rounding of zero, not by the 2^-9 rounding of dY.  The forward products
+ * (logits, loss: the 1e-3 / bit-exact-argmax bar) always take 3 passes at precision 3.  Env: SLNLP_WGRAD_PASSES / SLNLP_DGRAD_PASSES. */
 int slnlp_set_backward_passes(int wgrad, int dgrad);
 int slnlp_get_backward_passes(int* wgrad, int* dgrad);
+
+/* Measurement hook (bench.py's roofline): between _start and _stop every plane-GEMM group launch that goes out as a plain launch
+ * (not under graph capture) is bracketed by two HIP events on ITS stream; _stop waits for them and returns up to max_out records --
+ * the launch's workgroup count, job count, tile geometry (0: 64 x 64, 1: 128 x 128 / 64-k, 2: 128 x 128 / 32-k) and the time
+ * between the events in microseconds: the dominant kernel timed inside the train step it belongs to.  Process-wide; not for
+ * production steps (two event records per launch). */
+typedef struct slnlp_timed_launch { int32_t blocks, njobs, geometry; float us; } slnlp_timed_launch;
+int slnlp_launch_timer_start(int max_records);
+int slnlp_launch_timer_stop(slnlp_timed_launch* out, int max_out);
 
 /* ---------------------------------------------------------------- lockstep --
  * K Transformer fits of ONE shape (own weights, lr, dropout rate, seed and data) advancing through one launch

@@ -148,12 +148,16 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
 }
+// x = hi + lo, hi = bf16(x) ROUNDED TO NEAREST (v_cvt_pk_bf16_f32; a NaN stays a NaN), lo = bf16(x - hi): |lo| <= 2^-9 |x|, and the head
+// alone is an unbiased bf16 image of x -- what the two-pass gradient products (gemm_planes.hip, precision 2) contract with.
+// (Rounds 1-3 truncated: hi = the top 16 bits, |lo| <= 2^-8 |x|, and a head that is 0.2 % short on average.)
 __device__ __forceinline__ void split_bf16(float x, unsigned short& h, unsigned short& l) {
-    const unsigned u = __float_as_uint(x);
-    h = (unsigned short)(u >> 16);
-    __bf16 b = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
+    const __bf16 hb = (__bf16)x;
+    h = __builtin_bit_cast(unsigned short, hb);
+    const __bf16 b = (__bf16)(x - (float)hb);
     l = __builtin_bit_cast(unsigned short, b);
 }
+__device__ __forceinline__ unsigned short head_bf16(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ void store_planes1(const PlaneOut& po, long idx, float v) {
     if (!po.hi) return;
     unsigned short h, l;
@@ -175,12 +179,11 @@ __device__ __forceinline__ void store_planes4(const PlaneOut& po, long idx, floa
 }
 
 // ------------------------------------------------------------- wave ops -----
-// Cross-lane reductions WITHOUT the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 on gfx950 -- an LDS-unit
-// instruction -- and round 3's probes (tools/probes/probe_victim.py) found the one kind of kernel whose
-// result changed when kernels of another hardware queue ran on the same CUs to be the ones reducing through it (layernorm_bwd on
-// CONSTANT inputs: 85 % of the runs differ beside two other fits, 4-lane and whole-row patterns that only a wrong shuffle
-// result explains; the GEMMs beside it, which reduce nothing across lanes, never differ).  These use DPP row operations inside a
-// row of 16 lanes and v_readlane across the four rows: VALU only.
+// Cross-lane reductions WITHOUT the LDS crossbar: DPP row operations inside a row of 16 lanes and v_readlane across the four
+// rows -- VALU only (`__shfl_xor` compiles to ds_bpermute_b32 on gfx950, an LDS-unit instruction).  History: round 3 suspected
+// ds_bpermute of the multi-queue nondeterminism and moved every reduction here; that changed nothing -- the cause turned out to
+// be packed fp32 VALU instructions (the library is built without them, Makefile).  The DPP forms stay
+// because they are no slower and keep reductions off the LDS pipe the GEMM tiles load; they are not a required mitigation.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {      // every lane has a valid source for the controls used here
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));

@@ -2,6 +2,7 @@
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "launch.hpp"
 
@@ -35,9 +36,11 @@ struct DevSeq {
 };
 static DevSeq g_seq[MAX_DEV];
 static thread_local int tl_scope_depth = 0;
+static thread_local int tl_stream_policy = -1;     // -1: the process-wide policy; 0 / 1: this host thread's own (slnlp_set_thread_stream_policy)
 
 StepScope::StepScope(hipStream_t st) : st_(st) {
-    if (tl_scope_depth++ > 0 || !g_stream_policy.load(std::memory_order_relaxed) || recording()) return;
+    const int policy = tl_stream_policy >= 0 ? tl_stream_policy : g_stream_policy.load(std::memory_order_relaxed);
+    if (tl_scope_depth++ > 0 || !policy || recording()) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
     dev_ = dev;
@@ -107,6 +110,69 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
 
 }  // namespace slnlp
 
+// ---- launch timer (launch.hpp)
+namespace slnlp {
+struct TimedLaunch { hipEvent_t e0 = nullptr, e1 = nullptr; int blocks = 0, njobs = 0, geo = 0; bool done = false; };
+static std::mutex g_timer_mu;
+static std::vector<TimedLaunch> g_timer_recs;
+static std::atomic<int> g_timer_on{0};
+static int g_timer_max = 0;
+
+int launch_timer_begin(hipStream_t st) {
+    if (!g_timer_on.load(std::memory_order_relaxed)) return -1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (cap != hipStreamCaptureStatusNone) return -1;
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if ((int)g_timer_recs.size() >= g_timer_max) return -1;
+    TimedLaunch t;
+    if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess || hipEventRecord(t.e0, st) != hipSuccess) {
+        (void)hipGetLastError();
+        if (t.e0) (void)hipEventDestroy(t.e0);
+        if (t.e1) (void)hipEventDestroy(t.e1);
+        return -1;
+    }
+    g_timer_recs.push_back(t);
+    return (int)g_timer_recs.size() - 1;
+}
+void launch_timer_end(int rec, hipStream_t st, int blocks, int njobs, int geo) {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if (rec < 0 || rec >= (int)g_timer_recs.size()) return;
+    TimedLaunch& t = g_timer_recs[rec];
+    t.blocks = blocks; t.njobs = njobs; t.geo = geo;
+    t.done = hipEventRecord(t.e1, st) == hipSuccess;
+}
+}  // namespace slnlp
+
+extern "C" int slnlp_launch_timer_start(int max_records) {
+    std::lock_guard<std::mutex> lk(slnlp::g_timer_mu);
+    if (!slnlp::g_timer_recs.empty() || max_records < 1) {
+        slnlp::set_error("launch_timer_start: %s", max_records < 1 ? "max_records < 1" : "a previous run was not read (slnlp_launch_timer_stop)");
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    slnlp::g_timer_max = max_records;
+    slnlp::g_timer_recs.reserve(max_records);
+    slnlp::g_timer_on.store(1, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int slnlp_launch_timer_stop(slnlp_timed_launch* out, int max_out) {
+    slnlp::g_timer_on.store(0, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lk(slnlp::g_timer_mu);
+    int n = 0;
+    for (auto& t : slnlp::g_timer_recs) {
+        float ms = -1.f;
+        if (t.done && hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) { (void)hipGetLastError(); ms = -1.f; }
+        if (out && n < max_out && ms >= 0.f) {
+            out[n].blocks = t.blocks; out[n].njobs = t.njobs; out[n].geometry = t.geo; out[n].us = ms * 1e3f;
+            ++n;
+        }
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    slnlp::g_timer_recs.clear();
+    return n;
+}
+
 // ---- how many split-bf16 passes the gradient products of the plane GEMM take (slnlp.h: slnlp_set_backward_passes)
 namespace slnlp {
 static int env_passes(const char* name, int dflt) {
@@ -115,7 +181,7 @@ static int env_passes(const char* name, int dflt) {
     return v == 2 || v == 3 ? v : dflt;
 }
 static std::atomic<int> g_wgrad_passes{env_passes("SLNLP_WGRAD_PASSES", 2)};
-static std::atomic<int> g_dgrad_passes{env_passes("SLNLP_DGRAD_PASSES", 3)};
+static std::atomic<int> g_dgrad_passes{env_passes("SLNLP_DGRAD_PASSES", 2)};
 int wgrad_passes() { return g_wgrad_passes.load(std::memory_order_relaxed); }
 int dgrad_passes() { return g_dgrad_passes.load(std::memory_order_relaxed); }
 }  // namespace slnlp
@@ -132,6 +198,11 @@ extern "C" int slnlp_set_backward_passes(int wgrad, int dgrad) {
 extern "C" int slnlp_get_backward_passes(int* wgrad, int* dgrad) {
     if (wgrad) *wgrad = slnlp::wgrad_passes();
     if (dgrad) *dgrad = slnlp::dgrad_passes();
+    return 0;
+}
+
+extern "C" int slnlp_set_thread_stream_policy(int serialise) {
+    slnlp::tl_stream_policy = serialise < 0 ? -1 : (serialise ? 1 : 0);
     return 0;
 }
 

@@ -158,14 +158,20 @@ int zlaunch(void (*kern)(P, const P*), dim3 grid, int threads, size_t lds, hipSt
 // goes away.
 void destroy_sync(int plan_wants_sync);
 
-// ONE kernel sequence per device.  Measured on MI355X / ROCm 7.2 (tools/probes/): kernels of this library
-// running on two hardware queues at once can read each other's ... producer output stale.  Until that is root-caused the
-// library itself keeps its kernels from overlapping across streams: every top-level step entry point opens a StepScope, which
+// ONE kernel sequence per device, by default.  Round 2 measured that fits on two hardware queues changed each other's results;
+// round 3 found the cause (tools/probes/PACKED_FP32_REPORT.md): packed fp32 VALU instructions with an op_sel
+// half-select compute wrongly in lanes 48-63 while a workgroup of ANOTHER kernel runs MFMA on the same CU -- a property of
+// generated code, not of these sources; this library is built without them (Makefile, checked by disassembly in tests/).  The
+// ordering stays as the library's default because it is free with one stream and gives a C-API caller that brings several
+// streams solo bits even from a library someone rebuilt with other flags: every top-level step entry point opens a StepScope, which
 //   * holds a per-device mutex while the step's launches are enqueued (host threads take turns, whole steps at a time),
 //   * when the previous step of this device was enqueued on ANOTHER stream, records an event at that stream's tail and makes
 //     this step's stream wait for it (the common case -- one shared stream -- costs a mutex and nothing on the GPU).
 // Scopes nest (slnlp_tf_train_step -> slnlp_tf_forward ...): only the outermost acts.  Skipped while a launch recorder is
-// installed (nothing is launched) and on a capturing stream.  slnlp_set_stream_policy(0) switches it off for experiments.
+// installed (nothing is launched) and on a capturing stream.  Opting out is scoped to the HOST THREAD that owns a stream of its
+// own (slnlp_set_thread_stream_policy(0): the grid search's worker threads); slnlp_set_stream_policy(0) is the process-wide
+// switch (probes).  Still required whatever the policy: nothing -- DPP reductions instead of ds_bpermute and the StepScope itself
+// are defensive; the build without packed fp32 is what the results depend on.
 struct StepScope {
     explicit StepScope(hipStream_t st);
     ~StepScope();
@@ -183,6 +189,12 @@ struct LsAdam { float beta1, beta2, eps, weight_decay; };
 
 // zero `bytes` (a multiple of 16, 16-B aligned) with a kernel of ours: recordable, unlike hipMemsetAsync
 int fill_zero(void* p, size_t bytes, hipStream_t st);
+
+// Launch timer (slnlp_launch_timer_start / _stop): while it runs, every plane-GEMM group launch issued as a plain launch (not
+// recorded, not under graph capture) is bracketed by two HIP events on its stream, so bench.py can time the dominant kernel
+// where it lives -- between the other kernels of a train step, caches as the step leaves them -- not only back to back.
+int launch_timer_begin(hipStream_t st);            // -> record index, or -1 when the timer is off / full / the stream is capturing
+void launch_timer_end(int rec, hipStream_t st, int blocks, int njobs, int geo);
 
 // split-bf16 passes of the plane GEMM's gradient products (2: the dY operand enters with its bf16 head only; 3: full split) --
 // process-wide, read when a plan builds (or records) its launches: slnlp_set_backward_passes, launch.hip

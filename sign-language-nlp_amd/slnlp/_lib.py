@@ -32,6 +32,10 @@ class GemmArgs(C.Structure):
                 ("batch", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64)]
 
 
+class TimedLaunch(C.Structure):
+    _fields_ = [("blocks", i32), ("njobs", i32), ("geometry", i32), ("us", f32)]
+
+
 class TfConfig(C.Structure):
     _fields_ = [("E", i32), ("H", i32), ("N", i32), ("F", i32), ("Vs", i32), ("Vt", i32),
                 ("B", i32), ("S", i32), ("pad_src", i32), ("pad_tgt", i32),
@@ -147,8 +151,11 @@ SIGNATURES = {
     "slnlp_tf_debug_layout": (i32, [vp, C.c_char_p, i64]),
     "slnlp_tf_set_destroy_sync": (i32, [vp, i32]),
     "slnlp_set_stream_policy": (i32, [i32]),
+    "slnlp_set_thread_stream_policy": (i32, [i32]),
     "slnlp_set_backward_passes": (i32, [i32, i32]),
     "slnlp_get_backward_passes": (i32, [C.POINTER(i32), C.POINTER(i32)]),
+    "slnlp_launch_timer_start": (i32, [i32]),
+    "slnlp_launch_timer_stop": (i32, [C.POINTER(TimedLaunch), i32]),
     "slnlp_set_plane_tile": (i32, [i32]),
     "slnlp_set_fp8_tile": (i32, [i32]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),

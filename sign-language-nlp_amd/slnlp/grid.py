@@ -525,6 +525,14 @@ class ShardedGridSearchCV:
                           f"({float(rows[t, 1]):.2f}s)", flush=True)
 
         def worker():
+            try:
+                worker_loop()
+            finally:
+                if is_cuda and self.fits_per_gpu > 1:       # a host thread that ends gives its stream back (slnlp.net)
+                    from .net import release_thread_streams
+                    release_thread_streams()
+
+        def worker_loop():
             while True:
                 i = counter.acquire()
                 if i is None:

@@ -141,6 +141,14 @@ def fit_lockstep(nets, datasets):
     """``net.partial_fit(ds)`` for every (net, ds) pair, all fits advancing together.  The nets must be initialised,
     of one shape (lr and dropout rate may differ) and their datasets of one size; fits that stop early (EarlyStopping)
     leave the group, the others go on."""
+    nets[0]._gate.enter(False)                          # fused fits share the device (slnlp.net: _DeviceGate)
+    try:
+        return _fit_lockstep_gated(nets, datasets)
+    finally:
+        nets[0]._gate.leave(False)
+
+
+def _fit_lockstep_gated(nets, datasets):
     from .net import _FitRun, stream_sync
     K = len(nets)
     stream = nets[0]._stream
@@ -202,6 +210,14 @@ def predict_proba_lockstep(nets, datasets):
     skorch's predict_nonlinearity='auto' does)."""
     from .net import stream_sync
     bs = int(nets[0].batch_size)
+    nets[0]._gate.enter(False)
+    try:
+        return _predict_proba_lockstep_gated(nets, datasets, bs, stream_sync)
+    finally:
+        nets[0]._gate.leave(False)
+
+
+def _predict_proba_lockstep_gated(nets, datasets, bs, stream_sync):
     nets[0]._enter_stream()
     with torch.cuda.stream(nets[0]._stream):
         dev = [n._device_data(d) for n, d in zip(nets, datasets)]
@@ -212,9 +228,11 @@ def predict_proba_lockstep(nets, datasets):
         group = LockstepGroup(engines)
         group.set_data(TEST, [d[0] for d in dev], [d[2] for d in dev], bs, [d[1] for d in dev])
         group.epoch(TEST, bs, False)
-        out = [torch.softmax(lp, dim=-1) if n.predict_nonlinearity == "auto" else lp for n, lp in zip(nets, group.logp[TEST])]
+        out = [lp.clone() for lp in group.logp[TEST]]
         stream_sync(nets[0]._stream)
-        out = [o.cpu().numpy() for o in out]
+        # softmax on the host copies (torch's CPU op, as in NeuralNetClassifier.predict_proba: no torch arithmetic kernel runs
+        # beside other fits on the GPU)
+        out = [(torch.softmax(o.cpu(), dim=-1) if n.predict_nonlinearity == "auto" else o.cpu()).numpy() for n, o in zip(nets, out)]
         group.close()
     return out
 

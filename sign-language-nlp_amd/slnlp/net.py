@@ -35,17 +35,81 @@ from .data import TokenDataset
 # module construction consumes torch's global CPU generator (initial weights): concurrent fits take turns
 INIT_LOCK = threading.RLock()
 
-# Which stream a fit runs on.  "thread" (default): one stream per host thread and device -- the grid search's `fits_per_gpu` host
-# threads feed separate hardware queues, so one unit's small launches (the decoder's [B, E] chain, the optimizer) run beside
-# another's; measured +17 % folds/hr on bench.py's grid sample, scores bit-identical (bench.py prints their CRC-32).
-# "device": one stream per device for every estimator of the process (rounds 2's rule, SLNLP_STREAM_MODE=device).
+# Which stream a fit runs on.  "thread" (default): one stream per host thread and device for FUSED fits -- fits whose every
+# kernel is this library's (fused SGD / Adam step, slnlp.lockstep): the grid search's `fits_per_gpu` host threads feed separate
+# hardware queues, so one unit's small launches (the decoder's [B, E] chain, the optimizer) run beside another's; measured +17 %
+# folds/hr on bench.py's grid sample, scores bit-identical (bench.py prints their CRC-32).  "device": one stream per device for
+# every estimator of the process (round 2's rule, SLNLP_STREAM_MODE=device).
 # History: round 2 measured that fits on several queues changed each other's results and shipped the
 # one-stream rule.  Round 3 found the cause -- packed fp32 VALU instructions compute wrongly when a workgroup of another kernel
-# shares the CU -- and builds the library without them; every probe (three processes, three streams, the grid's scores across
-# stream modes, tests/test_streams_gpu.py) has been bit-identical since.
+# shares the CU -- and builds the library without them.  torch's own kernels (and rocBLAS) ARE built with packed fp32, so
+# whatever runs them never shares the GPU with another fit here:
+#   * a fit that steps through torch (another optimizer / criterion: `_fused` False) runs on the shared device stream and holds
+#     the device EXCLUSIVELY for its fit / predict calls (`_DeviceGate`: fused fits of other threads hold it shared);
+#   * the scoring softmax of `predict_proba` runs on the host copy of the log-probs (torch's CPU op, what the reference runs);
+#   * what is left on the GPU from torch beside other fits moves or compares bits (copies, cat, argmax, gather): no fp32 arithmetic.
+# The library-wide stream policy is never flipped from here: a thread that gets a stream of its own opts ITS steps out
+# (slnlp_set_thread_stream_policy).
 STREAM_MODE = os.environ.get("SLNLP_STREAM_MODE", "thread")      # "thread" | "device"
 _DEVICE_STREAMS = {}
 _DEVICE_STREAMS_LOCK = threading.Lock()
+
+
+class _DeviceGate:
+    """Readers-writer gate per device: fused fits enter shared, fits that run torch kernels enter exclusive (writer
+    preference, re-entrant per thread for nested fit -> predict calls)."""
+    def __init__(self):
+        self._cv = threading.Condition()
+        self._shared, self._excl_owner, self._excl_depth, self._excl_waiting = 0, None, 0, 0
+        self._tl = threading.local()
+
+    def enter(self, exclusive):
+        me = threading.get_ident()
+        with self._cv:
+            if self._excl_owner == me:                       # nested call of the exclusive holder
+                self._excl_depth += 1
+                return
+            depth = getattr(self._tl, "shared", 0)
+            if not exclusive and depth:                      # nested shared call
+                self._tl.shared = depth + 1
+                return
+            if exclusive:
+                self._excl_waiting += 1
+                while self._excl_owner is not None or self._shared:
+                    self._cv.wait()
+                self._excl_waiting -= 1
+                self._excl_owner, self._excl_depth = me, 1
+            else:
+                while self._excl_owner is not None or self._excl_waiting:
+                    self._cv.wait()
+                self._shared += 1
+                self._tl.shared = 1
+
+    def leave(self, exclusive):
+        with self._cv:
+            if self._excl_owner == threading.get_ident():
+                self._excl_depth -= 1
+                if self._excl_depth == 0:
+                    self._excl_owner = None
+                    self._cv.notify_all()
+                return
+            self._tl.shared -= 1
+            if self._tl.shared == 0:
+                self._shared -= 1
+                self._cv.notify_all()
+
+
+_GATES = {}
+
+
+def device_gate(dev):
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _DEVICE_STREAMS_LOCK:
+        g = _GATES.get(idx)
+        if g is None:
+            g = _GATES[idx] = _DeviceGate()
+        return g
 
 
 def stream_sync(stream):
@@ -56,16 +120,35 @@ def stream_sync(stream):
     ev.synchronize()
 
 
-def device_stream(dev):
+def device_stream(dev, per_thread=None):
+    """The stream a fit on `dev` runs on: this host thread's own (`per_thread`, default: STREAM_MODE == "thread") or the one
+    every estimator of the process shares on that device.  A thread that gets a stream of its own also opts its library steps
+    out of the one-sequence-per-device ordering (thread-scoped: slnlp_set_thread_stream_policy)."""
     dev = torch.device(dev)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    key = (dev.index, threading.get_ident()) if STREAM_MODE == "thread" else dev.index
+    if per_thread is None:
+        per_thread = STREAM_MODE == "thread"
+    key = (dev.index, threading.get_ident()) if per_thread else dev.index
     with _DEVICE_STREAMS_LOCK:
         st = _DEVICE_STREAMS.get(key)
         if st is None:
             st = _DEVICE_STREAMS[key] = torch.cuda.Stream(device=dev)
-        return st
+    if per_thread:
+        from . import _lib
+        _lib.load().slnlp_set_thread_stream_policy(0)
+    return st
+
+
+def release_thread_streams():
+    """Drop the calling thread's per-thread streams (a grid worker thread about to exit) and put its library steps back under
+    the process-wide stream policy."""
+    me = threading.get_ident()
+    with _DEVICE_STREAMS_LOCK:
+        for key in [k for k in _DEVICE_STREAMS if isinstance(k, tuple) and k[1] == me]:
+            del _DEVICE_STREAMS[key]
+    from . import _lib
+    _lib.load().slnlp_set_thread_stream_policy(-1)
 
 
 _RESOLVED = {}
@@ -331,18 +414,11 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
             raise RuntimeError("slnlp.net: device %r -- the HIP path is the only compute path (no CPU fallback)" % (self.device,))
         kw = self._sub("module")
         kw.setdefault("device", dev)
-        self._stream = device_stream(dev)
-        if STREAM_MODE == "thread":
-            # the library's own default orders the step entry points of different streams (for C-API callers that bring their
-            # own streams); the host threads of a grid search are meant to overlap
-            from . import _lib
-            _lib.load().slnlp_set_stream_policy(0)
-        with torch.cuda.stream(self._stream):            # the weight draw / upload too: nothing of a fit runs on another queue
-            self.module_ = _resolve(self.module)(**kw).to(dev)
         self.criterion_ = _resolve(self.criterion)(**self._sub("criterion"))
         self._opt_cls = _resolve(self.optimizer)
         ok = self._opt_kwargs = self._sub("optimizer")
-        ce = isinstance(self.criterion_, torch.nn.CrossEntropyLoss) and hasattr(self.module_, "engine")
+        mod_cls = _resolve(self.module)
+        ce = isinstance(self.criterion_, torch.nn.CrossEntropyLoss) and hasattr(mod_cls, "engine")
         self._fused_kind = None                   # which fused clip + update kernel replaces the torch optimizer
         if ce and self._opt_cls is torch.optim.SGD and not ok.get("nesterov", False) and not ok.get("weight_decay", 0) \
                 and not ok.get("dampening", 0) and not ok.get("maximize", False):
@@ -350,6 +426,12 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         elif ce and self._opt_cls is torch.optim.Adam and not ok.get("amsgrad", False) and not ok.get("maximize", False):
             self._fused_kind = "adam"
         self._fused = self._fused_kind is not None
+        # a fused fit may take this host thread's own stream; one that steps through torch kernels stays on the device's shared
+        # stream and holds the device exclusively while it runs (see STREAM_MODE above)
+        self._stream = device_stream(dev, per_thread=(STREAM_MODE == "thread" and self._fused))
+        self._gate = device_gate(dev)
+        with torch.cuda.stream(self._stream):            # the weight draw / upload too: nothing of a fit runs on another queue
+            self.module_ = mod_cls(**kw).to(dev)
         if not self._fused:
             self.optimizer_ = self._opt_cls(self.module_.parameters(), lr=self.lr, **ok)
         self.lr_ = float(self.lr)
@@ -385,6 +467,13 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
     def partial_fit(self, X, y=None, **fit_params):
         if not self.initialized_:
             self.initialize()
+        self._gate.enter(not self._fused)
+        try:
+            return self._partial_fit_gated(X, y)
+        finally:
+            self._gate.leave(not self._fused)
+
+    def _partial_fit_gated(self, X, y):
         self._enter_stream()
         with torch.cuda.stream(self._stream):
             run = _FitRun(self, self._as_dataset(X, y))
@@ -468,15 +557,21 @@ class NeuralNetClassifier(ClassifierMixin, BaseEstimator):
         ds = self._as_dataset(X)
         self.module_.eval()
         outs = []
-        self._enter_stream()
-        with torch.cuda.stream(self._stream), torch.no_grad():
-            Xd, Ld, yd = self._device_data(ds)
-            for i in range(0, len(ds), int(self.batch_size)):
-                lp = self.module_(X=Xd[i:i + self.batch_size], y=yd[i:i + self.batch_size], lengths=Ld[i:i + self.batch_size])
-                outs.append(torch.softmax(lp, dim=-1) if self.predict_nonlinearity == "auto" else lp)
-            out = torch.cat(outs)
-        stream_sync(self._stream)
-        return out.cpu().numpy()
+        self._gate.enter(not self._fused)
+        try:
+            self._enter_stream()
+            with torch.cuda.stream(self._stream), torch.no_grad():
+                Xd, Ld, yd = self._device_data(ds)
+                for i in range(0, len(ds), int(self.batch_size)):
+                    outs.append(self.module_(X=Xd[i:i + self.batch_size], y=yd[i:i + self.batch_size], lengths=Ld[i:i + self.batch_size]))
+                out = torch.cat(outs)
+            stream_sync(self._stream)
+        finally:
+            self._gate.leave(not self._fused)
+        out = out.cpu()
+        # the nonlinearity on the host copy (torch's CPU softmax -- the op the reference's CPU path runs): torch's GPU kernels
+        # are built with packed fp32 and must not run beside other fits' kernels (STREAM_MODE above); [N, V] is tiny
+        return (torch.softmax(out, dim=-1) if self.predict_nonlinearity == "auto" else out).numpy()
 
     def predict(self, X):
         return self.classes_[self.predict_proba(X).argmax(-1)]

@@ -266,22 +266,14 @@ def test_the_built_library_contains_no_packed_fp32_instructions():
     of a wave when a workgroup of another kernel shares the CU (MI355X / ROCm 7.2; DESIGN.md section 6: two independent victim
     kernels, each flipped from nondeterministic to bit-stable by compiling without them).  The Makefile builds with
     -target-feature -packed-fp32-ops; this disassembles every code object of the built library and holds it to that."""
-    import importlib.util, re, subprocess, tempfile
+    import importlib.util
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(ROOT, "sign-language-nlp_amd", "lib", "libslnlp.so")
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(lib) or not os.path.exists(objdump):
+    spec = importlib.util.spec_from_file_location("check_no_packed_fp32", os.path.join(ROOT, "tools", "check_no_packed_fp32.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not os.path.exists(lib) or not os.path.exists(chk.OBJDUMP):
         pytest.skip("library or llvm-objdump not present")
-    spec = importlib.util.spec_from_file_location("kernel_registers", os.path.join(ROOT, "tools", "kernel_registers.py"))
-    kr = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(kr)
-    lines, hits = 0, []
-    for _, elf in kr.code_objects(open(lib, "rb").read()):
-        with tempfile.NamedTemporaryFile(suffix=".co") as f:
-            f.write(elf)
-            f.flush()
-            out = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
-        lines += out.count("\n")
-        hits += re.findall(r"v_pk_(?:add|mul|fma)_f32", out)      # (v_pk_mov_b32, a move, stays: the builds that pass the probes have it)
+    lines, hits = chk.packed_fp32_hits(lib)          # (the Makefile runs the same check after linking)
     assert lines > 100000, "disassembly looks empty"
     assert not hits, f"{len(hits)} packed fp32 instructions in the built library (first: {hits[0]})"

@@ -501,7 +501,7 @@ def test_two_pass_gradient_products_equal_the_product_with_the_bf16_head_of_dY(o
     from slnlp._lib import load, check
     Mtok, Nout, Kin = 2400, 192, 320
     dY, X, W = rnd(Mtok, Nout, seed=1), rnd(Mtok, Kin, seed=2), rnd(Nout, Kin, seed=3)
-    dYh = (dY.view(torch.int32) & -65536).view(torch.float32).double()       # the hi plane is the fp32 value's top 16 bits
+    dYh = dY.bfloat16().double()                                               # the hi plane: bf16 rounded to nearest
     dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
     def run():
         rs = torch.empty(Nout, device="cuda")
@@ -521,7 +521,7 @@ def test_two_pass_gradient_products_equal_the_product_with_the_bf16_head_of_dY(o
     dW, rs, dX, dX3 = outs[64]
     assert rel(dW, dYh.T @ X.double()) < 1e-4 and rel(dX, dYh @ W.double()) < 1e-4 and rel(rs, dYh.sum(0)) < 1e-4
     assert rel(dX3, dY.double() @ W.double()) < 1e-4
-    assert 1e-5 < rel(dW, dY.double().T @ X.double()) < 4e-3 and rel(dX, dY.double() @ W.double()) < 4e-3
+    assert 1e-5 < rel(dW, dY.double().T @ X.double()) < 2e-3 and rel(dX, dY.double() @ W.double()) < 2e-3
     for knob in (128, 12832):
         for a, b in zip(outs[64], outs[knob]):
             assert torch.equal(a, b), f"geometry {knob} differs from the 64 x 64 tile"

@@ -173,3 +173,67 @@ def test_rnn_grid_scores_do_not_depend_on_the_stream_mode(monkeypatch, module):
         scores.setdefault(mode, []).append(np.asarray(gs.cv_results_["mean_test_score"], dtype=np.float64).tobytes())
     load().slnlp_set_stream_policy(1)
     assert scores["device"][0] == scores["thread"][0] == scores["thread"][1]
+
+
+def test_a_fit_that_steps_through_torch_kernels_never_shares_the_gpu(monkeypatch):
+    """torch's own kernels are built WITH packed fp32, so a fit whose step goes through them (another
+    optimizer: criterion / clip_grad_norm_ / optimizer.step on the GPU) must not run beside other fits' MFMA kernels.  slnlp.net
+    gives it the device's shared stream and the device exclusively (_DeviceGate): next to two host threads running fused fits
+    on streams of their own it gets the bits of the same fit running alone, and the gate never had a fused fit inside while
+    it ran.  The library-wide stream policy is not touched by any of this (thread-scoped opt-out only)."""
+    from slnlp import net
+    from slnlp.data import synthetic_dataset
+    from slnlp.net import NeuralNetClassifier
+    monkeypatch.setattr(net, "STREAM_MODE", "thread")
+    ds = synthetic_dataset(300, seq_len=48, src_vocab=3000, n_labels=50, seed=5, min_len=8)
+
+    def make(opt, **kw):
+        return NeuralNetClassifier(
+            module="model.Transformer", module__dropout=0.1, module__src_vocab=ds.vocab_X, module__tgt_vocab=ds.vocab_y,
+            module__batch_first=True, module__embedding_size=256, module__num_heads=4, module__num_layers=2, module__hidden_size=256,
+            criterion="torch.nn.CrossEntropyLoss", criterion__ignore_index=1, optimizer=opt, lr=0.02, max_epochs=2, batch_size=50,
+            device="cuda:0", gradient_clipping={"gradient_clip_value": 0.5}, scoring=["neg_log_loss"], use_graph=False, **kw)
+
+    def fit_torch_stepper():
+        with net.INIT_LOCK:
+            torch.manual_seed(3)
+            n = make("torch.optim.Adagrad").initialize()
+        assert not n._fused and n._stream is net.device_stream("cuda:0", per_thread=False)
+        n.partial_fit(ds)
+        return torch.cat([p.detach().flatten() for p in n.module_.parameters()]).clone(), n.predict_proba(ds)
+
+    ref_w, ref_p = fit_torch_stepper()
+    gate = net.device_gate("cuda:0")
+    overlaps, stop = [], threading.Event()
+    orig_enter = gate.enter
+
+    def spy_enter(exclusive):
+        orig_enter(exclusive)
+        if exclusive and gate._shared:
+            overlaps.append(gate._shared)
+    monkeypatch.setattr(gate, "enter", spy_enter)
+
+    def fused_worker(seed):
+        try:
+            while not stop.is_set():
+                with net.INIT_LOCK:
+                    torch.manual_seed(seed)
+                    n = make("torch.optim.SGD", optimizer__momentum=0.9).initialize()
+                assert n._fused and n._stream is not net.device_stream("cuda:0", per_thread=False)
+                n.partial_fit(ds)
+        finally:
+            net.release_thread_streams()
+
+    ths = [threading.Thread(target=fused_worker, args=(7 + i,)) for i in range(2)]
+    [t.start() for t in ths]
+    try:
+        for _ in range(2):
+            w, p = fit_torch_stepper()
+            assert torch.equal(w, ref_w), "a torch-stepped fit beside fused fits differs from the same fit alone"
+            assert (p == ref_p).all()
+    finally:
+        stop.set()
+        [t.join() for t in ths]
+    assert not overlaps
+    import ctypes as C
+    assert load().slnlp_set_thread_stream_policy(-1) == 0       # (this thread: back to the process-wide default)

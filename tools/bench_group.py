@@ -2,14 +2,18 @@
 import sys, torch
 sys.path.insert(0, "sign-language-nlp_amd")
 from slnlp import ops
+from slnlp._lib import load
 Mtok, Nout = 2400, int(sys.argv[1]) if len(sys.argv) > 1 else 512
 Kin = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 g = torch.Generator().manual_seed(0)
 dY, X, W = [torch.randn(*s, generator=g) for s in ((Mtok, Nout), (Mtok, Kin), (Nout, Kin))]
 dYp, Xp, Wp = ops.split_planes(dY.cuda()), ops.split_planes(X.cuda()), ops.split_planes(W.cuda())
 rs = torch.empty(Nout, device="cuda")
-jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
-jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+import ctypes as _C
+_w, _d = _C.c_int32(3), _C.c_int32(3)
+load().slnlp_get_backward_passes(_C.byref(_w), _C.byref(_d))   # the passes the plans use (default 2, 2)
+jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=_w.value)
+jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=_d.value)
 scr = ops.gemm_group([jw, jd], [8, 1])
 def timeit(fn, n=200):
     for _ in range(20): fn()

@@ -10,8 +10,11 @@ g = torch.Generator().manual_seed(0)
 dY, X, W = [torch.randn(*s, generator=g).cuda() for s in ((Mtok, Nout), (Mtok, Kin), (Nout, Kin))]
 dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
 rs = torch.empty(Nout, device="cuda")
-jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs)
-jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False)
+import ctypes as _C
+_w, _d = _C.c_int32(3), _C.c_int32(3)
+load().slnlp_get_backward_passes(_C.byref(_w), _C.byref(_d))   # the passes the plans use (default 2, 2)
+jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=_w.value)
+jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=_d.value)
 check(load().slnlp_set_plane_tile(tile), "set_plane_tile")
 scr = ops.gemm_group([jw, jd], [split, 1])
 torch.cuda.synchronize()

@@ -6,6 +6,7 @@
 #   tiles_big    plane-GEMM geometries on the large gradient groups (tools/bench_plane_tiles.py big)
 #   tiles_fwd    ... on the forward launches
 #   tiles_quick  ... on the cfg2 launches + bit-identity of the geometries
+#   planes       the plane-GEMM tests of tests/test_kernels_gpu.py
 #   kernels      tests/test_kernels_gpu.py
 #   quick        transformer / edge / lockstep tests
 #   rnn          tests/test_rnn_gpu.py
@@ -19,13 +20,13 @@
 #   lockstep_rnn lockstep sweep cfg3 / cfg3gru
 #   grid         the bench's grid leg only (folds/hr + CRC)
 #   rehearsal    2 ranks on the one GPU (gloo): bench.py --gpus 2
+#   passerr      golden-trajectory errors under (wgrad, dgrad) passes (3,3) / (2,3) / (2,2) (tools/backward_pass_errors.py)
 #   gridcal      grid leg alone at (lockstep x threads) pairs with per-unit logs (tools/bench_grid.py; GRIDCAL="15x1 15x4 5x4")
 #   profile      rocprofv3 kernel traces + PMC passes -> gpurun_out/<tag>/prof (tools/gpu/profile.sh <round>)
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=$1; shift
-O=gpurun_out/$TAG; mkdir -p $O
 line() { python - "$1" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -34,21 +35,30 @@ print({k: d.get(k) for k in ("value", "ms_per_step", "parity", "launches_per_ste
       "grid", (d.get("grid") or {}).get("value"), (d.get("grid") or {}).get("scores_crc32"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 PY
 }
-for step in "$@"; do
-  echo "=== [$step]"
+for spec in "$@"; do
+  echo "=== [$spec]"
+  step=${spec%%@*}                       # "<step>@<w>,<d>": split-bf16 passes of the weight / data gradient products for this step
+  if [ "$spec" != "$step" ]; then
+    export PLANE_PASSES=${spec#*@}; export SLNLP_WGRAD_PASSES=${PLANE_PASSES%,*}; export SLNLP_DGRAD_PASSES=${PLANE_PASSES#*,}
+  else
+    unset PLANE_PASSES SLNLP_WGRAD_PASSES SLNLP_DGRAD_PASSES
+  fi
+  O=gpurun_out/$TAG/$(echo $spec | tr '@,' '__'); mkdir -p $O
   case $step in
     clock)       SLNLP_PROBE_LIB=128 timeout -k 10 400 python tools/probes/probe_tile_timeline.py > $O/clock.txt 2> $O/clock.err || { tail -5 $O/clock.err; exit 1; }; cat $O/clock.txt ;;
     tiles_big)   timeout -k 10 400 python tools/bench_plane_tiles.py big > $O/tiles_big.txt 2> $O/tiles_big.err || { tail -5 $O/tiles_big.txt $O/tiles_big.err; exit 1; }; cat $O/tiles_big.txt ;;
     tiles_fwd)   timeout -k 10 400 python tools/bench_plane_tiles.py fwd > $O/tiles_fwd.txt 2> $O/tiles_fwd.err || { tail -5 $O/tiles_fwd.txt $O/tiles_fwd.err; exit 1; }; cat $O/tiles_fwd.txt ;;
     tiles_quick) timeout -k 10 400 python tools/bench_plane_tiles.py quick > $O/tiles_quick.txt 2> $O/tiles_quick.err || { tail -5 $O/tiles_quick.txt $O/tiles_quick.err; exit 1; }; cat $O/tiles_quick.txt ;;
-    kernels|quick|rnn|suite)
+    kernels|quick|rnn|suite|planes)
+      KEXPR=""
       case $step in
         kernels) T="tests/test_kernels_gpu.py" ;;
+        planes)  T="tests/test_kernels_gpu.py"; KEXPR="plane_tile_geometries or two_pass or gemm_planes" ;;
         quick)   T="tests/test_transformer_gpu.py tests/test_edge_shapes_gpu.py tests/test_lockstep_gpu.py" ;;
         rnn)     T="tests/test_rnn_gpu.py" ;;
         suite)   T="tests -m gpu" ;;
       esac
-      timeout -k 10 1100 python -m pytest $T -q -x > $O/$step.log 2>&1; rc=$?
+      timeout -k 10 1100 python -m pytest $T -k "$KEXPR" -q -x > $O/$step.log 2>&1; rc=$?
       tail -3 $O/$step.log | cut -c1-300
       if [ $rc -ne 0 ]; then grep -E "^E |^FAILED|^ERROR" $O/$step.log | head -20 | cut -c1-300; exit $rc; fi ;;
     bench)       timeout -k 10 300 python bench.py --steps 100 --warmup 20 --no-grid --no-cpu-baseline > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }; line $O/bench.json ;;
@@ -62,6 +72,7 @@ for step in "$@"; do
                  tail -1 $O/lockstep_$w.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], [(r['K'], r['seq_per_s'], r['ms_per_lockstep_step']) for r in d['results']])"; done ;;
     grid)        timeout -k 10 500 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/grid.json 2> $O/grid.err || { tail -5 $O/grid.err; exit 1; }; line $O/grid.json ;;
     rehearsal)   timeout -k 10 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/rehearsal.json 2> $O/rehearsal.err || { tail -5 $O/rehearsal.err; exit 1; }; line $O/rehearsal.json ;;
+    passerr)     timeout -k 10 400 python tools/backward_pass_errors.py ${PASSERR:-cfg1 cfg2 cfg5} > $O/passerr.jsonl 2> $O/passerr.err || { tail -5 $O/passerr.err; exit 1; }; cat $O/passerr.jsonl ;;
     gridcal)     timeout -k 10 700 python tools/bench_grid.py ${GRIDCAL:-15x1 15x4 5x4} > $O/gridcal.jsonl 2> $O/gridcal.err || { tail -5 $O/gridcal.err; exit 1; }
                  python -c "
 import json,sys
