@@ -315,6 +315,21 @@ int slnlp_rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, i
                        const int64_t* lengths, int64_t ld_dout,
                        float drop_p, int drop_site, const unsigned long long* rng, void* stream);
 
+/* One backward timestep in ONE launch: the recurrent data gradient of the step processed just before and this step's cell
+ * backward (what autograd does for nn.LSTM / nn.GRU behind /root/reference/model/base/encoder_decoder_attn_bkp.py:95-132):
+ *   dh = dgh_next W_hh + carry (+ dout)  ->  slnlp_rnn_cell_bwd's arithmetic  ->  dgx, dgh, dc_state, carry of this step.
+ * dgh_next == NULL (both directions): the first step of a layer, dh = cell.dh_state.  cell.dh_extra / n_extra are ignored; the
+ * product's partial sums are added in gate order, exactly as the K-sliced slnlp_gemm_group + slnlp_rnn_cell_bwd pair does.
+ * Covered: Hd % 64 == 0 (any B); dgh_next / w_hh 16-byte aligned. */
+typedef struct slnlp_rnn_step_bwd_dir {
+    slnlp_rnn_cell_bwd_dir cell;
+    const float* dgh_next;   /* [B, G*Hd] dgh written by the previous launch of this chain, or NULL */
+    const float* w_hh;       /* [G*Hd, Hd] */
+} slnlp_rnn_step_bwd_dir;
+int slnlp_rnn_step_bwd(int lstm, const slnlp_rnn_step_bwd_dir* dirs, int ndir, int B, int Hd,
+                       const int64_t* lengths, int64_t ld_dout,
+                       float drop_p, int drop_site, const unsigned long long* rng, int precision, void* stream);
+
 /* Bahdanau (MLP) attention, one query per sequence (bkp.py:304-327 with max_len 1):
  * scores[s] = w_e . tanh(q[b] + proj_key[s,b]); masked where ids[b,s] == pad; softmax;
  * ctx = alphas . value.  proj_key [S*B,Hd] / value [S*B,2Hd] rows are time-major. */
@@ -501,6 +516,12 @@ int slnlp_rnn_forward(slnlp_rnn_plan* plan, const int64_t* X, const int64_t* y, 
  * per timestep.  Default 0: measured no faster in round 1, and its Hd/16 x 2 workgroups must all be resident at
  * once, so never enable it when several fits share the GPU. */
 int slnlp_rnn_set_persistent(slnlp_rnn_plan* plan, int on);
+/* on = 1: the encoder's backward through time issues ONE launch per timestep (slnlp_rnn_step_bwd: recurrent data gradient +
+ * cell backward; Hd % 64 == 0); on = 0 (default): the cell kernel + K-sliced grouped GEMM pair.  The fused launch halves the
+ * launches of a backward pass but measured slower for one fit (cfg3 LSTM 9.11 vs 8.09 ms) and faster only
+ * for many GRU fits in lockstep, so it is opt-in (env SLNLP_RNN_FUSED_BWD=1 sets it for new plans).  Same results to fp32
+ * rounding.  Takes effect for launches issued (or recorded by a lockstep group) after the call. */
+int slnlp_rnn_set_fused_backward(slnlp_rnn_plan* plan, int on);
 /* *status = 0 when every device-wide barrier of the plan's persistent kernels completed, 1 if a workgroup timed out
  * (bounded spin; that step's results are invalid).  Synchronises the device. */
 int slnlp_rnn_health(slnlp_rnn_plan* plan, int* status);

@@ -296,6 +296,10 @@ int rnn_layer_fwd(int lstm, const slnlp_rnn_layer_dir* dirs, int ndir, int B, in
                   unsigned* bar, int* err, int* launched, hipStream_t st);
 int rnn_cell_bwd(int lstm, const slnlp_rnn_cell_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
                  int64_t ld_dout, float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st);
+bool rnn_step_bwd_covers(int B, int Hd);
+int rnn_step_bwd_init();
+int rnn_step_bwd(int lstm, const slnlp_rnn_step_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, int64_t ld_dout,
+                 float drop_p, int drop_site, const unsigned long long* rng, int precision, hipStream_t st);
 int bahdanau_fwd(const float* q, const float* pk, const float* val, const float* we, const int64_t* ids,
                  int64_t ld_ids, int64_t pad, int B, int S, int Hd, float* alphas, float* ctx, hipStream_t st);
 int bahdanau_bwd(const float* q, const float* pk, const float* val, const float* we, const float* alphas,

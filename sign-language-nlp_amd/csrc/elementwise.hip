@@ -385,7 +385,10 @@ __device__ __forceinline__ void layernorm_bwd_rows(
     const unsigned long long* __restrict__ rng, PlaneOut po_dx, PlaneOut po_drop) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
-    const bool drop = dx_drop != nullptr && drop_p > 0.f;
+    // the dropout-masked copy goes out as fp32 (dx_drop), as bf16 planes (po_drop), or both: a caller whose consumers read planes
+    // only (the plane-GEMM path) passes dx_drop = nullptr and saves the fp32 store
+    const bool want_drop = dx_drop != nullptr || po_drop.hi != nullptr;
+    const bool drop = want_drop && drop_p > 0.f;
     const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * GS;   // one group per wave: the launch covers ceil(rows / GS) waves
     if (row0 >= rows) return;
     float4 g[U];
@@ -455,14 +458,14 @@ __device__ __forceinline__ void layernorm_bwd_rows(
                 }
                 *reinterpret_cast<float4*>(dx + (long)row * E + c) = o;
                 store_planes4(po_dx, (long)row * E + c, o);
-                if (dx_drop) {
+                if (want_drop) {
                     if (drop) {
                         o.x = pick_word(kb[0], wsel) >= drop_thr ? o.x * ik : 0.f;
                         o.y = pick_word(kb[1], wsel) >= drop_thr ? o.y * ik : 0.f;
                         o.z = pick_word(kb[2], wsel) >= drop_thr ? o.z * ik : 0.f;
                         o.w = pick_word(kb[3], wsel) >= drop_thr ? o.w * ik : 0.f;
                     }
-                    *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
+                    if (dx_drop) *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
                     store_planes4(po_drop, (long)row * E + c, o);
                 }
             }

@@ -595,6 +595,229 @@ __device__ __forceinline__ slnlp_rnn_step_dir as_global(slnlp_rnn_step_dir d) {
     return d;
 }
 
+// ------------------------------------------------------------------------------------------ fused backward timestep ---
+// One launch per backward timestep (rounds 1-3: a cell kernel + a grouped K-sliced GEMM launch, 192 + 192 launches per cfg3 step):
+//   dh(t) = dgh(t+1) W_hh + carry(t+1)            [B, Hd]     recurrent data gradient of the step processed just before
+//   cell backward of step t (rnn.hip, rnn_cell_bwd_body: same arithmetic, same order)  ->  dgx(t), dgh(t), dc, carry(t)
+// A workgroup owns 16 hidden units (output columns of the GEMM) of one direction and 64 batch rows.  The contraction runs over
+// the G * Hd gate columns: G groups of 256 threads, group g contracting gate g's Hd columns with its own stage images (all G K
+// loops in flight together: the dependent chain is Hd / 64 steps, as in the K-sliced launch it replaces); the groups' partial
+// sums meet in LDS and are added in gate order -- ((P0 + carry) + P1) + P2 (+ P3), the order of the unfused path -- and group 0
+// applies the cell in the accumulator layout.  dgh_next == NULL: first step of a layer, dh = dh_state (no product).
+struct RnnStepBwdParams {
+    slnlp_rnn_step_bwd_dir d[2];
+    int B, Hd, ndir;
+    const long* lengths;
+    long ld_dout;
+    float drop_p;
+    unsigned drop_thr;
+    int drop_site;
+    const unsigned long long* rng;
+};
+__device__ __forceinline__ slnlp_rnn_step_bwd_dir as_global(slnlp_rnn_step_bwd_dir d) {
+    d.cell = as_global(d.cell);
+    d.dgh_next = as_global(d.dgh_next); d.w_hh = as_global(d.w_hh);
+    return d;
+}
+template <int NSPLIT, bool LSTM>
+constexpr int rnn_step_bwd_group_elems() {
+    return (NSPLIT == 3 ? 2 : 1) * (TileIO<true, BM>::PLANE + TileIO<false, 16>::PLANE);
+}
+template <int NSPLIT, bool LSTM>
+constexpr size_t rnn_step_bwd_lds() {
+    constexpr int G = LSTM ? 4 : 3;
+    return (size_t)G * rnn_step_bwd_group_elems<NSPLIT, LSTM>() * sizeof(unsigned short) + (size_t)(G - 1) * 256 * sizeof(f32x4);
+}
+
+template <int NSPLIT, bool LSTM>
+__global__ __launch_bounds__(LSTM ? 1024 : 768) void rnn_step_bwd_kernel(const RnnStepBwdParams P0, const RnnStepBwdParams* __restrict__ tab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short bsm[];
+    RnnStepBwdParams P;
+    if (tab) P = tab[blockIdx.z];
+    else P = P0;
+    P.lengths = as_global(P.lengths);
+    P.rng = as_global(P.rng);
+    constexpr int G = LSTM ? 4 : 3;
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    using TA = TileIO<true, BM>;
+    using TB = TileIO<false, 16>;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    unsigned short* As = bsm + grp * rnn_step_bwd_group_elems<NSPLIT, LSTM>();
+    unsigned short* Bs = As + NP * TA::PLANE;
+    f32x4* red = reinterpret_cast<f32x4*>(bsm + G * rnn_step_bwd_group_elems<NSPLIT, LSTM>());
+    const int dir = blockIdx.y % P.ndir;
+    const slnlp_rnn_step_bwd_dir sd = as_global(dir == 0 ? P.d[0] : P.d[1]);
+    const slnlp_rnn_cell_bwd_dir& d = sd.cell;
+    const int B = P.B, Hd = P.Hd, GH = G * Hd, j0 = blockIdx.x * 16, bm0 = (blockIdx.y / P.ndir) * BM;
+    const bool product = sd.dgh_next != nullptr;       // (launch-uniform per direction)
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (product) {
+        const int ktiles = Hd / BKT, kg = grp * Hd;    // this group's gate columns [kg, kg + Hd)
+        float4 ra0[TA::NV], ra1[TA::NV], rb0[TB::NV], rb1[TB::NV];
+        auto fetch = [&](int kt, float4 (&ra)[TA::NV], float4 (&rb)[TB::NV]) {
+            const int kc = kt < ktiles ? kt : 0;           // past-the-end prefetch: a valid tile, never stashed
+            TA::template fetch<true>(sd.dgh_next, GH, bm0, B, kg + kc * BKT, GH, tid, ra);
+            TB::template fetch<true>(sd.w_hh, Hd, j0, Hd, kg + kc * BKT, GH, tid, rb);
+        };
+        auto stash = [&](int kt, const float4 (&ra)[TA::NV], const float4 (&rb)[TB::NV]) {
+            // rows >= B hold a clamped row's data and only feed accumulator rows that are never used (no masks: Hd % 64 == 0)
+            TA::template stash<NSPLIT, false>(As, tid, ra, bm0, B, kg + kt * BKT, GH);
+            TB::template stash<NSPLIT, false>(Bs, tid, rb, j0, Hd, kg + kt * BKT, GH);
+        };
+        auto consume = [&]() {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 ah = TA::frag(As, wave * 16, kk, lane);
+                const bf16x8 bh = TB::frag(Bs, 0, kk, lane);
+                if (NSPLIT == 3) {
+                    const bf16x8 al = TA::frag(As + TA::PLANE, wave * 16, kk, lane);
+                    const bf16x8 bl = TB::frag(Bs + TB::PLANE, 0, kk, lane);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        };
+        fetch(0, ra0, rb0);
+        fetch(1, ra1, rb1);
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            lds_barrier();
+            stash(kt, ra0, rb0);
+            lds_barrier();
+            fetch(kt + 2, ra0, rb0);
+            consume();
+            if (kt + 1 >= ktiles) break;
+            lds_barrier();
+            stash(kt + 1, ra1, rb1);
+            lds_barrier();
+            fetch(kt + 3, ra1, rb1);
+            consume();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy prefetches
+        if (grp > 0) red[(grp - 1) * 256 + tid] = acc;
+        __syncthreads();
+    }
+    if (grp != 0) return;
+
+    // ---- the cell backward of this timestep in the accumulator layout (rnn.hip rnn_cell_bwd_body: same arithmetic and order)
+    const int j = j0 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = bm0 + wave * 16 + ((lane >> 4) << 2) + r;
+        if (b >= B) break;
+        const long idx = (long)b * Hd + j;
+        const bool valid = P.lengths ? (d.t < P.lengths[b]) : true;
+        float dh;
+        if (product) {
+            dh = acc[r] + d.carry[idx];                      // (the unfused path adds carry as the first job's residual)
+#pragma unroll
+            for (int e = 0; e < G - 1; ++e) dh += red[e * 256 + tid][r];
+        } else {
+            dh = d.dh_state[idx];
+        }
+        float* gx = d.dgx + (long)b * GH;
+        float* gh = LSTM ? gx : d.dgh + (long)b * GH;
+        if (!valid) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                gx[g * Hd + j] = 0.f;
+                if (!LSTM) gh[g * Hd + j] = 0.f;
+            }
+            d.carry[idx] = dh;
+            continue;
+        }
+        if (d.dout) {
+            float g = d.dout[(long)b * P.ld_dout + j];
+            if (P.drop_p > 0.f)
+                g = dropout_keep(P.rng, P.drop_site, (unsigned)(d.out_row0 + b), (unsigned)(d.out_col0 + j), P.drop_thr)
+                        ? g / (1.f - P.drop_p) : 0.f;
+            dh += g;
+        }
+        const float* a = d.acts + (long)b * GH;
+        if constexpr (LSTM) {
+            const float gi = a[j], gf = a[Hd + j], gg = a[2 * Hd + j], go = a[3 * Hd + j];
+            const float cprev = d.cprev_save[idx];
+            const float tc = tanhf(gf * cprev + gi * gg);
+            const float dc = d.dc_state[idx] + dh * go * (1.f - tc * tc);
+            gx[j] = dc * gg * gi * (1.f - gi);
+            gx[Hd + j] = dc * cprev * gf * (1.f - gf);
+            gx[2 * Hd + j] = dc * gi * (1.f - gg * gg);
+            gx[3 * Hd + j] = dh * tc * go * (1.f - go);
+            d.dc_state[idx] = dc * gf;
+            d.carry[idx] = 0.f;
+        } else {
+            const float rr = a[j], z = a[Hd + j], nn = a[2 * Hd + j];
+            const float hprev = d.hprev_save[idx], hn = d.hn_save[idx];
+            const float dn_pre = dh * (1.f - z) * (1.f - nn * nn);
+            const float dr_pre = dn_pre * hn * rr * (1.f - rr);
+            const float dz_pre = dh * (hprev - nn) * z * (1.f - z);
+            gx[j] = dr_pre; gx[Hd + j] = dz_pre; gx[2 * Hd + j] = dn_pre;
+            gh[j] = dr_pre; gh[Hd + j] = dz_pre; gh[2 * Hd + j] = dn_pre * rr;
+            d.carry[idx] = dh * z;
+        }
+    }
+}
+
+template <int NSPLIT, bool LSTM>
+static const void* rnn_step_bwd_fn() { return (const void*)rnn_step_bwd_kernel<NSPLIT, LSTM>; }
+
+// raise the kernels' dynamic LDS limit once per device (plan creation: never inside a graph capture)
+int rnn_step_bwd_init() {
+    static DeviceOnce once;
+    return once.run([]() -> int {
+        const bool ok =
+            hipFuncSetAttribute(rnn_step_bwd_fn<3, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_step_bwd_lds<3, true>()) == hipSuccess &&
+            hipFuncSetAttribute(rnn_step_bwd_fn<3, false>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_step_bwd_lds<3, false>()) == hipSuccess &&
+            hipFuncSetAttribute(rnn_step_bwd_fn<1, true>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_step_bwd_lds<1, true>()) == hipSuccess &&
+            hipFuncSetAttribute(rnn_step_bwd_fn<1, false>(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_step_bwd_lds<1, false>()) == hipSuccess;
+        if (!ok) {
+            set_error("rnn_step_bwd_init: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
+        return 0;
+    });
+}
+
+bool rnn_step_bwd_covers(int B, int Hd) { return Hd % 64 == 0 && B > 0; }
+
+int rnn_step_bwd(int lstm, const slnlp_rnn_step_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, int64_t ld_dout,
+                 float drop_p, int drop_site, const unsigned long long* rng, int precision, hipStream_t st) {
+    SLNLP_CHECK_ARG(dirs && (ndir == 1 || ndir == 2) && rnn_step_bwd_covers(B, Hd), "rnn_step_bwd: bad args (Hd %% 64 == 0)");
+    SLNLP_CHECK_ARG(precision == 1 || precision == 3, "rnn_step_bwd: precision must be 1 or 3");
+    SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "rnn_step_bwd: bad dropout args");
+    const int G = lstm ? 4 : 3;
+    RnnStepBwdParams P;
+    for (int k = 0; k < ndir; ++k) {
+        const slnlp_rnn_step_bwd_dir& d = dirs[k];
+        SLNLP_CHECK_ARG(d.cell.dc_state || !lstm, "rnn_step_bwd: dc_state missing in direction %d", k);
+        SLNLP_CHECK_ARG(d.cell.acts && d.cell.dgx && d.cell.carry && (lstm ? d.cell.cprev_save != nullptr : (d.cell.hprev_save && d.cell.hn_save && d.cell.dgh)),
+                        "rnn_step_bwd: null pointer in direction %d", k);
+        SLNLP_CHECK_ARG(d.dgh_next ? (d.w_hh && vec_ok(d.dgh_next, (long)G * Hd) && vec_ok(d.w_hh, Hd)) : d.cell.dh_state != nullptr,
+                        "rnn_step_bwd: direction %d needs {dgh_next, w_hh} (16-byte aligned) or dh_state", k);
+        SLNLP_CHECK_ARG((dirs[0].dgh_next != nullptr) == (d.dgh_next != nullptr), "rnn_step_bwd: the directions of a launch are both first steps or both not");
+        P.d[k] = d;
+    }
+    if (ndir == 1) P.d[1] = P.d[0];
+    P.B = B; P.Hd = Hd; P.ndir = ndir; P.lengths = (const long*)lengths; P.ld_dout = ld_dout;
+    P.drop_p = drop_p; P.drop_thr = dropout_threshold(drop_p); P.drop_site = drop_site; P.rng = rng;
+    SLNLP_TRY(rnn_step_bwd_init());
+    const dim3 grid(Hd / 16, ndir * ceil_div(B, BM));
+    const dim3 block(G * 256);
+    const void* fn = precision == 3 ? (lstm ? rnn_step_bwd_fn<3, true>() : rnn_step_bwd_fn<3, false>())
+                                    : (lstm ? rnn_step_bwd_fn<1, true>() : rnn_step_bwd_fn<1, false>());
+    const size_t lds = precision == 3 ? (lstm ? rnn_step_bwd_lds<3, true>() : rnn_step_bwd_lds<3, false>())
+                                      : (lstm ? rnn_step_bwd_lds<1, true>() : rnn_step_bwd_lds<1, false>());
+    if (recording()) return record_op(fn, grid, block, lds, REC_Z, &P, sizeof(P), "rnn_step_bwd");
+    const RnnStepBwdParams* tab = nullptr;
+    void* args[2] = {&P, &tab};
+    if (hipLaunchKernel(fn, grid, block, args, lds, st) != hipSuccess) {
+        set_error("rnn_step_bwd: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
+    }
+    return SLNLP_OK;
+}
+
 // grid (Hd / 16, ndir x row tiles, fit): `tab` != nullptr is a lockstep launch, fit z takes tab[z] (launch.hpp)
 template <int NSPLIT, bool LSTM, bool EDGE>
 __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P0, const RnnStepParams* __restrict__ tab) {
@@ -1002,6 +1225,12 @@ extern "C" int slnlp_rnn_layer_fwd(int lstm, const slnlp_rnn_layer_dir* dirs, in
     }
     return slnlp::rnn_layer_fwd(lstm, dirs, ndir, B, Hd, S, lengths, fill, ld_out, drop_p, drop_site, rng, precision, sync,
                                 reinterpret_cast<int*>(sync + 2), launched, (hipStream_t)stream);
+}
+
+extern "C" int slnlp_rnn_step_bwd(int lstm, const slnlp_rnn_step_bwd_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,
+                                  int64_t ld_dout, float drop_p, int drop_site, const unsigned long long* rng, int precision,
+                                  void* stream) {
+    return slnlp::rnn_step_bwd(lstm, dirs, ndir, B, Hd, lengths, ld_dout, drop_p, drop_site, rng, precision, (hipStream_t)stream);
 }
 
 extern "C" int slnlp_rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths,

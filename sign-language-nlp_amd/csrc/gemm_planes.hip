@@ -434,17 +434,26 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                     stg[(lm0 + r) * SLD + ln] = v;
                 }
             }
+        // the residual pieces of ALL passes are requested before the barrier: resid may alias C (an in-place add), so inside the
+        // store loop the compiler has to keep every load behind the previous pass's stores -- eight serialised round trips for a
+        // 128 x 128 tile; a thread only ever reads the elements it is about to write, so reading them all up front is safe
+        constexpr int NPASS = BM * BN / 4 / PTHREADS;
+        float4 rr[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int piece = pass * PTHREADS + tid, row = piece / (BN / 4), c4 = (piece % (BN / 4)) << 2;
+            const int gm = bm0 + row, gn = bn0 + c4;
+            rr[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.resid && gm < M && gn < N) rr[pass] = *reinterpret_cast<const float4*>(g.resid + (long)gm * g.ldr + gn);
+        }
         __syncthreads();
 #pragma unroll
-        for (int pass = 0; pass < BM * BN / 4 / PTHREADS; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int piece = pass * PTHREADS + tid, row = piece / (BN / 4), c4 = (piece % (BN / 4)) << 2;
             const int gm = bm0 + row, gn = bn0 + c4;
             if (gm >= M || gn >= N) continue;                 // N % 4 == 0 (vec_out): a live piece is 4 live columns
             float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
-            if (g.resid) {
-                const float4 rr = *reinterpret_cast<const float4*>(g.resid + (long)gm * g.ldr + gn);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
+            if (g.resid) { v.x += rr[pass].x; v.y += rr[pass].y; v.z += rr[pass].z; v.w += rr[pass].w; }
             if (g.C) *reinterpret_cast<float4*>(g.C + (long)gm * g.ldc + gn) = v;
             if (g.C_hi) {
                 PlaneOut po;

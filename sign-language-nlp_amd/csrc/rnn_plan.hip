@@ -256,6 +256,12 @@ struct slnlp_rnn_plan {
     int planes_B = -1;        // batch size the activation planes' zero padding is valid for
     int destroy_sync = 1;     // slnlp_rnn_set_destroy_sync: wait for the device before the plan goes away (launch.hpp)
     bool persistent = false;  // opt-in: all timesteps of an encoder layer in one launch (not yet faster; needs one fit per GPU)
+    // backward through time: the cell kernel + K-sliced grouped GEMM pair per timestep (default), or ONE launch per timestep
+    // (gemm.hip rnn_step_bwd_kernel; slnlp_rnn_set_fused_backward(plan, 1), env SLNLP_RNN_FUSED_BWD=1).  Round 4 built the
+    // fused kernel to halve the 384 dependent launches of a cfg3 backward and measured it SLOWER solo (LSTM 9.11 vs 8.09 ms, GRU
+    // 7.73 vs 7.27): its G K-slices share one CU's LDS-write and conversion bandwidth where the K-sliced launch spreads them over
+    // 256 CUs, and a timestep is a latency chain either way.  16 GRU fits in lockstep gain 4 % from it.
+    bool unfused_bwd = [] { const char* e = getenv("SLNLP_RNN_FUSED_BWD"); return !(e && atoi(e) != 0); }();
     // lockstep (lockstep.hip): where lsm_nll also puts the batch's log-probs / loss (device row and batch index in ls_dyn)
     float* ls_logp = nullptr;
     float* ls_loss = nullptr;
@@ -323,7 +329,7 @@ struct slnlp_rnn_plan {
         a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
         a.resid = resid; a.ldr = Kin;
-        a.precision = cfg.precision;
+        a.precision = cfg.precision == 3 ? dgrad_passes() : cfg.precision;     // (slnlp_set_backward_passes: dY's bf16 head only)
         return a;
     }
     slnlp_gemm_args wgr_p(const RPP& dy, int T, int Nout, const RPP& x, int Kin, float* dW, float* db) const {
@@ -333,7 +339,7 @@ struct slnlp_rnn_plan {
         a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
-        a.precision = cfg.precision;
+        a.precision = cfg.precision == 3 ? wgrad_passes() : cfg.precision;
         return a;
     }
     // the recurrent dgrad dh(t-1) = dgh W_hh + carry contracts over the G*Hd gate columns: one K-slice per gate
@@ -407,7 +413,7 @@ int slnlp_rnn_create(const slnlp_rnn_config* cfg, const slnlp_tf_buffers* buf, s
         hipMemset(buf->grads, 0, p->L.total * sizeof(float)) != hipSuccess ||   // pre_output_layer + pads stay 0
         hipMemset(p->w.sync, 0, 64 * sizeof(unsigned)) != hipSuccess ||
         hipStreamSynchronize(nullptr) != hipSuccess ||      // null-stream memsets must not land inside the caller's first step
-        rnn_layer_init() != 0 || gemm_planes_init() != 0) {
+        rnn_layer_init() != 0 || rnn_step_bwd_init() != 0 || gemm_planes_init() != 0) {
         set_error("rnn_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
         delete p;
         return SLNLP_ERR_LAUNCH;
@@ -547,6 +553,11 @@ int slnlp_rnn_forward(slnlp_rnn_plan* pl, const int64_t* X, const int64_t* y, co
 // on = 1: all timesteps of an encoder layer in ONE persistent launch (gemm.hip rnn_layer_fwd_kernel) instead of one
 // launch per timestep.  Off by default: measured no faster yet, and its workgroups must all be resident at once, so it
 // must not be used when several fits share the GPU.
+int slnlp_rnn_set_fused_backward(slnlp_rnn_plan* pl, int on) {
+    SLNLP_CHECK_ARG(pl, "rnn_set_fused_backward: null plan");
+    pl->unfused_bwd = on == 0;
+    return 0;
+}
 int slnlp_rnn_set_persistent(slnlp_rnn_plan* pl, int on) {
     SLNLP_CHECK_ARG(pl, "rnn_set_persistent: null plan");
     pl->persistent = on != 0;
@@ -643,6 +654,10 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
             SLNLP_TRY(add_rows(w.denc_final + (long)l * B * 2 * Hd + d * Hd, 2 * Hd, a.d[d].dh, Hd, B, Hd, 0, st));
         }
         const int nsl = pl->kslices(), Ks = GH / nsl;
+        // one launch per timestep (gemm.hip rnn_step_bwd_kernel: the recurrent dgrad of the step before + this step's cell
+        // backward); shapes it does not cover -- and SLNLP_RNN_UNFUSED_BWD=1, the comparison path of the tests -- take the
+        // cell kernel + K-sliced grouped GEMM pair
+        const bool fused_bwd = rnn_step_bwd_covers(B, Hd) && !pl->unfused_bwd;
         for (int step = S - 1; step >= 0; --step) {
             slnlp_rnn_cell_bwd_dir dirs[2] = {};
             for (int d = 0; d < 2; ++d) {
@@ -661,6 +676,20 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
                 k.dgh = e.dgh + (long)t * B * GH;
                 k.carry = e.carry;
                 k.t = t; k.out_row0 = t * B; k.out_col0 = d * Hd;
+            }
+            if (fused_bwd) {
+                slnlp_rnn_step_bwd_dir sd[2] = {};
+                for (int d = 0; d < 2; ++d) {
+                    sd[d].cell = dirs[d];
+                    sd[d].cell.dh_extra = nullptr; sd[d].cell.n_extra = 0;
+                    if (step < S - 1) {                    // the step processed just before: time t + 1 (forward dir) / t - 1 (backward dir)
+                        const int tn = d == 0 ? step + 1 : S - 2 - step;
+                        sd[d].dgh_next = a.d[d].dgh + (long)tn * B * GH;
+                        sd[d].w_hh = pl->P(L.enc[d][l].w_hh);
+                    }
+                }
+                SLNLP_TRY(rnn_step_bwd(lstm, sd, 2, B, Hd, lengths, 2 * Hd, last ? 0.f : p, RSITE_ENC0 + l, rng, c.precision, st));
+                continue;
             }
             SLNLP_TRY(rnn_cell_bwd(lstm, dirs, 2, B, Hd, lengths, 2 * Hd, last ? 0.f : p, RSITE_ENC0 + l, rng, st));
             slnlp_gemm_args rec[8];

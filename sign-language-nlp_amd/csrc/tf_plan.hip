@@ -343,13 +343,15 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         const PlaneOut none{};
         // LayerNorm backward also emits the bf16 planes of the gradient that feeds the sub-layer's GEMMs
         // (the dropout-masked copy when dropout is on, else dx itself)
-        SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, a.gA2, p > 0.f ? a.gB2 : nullptr, p,
+        // (plane path: the sub-layer's GEMMs read the planes only, so neither the masked fp32 copy nor the fp32 ReLU-gated
+        //  gradient of the FFN hidden layer is stored)
+        SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, a.gA2, (p > 0.f && !up) ? a.gB2 : nullptr, p,
                                 pl->enc_site(l, 3), rng, nullptr, nullptr, 0, st, (up && p == 0.f) ? a.d2p.out() : none,
                                 (up && p > 0.f) ? a.d2p.out() : none));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
         if (up) {
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.d2p, E, M, E, a.hp, F, pl->G(q.l2_w), pl->G(q.l2_b)),
-                                   pl->dgrad_p_args(a.d2p, E, M, E, q.l2_w, F, a.gh, a.h, ik, nullptr, &a.ghp), 0, st));
+                                   pl->dgrad_p_args(a.d2p, E, M, E, q.l2_w, F, nullptr, a.h, ik, nullptr, &a.ghp), 0, st));
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.ghp, F, M, F, a.x1p, E, pl->G(q.l1_w), pl->G(q.l1_b)),
                                    pl->dgrad_p_args(a.ghp, F, M, F, q.l1_w, E, a.gx1, nullptr, 0.f, a.gA2, nullptr), 0, st));
         } else {
@@ -358,7 +360,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
             SLNLP_TRY(pl->wd_group_f(pl->wgrad_args(a.gh, F, M, F, a.x1, E, pl->G(q.l1_w), pl->G(q.l1_b)),
                                      pl->dgrad_args(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2), st));
         }
-        SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, p > 0.f ? a.gB1 : nullptr, p,
+        SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, (p > 0.f && !up) ? a.gB1 : nullptr, p,
                                 pl->enc_site(l, 1), rng, nullptr, nullptr, 0, st, (up && p == 0.f) ? a.d1p.out() : none,
                                 (up && p > 0.f) ? a.d1p.out() : none));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;

@@ -74,6 +74,10 @@ class RnnCellBwdDir(C.Structure):
                 ("dh_extra", vp), ("extra_stride", i64), ("n_extra", i32)]
 
 
+class RnnStepBwdDir(C.Structure):
+    _fields_ = [("cell", RnnCellBwdDir), ("dgh_next", vp), ("w_hh", vp)]
+
+
 class LnReduceEntry(C.Structure):
     _fields_ = [("partial", vp), ("dgamma", vp), ("dbeta", vp), ("nblk", i32), ("E", i32)]
 
@@ -110,6 +114,7 @@ SIGNATURES = {
                                   C.POINTER(i32), vp]),
     "slnlp_rnn_step_fwd": (i32, [i32, C.POINTER(RnnStepDir), i32, i32, i32, vp, f32, i64, f32, i32, vp, i32, vp]),
     "slnlp_rnn_cell_bwd": (i32, [i32, C.POINTER(RnnCellBwdDir), i32, i32, i32, vp, i64, f32, i32, vp, vp]),
+    "slnlp_rnn_step_bwd": (i32, [i32, C.POINTER(RnnStepBwdDir), i32, i32, i32, vp, i64, f32, i32, vp, i32, vp]),
     "slnlp_bahdanau_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]),
     "slnlp_bahdanau_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "slnlp_rnn_num_params": (i32, [C.POINTER(RnnConfig)]),
@@ -129,6 +134,7 @@ SIGNATURES = {
     "slnlp_rnn_graph_capture_train": (i32, [vp, vp, vp, vp, i32, f32, f32, vp, vp]),
     "slnlp_rnn_graph_launch": (i32, [vp, i32, vp]),
     "slnlp_rnn_set_persistent": (i32, [vp, i32]),
+    "slnlp_rnn_set_fused_backward": (i32, [vp, i32]),
     "slnlp_rnn_health": (i32, [vp, C.POINTER(i32)]),
     "slnlp_rnn_tap": (i32, [vp, C.c_char_p, vp, i64, C.POINTER(i64), vp]),
     "slnlp_tf_num_params": (i32, [C.POINTER(TfConfig)]),

@@ -159,6 +159,10 @@ class RnnEngine:
         assert n.value == rows * cols, (name, n.value, rows, cols)
         return out
 
+    def set_fused_backward(self, on):
+        """False: backward through time as the cell kernel + K-sliced grouped GEMM pair (the comparison path of the tests)."""
+        check(load().slnlp_rnn_set_fused_backward(self.handle, int(bool(on))), "rnn_set_fused_backward")
+
     def set_persistent(self, on):
         """True: each encoder layer's timesteps in one persistent launch (opt-in; one fit per GPU only)."""
         check(load().slnlp_rnn_set_persistent(self.handle, int(bool(on))), "rnn_set_persistent")

@@ -141,6 +141,37 @@ def test_dropout_path_vs_oracle_with_same_masks(rnn_type):
         assert e < 2e-3, f"{k}: grad err {e:.2e}"
 
 
+@pytest.mark.parametrize("rnn_type,name", [("lstm", "cfg3"), ("gru", "cfg3"), ("lstm", "mid"), ("gru", "mid")])
+def test_fused_backward_step_equals_cell_plus_ksliced_gemm(rnn_type, name):
+    """One launch per backward timestep (slnlp_rnn_step_bwd: recurrent data gradient + cell backward, round 4) against the
+    cell kernel + K-sliced grouped GEMM pair of rounds 1-3 (slnlp_rnn_set_fused_backward(plan, 0)) on the same plan: three
+    train steps with dropout and ragged lengths -- the same partial products added in the same gate order, so every gradient
+    and every weight agree to fp32 rounding (the stand-alone GEMM cuts its K loop over two wave groups: another order inside a
+    gate's sum), and the loss trajectories are the same."""
+    g, c, sd, X, L, y = gold.rnn_case(rnn_type, name)
+    Xc, yc, Lc = X.cuda(), y.cuda(), L.cuda()
+    res = []
+    for fused in (True, False):
+        eng = make_engine(c, sd, dropout=0.1)
+        eng.set_fused_backward(fused)
+        eng.set_lr(0.01)
+        eng.forward(Xc, yc, Lc, train=True)
+        eng.backward()
+        torch.cuda.synchronize()
+        grads = eng.grads.clone()
+        losses = []
+        for _ in range(3):
+            eng.train_step(Xc, yc, Lc, momentum=0.9, max_norm=0.5)
+            torch.cuda.synchronize()
+            losses.append(eng.loss)
+        res.append((grads, eng.params.clone(), losses))
+    (g1, w1, l1), (g0, w0, l0) = res
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) < 2e-5 * scale, float((g1 - g0).abs().max()) / scale
+    assert float((w1 - w0).abs().max()) < 2e-5 * float(w0.abs().max())
+    assert all(abs(a - b) < 1e-5 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+
+
 @pytest.mark.parametrize("lstm", [1, 0])
 @pytest.mark.parametrize("B,Hd", [(50, 512), (7, 40), (70, 64)])
 def test_fused_step_equals_gemm_plus_cell(lstm, B, Hd):

@@ -10,6 +10,8 @@
 #   kernels      tests/test_kernels_gpu.py
 #   quick        transformer / edge / lockstep tests
 #   rnn          tests/test_rnn_gpu.py
+#   streams      tests/test_streams_gpu.py (fits on overlapping queues)
+#   net          estimator / lockstep / configs tests
 #   suite        the whole -m gpu suite
 #   bench        default bench line (cfg2) without grid / cpu baseline
 #   bench_full   the default bench.py run, exactly as the driver runs it
@@ -49,13 +51,15 @@ for spec in "$@"; do
     tiles_big)   timeout -k 10 400 python tools/bench_plane_tiles.py big > $O/tiles_big.txt 2> $O/tiles_big.err || { tail -5 $O/tiles_big.txt $O/tiles_big.err; exit 1; }; cat $O/tiles_big.txt ;;
     tiles_fwd)   timeout -k 10 400 python tools/bench_plane_tiles.py fwd > $O/tiles_fwd.txt 2> $O/tiles_fwd.err || { tail -5 $O/tiles_fwd.txt $O/tiles_fwd.err; exit 1; }; cat $O/tiles_fwd.txt ;;
     tiles_quick) timeout -k 10 400 python tools/bench_plane_tiles.py quick > $O/tiles_quick.txt 2> $O/tiles_quick.err || { tail -5 $O/tiles_quick.txt $O/tiles_quick.err; exit 1; }; cat $O/tiles_quick.txt ;;
-    kernels|quick|rnn|suite|planes)
+    kernels|quick|rnn|suite|planes|streams|net)
       KEXPR=""
       case $step in
         kernels) T="tests/test_kernels_gpu.py" ;;
         planes)  T="tests/test_kernels_gpu.py"; KEXPR="plane_tile_geometries or two_pass or gemm_planes" ;;
         quick)   T="tests/test_transformer_gpu.py tests/test_edge_shapes_gpu.py tests/test_lockstep_gpu.py" ;;
         rnn)     T="tests/test_rnn_gpu.py" ;;
+        streams) T="tests/test_streams_gpu.py" ;;
+        net)     T="tests/test_net_gpu.py tests/test_lockstep_gpu.py tests/test_configs_gpu.py" ;;
         suite)   T="tests -m gpu" ;;
       esac
       timeout -k 10 1100 python -m pytest $T -k "$KEXPR" -q -x > $O/$step.log 2>&1; rc=$?
@@ -78,7 +82,7 @@ for spec in "$@"; do
 import json,sys
 for l in open('$O/gridcal.jsonl'):
     d=json.loads(l); print(d['lockstep'], d['fits_per_gpu'], d['units_per_thread'], d['folds_per_hr'], d['seconds'], d['work_units'], d['scores_crc32'])" ;;
-    profile)     bash tools/gpu/profile.sh r04 $O/prof || exit 1 ;;
+    profile)     bash tools/gpu/profile.sh r04 $O/prof ${PROFILE_SECTIONS:-} || exit 1 ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
