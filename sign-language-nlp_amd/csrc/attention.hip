@@ -207,7 +207,7 @@ __device__ __forceinline__ void attn_self_fwd_mfma_body(
                 const int i = i0 + r;
                 if (i >= S) continue;
                 const long at = ((long)i * B + b) * E + h * dh + d0 + d;
-                ctx[at] = acc[n][r];
+                if (ctx) ctx[at] = acc[n][r];               // (a caller whose consumers read the planes passes ctx = nullptr)
                 store_planes1(po, at, acc[n][r]);
             }
         }
@@ -322,7 +322,7 @@ __device__ __forceinline__ void attn_self_bwd_mfma_body(
                     const int i = i0 + r;
                     if (i >= S) continue;
                     const long at = ((long)i * B + b) * ld + (long)part * E + h * dh + d0 + d;
-                    dqkv[at] = o[n][r];
+                    if (dqkv) dqkv[at] = o[n][r];           // (likewise: planes only when dqkv = nullptr)
                     store_planes1(po, at, o[n][r]);
                 }
             }
@@ -591,7 +591,7 @@ static int check_attn(const char* who, int B, int S, int H, int dh) {
 int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t pad_idx, int causal, int B, int S,
                   int H, int dh, float* ctx, float* probs, float drop_p, int drop_site,
                   const unsigned long long* rng, hipStream_t st, PlaneOut po) {
-    SLNLP_CHECK_ARG(qkv && ctx && probs, "attn_self_fwd: null pointer");
+    SLNLP_CHECK_ARG(qkv && probs && (ctx || (po.hi && S <= SMAX)), "attn_self_fwd: null pointer (ctx may be NULL only with output planes, S <= %d)", SMAX);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_fwd: bad dropout args");
     if (S > SMAX) return attn_self_fwd_long(qkv, ids, ld_ids, pad_idx, causal, B, S, H, dh, ctx, probs, drop_p, drop_site, rng, st, po);
     SLNLP_TRY(check_attn("attn_self_fwd", B, S, H, dh));
@@ -602,7 +602,7 @@ int attn_self_fwd(const float* qkv, const int64_t* ids, int64_t ld_ids, int64_t 
 
 int attn_self_bwd(const float* qkv, const float* probs, const float* dctx, int B, int S, int H, int dh, float* dqkv,
                   float drop_p, int drop_site, const unsigned long long* rng, hipStream_t st, PlaneOut po, float* long_scratch) {
-    SLNLP_CHECK_ARG(qkv && probs && dctx && dqkv, "attn_self_bwd: null pointer");
+    SLNLP_CHECK_ARG(qkv && probs && dctx && (dqkv || (po.hi && S <= SMAX)), "attn_self_bwd: null pointer (dqkv may be NULL only with output planes, S <= %d)", SMAX);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "attn_self_bwd: bad dropout args");
     if (S > SMAX) return attn_self_bwd_long(qkv, probs, dctx, B, S, H, dh, dqkv, long_scratch, drop_p, drop_site, rng, st, po);
     SLNLP_TRY(check_attn("attn_self_bwd", B, S, H, dh));

@@ -188,7 +188,9 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         const EncA& a = w.enc[l];
         if (up) {
             SLNLP_TRY(pl->linear_p(*xp, M, E, q.in_w, 3 * E, pl->P(q.in_b), a.qkv, 3 * E, 0, 0.f, 0, nullptr, nullptr, st));
-            SLNLP_TRY(attn_self_fwd(a.qkv, X, S, c.pad_src, 1, B, S, H, dh, a.ctx, a.probs, p, pl->enc_site(l, 0), rng, st, a.ctxp.out()));
+            // (ctx and, in backward, d qkv leave the attention kernels as planes only when the sequence fits the single-tile kernels:
+            //  their fp32 copies have no reader in the plane path)
+            SLNLP_TRY(attn_self_fwd(a.qkv, X, S, c.pad_src, 1, B, S, H, dh, S <= 64 ? nullptr : a.ctx, a.probs, p, pl->enc_site(l, 0), rng, st, a.ctxp.out()));
             SLNLP_TRY(pl->linear_p(a.ctxp, M, E, q.out_w, E, pl->P(q.out_b), a.y1, E, 0, p, pl->enc_site(l, 1), x, nullptr, st));
             SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), M, E, 1e-5f, a.x1, a.st1, st, a.x1p.out()));
             SLNLP_TRY(pl->linear_p(a.x1p, M, E, q.l1_w, F, pl->P(q.l1_b), a.h, F, 1, p, pl->enc_site(l, 2), nullptr, &a.hp, st));
@@ -367,7 +369,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         if (up) {
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.d1p, E, M, E, a.ctxp, E, pl->G(q.out_w), pl->G(q.out_b)),
                                    pl->dgrad_p_args(a.d1p, E, M, E, q.out_w, E, a.gctx, nullptr, 0.f, nullptr, nullptr), 0, st));
-            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, a.gqkv, p, pl->enc_site(l, 0), rng, st, a.gqkvp.out(), w.attn_scratch));
+            SLNLP_TRY(attn_self_bwd(a.qkv, a.probs, a.gctx, B, S, H, dh, S <= 64 ? nullptr : a.gqkv, p, pl->enc_site(l, 0), rng, st, a.gqkvp.out(), w.attn_scratch));
             SLNLP_TRY(pl->wd_group(pl->wgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, xp_in, E, pl->G(q.in_w), pl->G(q.in_b)),
                                    pl->dgrad_p_args(a.gqkvp, 3 * E, M, 3 * E, q.in_w, E, a.gx0, nullptr, 0.f, a.gA1, nullptr), 0, st));
         } else {
