@@ -166,6 +166,13 @@ struct Blob {
     }
 };
 
+// merged fp32-operand GEMM launches re-tile their 16-column jobs to 64 columns from this many workgroups on
+// (env SLNLP_LS_RETILE_MIN: tuning / tests; 0 = never)
+static long gemm_group_retile_min() {
+    static const long v = [] { const char* e = getenv("SLNLP_LS_RETILE_MIN"); const long x = e ? atol(e) : 512; return x > 0 ? x : (1L << 40); }();
+    return v;
+}
+
 static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, hipStream_t st) {
     const int K = (int)recs.size();
     Blob blob;
@@ -213,15 +220,28 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
         } else {
             std::vector<GemmJob> jobs;
             std::vector<int> map;
+            long blocks = 0;
             for (int f = 0; f < K; ++f) {
                 const GemmGroupParams* P = reinterpret_cast<const GemmGroupParams*>(recs[f].ops[i].args.data());
                 for (int j = 0; j < P->njobs; ++j) {
                     GemmJob job;
                     job.p = P->job[j]; job.variant = P->variant[j]; job.gx = P->gx[j]; job.gy = P->gy[j];
-                    job.block_begin = (int)map.size();
-                    map.insert(map.end(), job.gx * job.gy * (job.p.a.batch > 1 ? job.p.a.batch : 1), (int)jobs.size());
+                    blocks += (long)job.gx * job.gy * (job.p.a.batch > 1 ? job.p.a.batch : 1);
                     jobs.push_back(job);
                 }
+            }
+            // A solo fit runs its 50-row products on 16-column tiles (4x the workgroups: the launch is a latency chain on a
+            // few CUs).  The merged launch of many fits is throughput-bound instead, and every 16-column workgroup converts
+            // the job's whole A tile again: once the launch fills the chip anyway, the narrow jobs take 64-column tiles -- a
+            // quarter of the A conversions and LDS writes per output.  Same K order per output element (the K loop and its
+            // KS split do not depend on the tile width): each fit keeps the bits of its solo launch.
+            if (blocks >= gemm_group_retile_min())
+                for (GemmJob& job : jobs)
+                    if ((job.variant & 1) && job.p.a.N > 16) { job.variant -= 1; job.gx = (job.p.a.N + 63) / 64; }
+            for (size_t j = 0; j < jobs.size(); ++j) {
+                GemmJob& job = jobs[j];
+                job.block_begin = (int)map.size();
+                map.insert(map.end(), job.gx * job.gy * (job.p.a.batch > 1 ? job.p.a.batch : 1), (int)j);
             }
             m.tab = (void*)(blob.add(jobs.data(), jobs.size() * sizeof(GemmJob)) + 1);
             m.blockmap = (int*)(blob.add(map.data(), map.size() * sizeof(int)) + 1);
