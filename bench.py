@@ -211,10 +211,10 @@ def large_launch_roofline(precision, dev):
     jw, _ = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=wp)
     jd, _ = ops.plane_job(dYp, Wp, M=M, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=dp)
     scr = ops.gemm_group([jw, jd], [split, 1])
-    for _ in range(3):
+    for _ in range(10):
         ops.gemm_group([jw, jd], [split, 1], scr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
+    n = 40
     e0.record()
     for _ in range(n):
         ops.gemm_group([jw, jd], [split, 1], scr)
