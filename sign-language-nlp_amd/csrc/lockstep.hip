@@ -320,6 +320,11 @@ static int ls_set_data(LockstepGroup* ls, int slot, const int64_t* const* X, con
     s.hy.assign(y, y + ls->K);
     if (ls->has_len) s.hlen.assign(len, len + ls->K);
     s.set = true;
+    // the baked optimizer constants belong to the TRAIN programs: once none is left a new momentum / max_norm is welcome again,
+    // whatever eval programs of other slots are still cached
+    bool any_train = false;
+    for (const auto& kv : ls->programs) any_train = any_train || std::get<2>(kv.first) != 0;
+    if (!any_train) ls->have_opt = false;
     if (ls->programs.empty()) {
         // no recorded program refers to the table space any more: hand it all back (a long-lived group that keeps getting new
         // data would otherwise run the bump allocator dry) and put the slots' pointer tables at its start again.  Ordered on
@@ -406,6 +411,8 @@ static int ls_set_adam(LockstepGroup* ls, float* const* exp_avg_sq, float beta1,
     ls->adam = LsAdam{beta1, beta2, eps, weight_decay};
     ls->use_adam = true;
     ls->have_opt = false;
+    // (the dropped train programs' tables stay in the bump-allocated workspace until every program is gone -- set_data on the
+    //  last slot hands the space back; set_adam is called once per group, before its first train epoch, when there is nothing to drop)
     return 0;
 }
 
