@@ -329,7 +329,7 @@ def grid_factory(ds, dev, max_epochs=GRID_EPOCHS):
         scoring=["neg_log_loss", "accuracy", "precision_weighted", "recall_weighted", "f1_weighted"])   # config-transformer.yaml:9
 
 
-def grid_folds_per_hour(dev, world, rank, fits_per_gpu=4, lockstep=15):
+def grid_folds_per_hour(dev, world, rank, fits_per_gpu=5, lockstep=15):
     """The other half of BASELINE.json's metric: (candidate x fold) fits per hour of the cross-validated grid search,
     on a bounded sample of config-transformer.yaml's grid -- 96 candidates x cv 5 = 480 fits of 6 epochs over 4000
     synthetic samples (batch 50, len 48, |src| 3000, 200 labels) -- run by ShardedGridSearchCV over all `world`
@@ -504,7 +504,9 @@ def main():
                     help="3: split-bf16 (parity grade, default); 1: single bf16 pass; 8: fp8 forward products (configs[4]'s \"fp8 MFMA weights\")")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true", help="skip the folds/hr leg")
-    ap.add_argument("--fits-per-gpu", type=int, default=4, help="host threads per GPU in the grid leg (each runs work units)")
+    ap.add_argument("--fits-per-gpu", type=int, default=5,
+                    help="host threads per GPU in the grid leg (each runs work units); measured round 4 on one MI355X, same sample: "
+                         "4 / 5 / 6 / 8 threads -> 30.7 / 31.3 / 31.0 / 30.7 k folds/hr (the GPU is the limit from 4)")
     ap.add_argument("--lockstep", type=int, default=15, help="fits per work unit, advanced through one launch sequence, in the grid leg")
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")

@@ -22,6 +22,8 @@
 #   lockstep_rnn lockstep sweep cfg3 / cfg3gru
 #   grid         the bench's grid leg only (folds/hr + CRC)
 #   rehearsal    2 ranks on the one GPU (gloo): bench.py --gpus 2
+#   smoke        __graft_entry__.smoke()
+#   fullgrid     configs[3]: all 324 candidates x cv 5 on one GPU (tools/full_grid.py)
 #   passerr      golden-trajectory errors under (wgrad, dgrad) passes (3,3) / (2,3) / (2,2) (tools/backward_pass_errors.py)
 #   gridcal      grid leg alone at (lockstep x threads) pairs with per-unit logs (tools/bench_grid.py; GRIDCAL="15x1 15x4 5x4")
 #   profile      rocprofv3 kernel traces + PMC passes -> gpurun_out/<tag>/prof (tools/gpu/profile.sh <round>)
@@ -76,6 +78,8 @@ for spec in "$@"; do
                  tail -1 $O/lockstep_$w.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], [(r['K'], r['seq_per_s'], r['ms_per_lockstep_step']) for r in d['results']])"; done ;;
     grid)        timeout -k 10 500 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/grid.json 2> $O/grid.err || { tail -5 $O/grid.err; exit 1; }; line $O/grid.json ;;
     rehearsal)   timeout -k 10 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/rehearsal.json 2> $O/rehearsal.err || { tail -5 $O/rehearsal.err; exit 1; }; line $O/rehearsal.json ;;
+    smoke)       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1 || { tail -5 $O/smoke.txt; exit 1; }; tail -2 $O/smoke.txt ;;
+    fullgrid)    timeout -k 10 600 python tools/full_grid.py --lockstep 15 > $O/full_grid_324x5.json 2> $O/fullgrid.err || { tail -8 $O/fullgrid.err; exit 1; }; cut -c1-400 $O/full_grid_324x5.json ;;
     passerr)     timeout -k 10 400 python tools/backward_pass_errors.py ${PASSERR:-cfg1 cfg2 cfg5} > $O/passerr.jsonl 2> $O/passerr.err || { tail -5 $O/passerr.err; exit 1; }; cat $O/passerr.jsonl ;;
     gridcal)     timeout -k 10 700 python tools/bench_grid.py ${GRIDCAL:-15x1 15x4 5x4} > $O/gridcal.jsonl 2> $O/gridcal.err || { tail -5 $O/gridcal.err; exit 1; }
                  python -c "
