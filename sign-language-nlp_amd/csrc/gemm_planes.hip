@@ -18,10 +18,6 @@
 #include "common.hpp"
 #include "gemm_jobs.hpp"
 
-#ifndef SLNLP_PLANE_INTERLEAVE
-#define SLNLP_PLANE_INTERLEAVE ((SLNLP_PROBE_FENCES & 256) != 0)     // A / B build: make PROBE=256
-#endif
-
 namespace slnlp {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -287,30 +283,6 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                     if (NPB == 2) bl[j] = pfrag32<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, lane);
                 }
             }
-#if SLNLP_PLANE_INTERLEAVE
-            // column-major over the MFMA tiles, and the fragment reads of column j + 1 scheduled between the MFMAs of column j:
-            // the compiler otherwise issues every ds_read of the step, waits for all of them (lgkmcnt(0)) and only then starts the
-            // MFMAs -- with the reads of the next column in flight behind the current column's MFMAs the wave exposes one
-            // column's read latency per step instead of the whole step's.  Each acc[i][j] still receives its products in the
-            // order lo-hi, hi-lo, hi-hi: same bits.
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    if (NPA == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    if (NPB == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-            {
-                constexpr int A_OPS = MT * NPA * (AK ? 1 : 2), B_OPS = NPB * (BK ? 1 : 2), M_OPS = MT * (NPA + NPB - 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, A_OPS + B_OPS, 0);           // A fragments + column 0 of B
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (j + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, B_OPS, 0);   // column j + 1's reads ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, M_OPS, 0);                   // ... behind them column j's MFMAs
-                }
-            }
-#else
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -319,7 +291,6 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                     if (NPB == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-#endif
         }
         if (do_rowsum) {
             // 64 k: thread = row (tid & 63) of every image, k-octet tid >> 6 of the step.  32 k: a step holds 4 octets, so the
