@@ -47,7 +47,7 @@ def fwd(Mtok, Nout, Kin):
     print(f"fwd   {Mtok}x{Nout}x{Kin}: real operands {res[False]:7.1f} us ({fl / res[False] / 1e6:6.1f} TFLOP/s)   aliased {res[True]:7.1f} us "
           f"({fl / res[True] / 1e6:6.1f} TFLOP/s)   memory side costs {100 * (1 - res[True] / res[False]):.0f} %", flush=True)
 
-if len(sys.argv) == 2 and sys.argv[1] == "rounds":
+if len(sys.argv) == 2 and sys.argv[1] in ("rounds", "half"):
     pass
 elif len(sys.argv) > 4:
     run(*[int(v) for v in sys.argv[1:5]], 2, 2)
@@ -64,3 +64,17 @@ if len(sys.argv) == 2 and sys.argv[1] == "rounds":       # does the memory-side 
         fwd(M, 1024, 3072)
     for M in (8192, 16384, 32768, 65536):
         fwd(M, 1024, 1024)
+if len(sys.argv) == 2 and sys.argv[1] == "half":         # only ONE operand aliased: about half the L2 -> LDS bytes per FLOP, what a 256-wide tile would move
+    for (M, N, K) in ((16384, 3072, 1024), (36000, 512, 512), (36000, 1536, 512), (65536, 1024, 3072)):
+        g = torch.Generator().manual_seed(0)
+        X, W = [torch.randn(*s, generator=g).cuda() for s in ((M, K), (N, K))]
+        Xp, Wp = ops.split_planes(X), ops.split_planes(W)
+        res = {}
+        for mode in ("real", "B aliased", "A aliased", "both"):
+            j, Y = ops.plane_job(Xp, Wp, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True)
+            if mode in ("A aliased", "both"): j.lda_p = 0
+            if mode in ("B aliased", "both"): j.ldb_p = 0
+            scr = ops.gemm_group([j], [1])
+            res[mode] = timeit(lambda: ops.gemm_group([j], [1], scr))
+        fl = 2.0 * M * N * K
+        print(f"fwd {M}x{N}x{K}: " + "  ".join(f"{m} {t:.1f} us ({fl / t / 1e6:.0f} TF)" for m, t in res.items()), flush=True)
