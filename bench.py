@@ -172,7 +172,9 @@ def dominant_kernel_roofline(c, precision, dev, workload, in_step=None):
             "algorithmic_bytes_per_launch": 4.0 * (M * E + M * F + E * F) + 4.0 * (M * F + E * F) + 4.0 * M * F,
             "note": "flops = 2 GEMMs x 2mnk (algorithmic: the split-bf16 MFMA passes are not counted; mfma_pipe_frac = executed passes x frac, "
                     "at the 2.4 GHz the 2.5 PF peak assumes -- the chip holds held_clock_ghz under this kernel); bytes = operand planes (hi+lo) read "
-                    "once + fp32 results + result planes; fields with a *_source / source key are read from committed profiles of an earlier run "
+                    "once + fp32 results + result planes; us_per_launch brackets each launch with two HIP events on its stream, which adds the "
+                    "dispatch gap a step really pays (rocprofv3's kernel-only stamps of the same command: us_per_launch_rocprof; two events "
+                    "around nothing read ~5 us on a busy stream, so the bracket is not corrected); fields with a *_source / source key are read from committed profiles of an earlier run "
                     "of this command, everything else is measured in this run"}
 
 
