@@ -309,10 +309,10 @@ int add_rows(const float* in, int64_t ld_in, float* out, int64_t ld_out, int R, 
 int tanh_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t st);
 int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                   float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
-                  hipStream_t st, PlaneOut wp = {});
+                  hipStream_t st, PlaneOut wp = {}, int64_t wp_begin = 0, int64_t wp_end = -1);   // planes written for floats [wp_begin, wp_end); -1: to the end
 int clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
                    float beta1, float beta2, float eps, float weight_decay, float max_norm, float* partials, float* norm_out,
-                   unsigned long long* rng, float* step_f, hipStream_t st, PlaneOut wp = {});
+                   unsigned long long* rng, float* step_f, hipStream_t st, PlaneOut wp = {}, int64_t wp_begin = 0, int64_t wp_end = -1);
 // Which version of a parameter arena a plan's derived data (bf16 weight planes) was made from: every optimizer step and
 // every slnlp_*_params_changed() call moves the arena to a new generation (process-wide table keyed by the arena pointer,
 // because several plans -- one per sequence length -- may share one arena).

@@ -768,9 +768,11 @@ __device__ __forceinline__ void sgd_body(float* __restrict__ p, const float* __r
                                                   long n4, const float* __restrict__ lr_dev, float momentum,
                                                   float max_norm, const float* __restrict__ partials,
                                                   float* __restrict__ norm_out, unsigned long long* __restrict__ rng,
-                                                  PlaneOut wp) {
+                                                  PlaneOut wp, long wp_begin4, long wp_end4) {
     // wp (optional): the updated weights also leave as bf16 hi / lo planes (same offsets as the arena) -- the operand
-    // form the plane GEMMs of the NEXT step stage by LDS-DMA -- instead of a separate pass that re-reads the arena
+    // form the plane GEMMs of the NEXT step stage by LDS-DMA -- instead of a separate pass that re-reads the arena.
+    // Only float4 indices in [wp_begin4, wp_end4) are written: the plan passes the range of the weights that FEED plane GEMMs
+    // (the encoder layers: a third of a Transformer's parameters), the rest of the plane arena has no reader
     __shared__ float red[4];
     // every block re-derives the total in the same fixed order: deterministic, no third launch
     float s = 0.f;
@@ -791,7 +793,7 @@ __device__ __forceinline__ void sgd_body(float* __restrict__ p, const float* __r
         w.x -= lr * b.x; w.y -= lr * b.y; w.z -= lr * b.z; w.w -= lr * b.w;
         reinterpret_cast<float4*>(buf)[i] = b;
         reinterpret_cast<float4*>(p)[i] = w;
-        store_planes4(wp, i * 4, w);
+        if (i >= wp_begin4 && i < wp_end4) store_planes4(wp, i * 4, w);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (norm_out) norm_out[0] = norm;
@@ -802,7 +804,7 @@ SLNLP_ZKERNEL(sgd_kernel, 256, sgd_body)
 
 int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n, const float* lr_dev,
                   float momentum, float max_norm, float* partials, float* norm_out, unsigned long long* rng,
-                  hipStream_t st, PlaneOut wp) {
+                  hipStream_t st, PlaneOut wp, int64_t wp_begin, int64_t wp_end) {
     SLNLP_CHECK_ARG(params && grads && momentum_buf && lr_dev && partials, "clip_sgd_step: null pointer");
     SLNLP_CHECK_ARG(n > 0 && n % 4 == 0, "clip_sgd_step: n=%ld must be a positive multiple of 4", (long)n);
     SLNLP_CHECK_ARG(((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0 && ((uintptr_t)momentum_buf & 15) == 0,
@@ -812,7 +814,8 @@ int clip_sgd_step(float* params, const float* grads, float* momentum_buf, int64_
     int grid = ceil_div(n / 4, 256);
     if (grid > 2048) grid = 2048;
     SLNLP_TRY(zlaunch(sgd_kernel, dim3(grid), 256, 0, st, "sgd",
-                      params, grads, momentum_buf, (long)(n / 4), lr_dev, momentum, max_norm, partials, norm_out, rng, wp));
+                      params, grads, momentum_buf, (long)(n / 4), lr_dev, momentum, max_norm, partials, norm_out, rng, wp,
+                      (long)(wp_begin / 4), (long)(wp_end < 0 ? n / 4 : (wp_end + 3) / 4)));
     return 0;
 }
 
@@ -825,7 +828,8 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __
                                           float* __restrict__ v, long n4, const float* __restrict__ lr_dev, float beta1,
                                           float beta2, float eps, float weight_decay, float max_norm,
                                           const float* __restrict__ partials, float* __restrict__ norm_out,
-                                          unsigned long long* __restrict__ rng, float* __restrict__ step_f, PlaneOut wp) {
+                                          unsigned long long* __restrict__ rng, float* __restrict__ step_f, PlaneOut wp,
+                                          long wp_begin4, long wp_end4) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < OPT_BLOCKS; i += 256) s += partials[i];
@@ -855,7 +859,7 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __
         reinterpret_cast<float4*>(v)[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
         const float4 wn = make_float4(we[0], we[1], we[2], we[3]);
         reinterpret_cast<float4*>(p)[i] = wn;
-        store_planes4(wp, i * 4, wn);
+        if (i >= wp_begin4 && i < wp_end4) store_planes4(wp, i * 4, wn);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (norm_out) norm_out[0] = norm;
@@ -870,7 +874,7 @@ SLNLP_ZKERNEL(adam_count_kernel, 64, adam_count_body)
 
 int clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
                    float beta1, float beta2, float eps, float weight_decay, float max_norm, float* partials, float* norm_out,
-                   unsigned long long* rng, float* step_f, hipStream_t st, PlaneOut wp) {
+                   unsigned long long* rng, float* step_f, hipStream_t st, PlaneOut wp, int64_t wp_begin, int64_t wp_end) {
     SLNLP_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && lr_dev && partials && step_f, "clip_adam_step: null pointer");
     SLNLP_CHECK_ARG(n > 0 && n % 4 == 0, "clip_adam_step: n=%ld must be a positive multiple of 4", (long)n);
     SLNLP_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
@@ -880,7 +884,8 @@ int clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     int grid = ceil_div(n / 4, 256);
     if (grid > 2048) grid = 2048;
     SLNLP_TRY(zlaunch(adam_kernel, dim3(grid), 256, 0, st, "adam", params, grads, exp_avg, exp_avg_sq, (long)(n / 4), lr_dev, beta1, beta2,
-                      eps, weight_decay, max_norm, partials, norm_out, rng, step_f, wp));
+                      eps, weight_decay, max_norm, partials, norm_out, rng, step_f, wp, (long)(wp_begin / 4),
+                      (long)(wp_end < 0 ? n / 4 : (wp_end + 3) / 4)));
     SLNLP_TRY(zlaunch(adam_count_kernel, dim3(1), 64, 0, st, "adam_count", step_f));
     return 0;
 }

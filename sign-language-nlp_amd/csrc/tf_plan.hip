@@ -394,7 +394,7 @@ int slnlp_tf_optim(slnlp_tf_plan* pl, float momentum, float max_norm, void* stre
     SLNLP_TRY(scope.rc);
     SLNLP_TRY(clip_sgd_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, pl->L.total, pl->buf.lr, momentum, max_norm,
                             pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, (hipStream_t)stream,
-                            pl->use_planes ? pl->w.wp.out() : PlaneOut{}));
+                            pl->use_planes ? pl->w.wp.out() : PlaneOut{}, pl->wplane_begin(), pl->wplane_end()));
     if (!recording()) pl->params_stepped();      // (a lockstep replay does this per step itself)
     return 0;
 }
@@ -408,7 +408,7 @@ int slnlp_tf_optim_adam(slnlp_tf_plan* pl, float* exp_avg_sq, float beta1, float
     SLNLP_TRY(scope.rc);
     SLNLP_TRY(clip_adam_step(pl->buf.params, pl->buf.grads, pl->buf.momentum, exp_avg_sq, pl->L.total, pl->buf.lr, beta1, beta2, eps,
                              weight_decay, max_norm, pl->w.opt_partials, pl->buf.scalars + 1, pl->buf.rng, pl->buf.scalars + 2,
-                             (hipStream_t)stream, pl->use_planes ? pl->w.wp.out() : PlaneOut{}));
+                             (hipStream_t)stream, pl->use_planes ? pl->w.wp.out() : PlaneOut{}, pl->wplane_begin(), pl->wplane_end()));
     if (!recording()) pl->params_stepped();
     return 0;
 }

@@ -367,6 +367,10 @@ struct slnlp_tf_plan {
         wplanes_gen = g;
         return 0;
     }
+    // the arena range whose planes have readers: the encoder layers' weights (everything else -- embeddings, the decoder's B-row
+    // GEMMs, the generator -- is read as fp32); the optimizer kernels write planes for this range only
+    long wplane_begin() const { return L.enc.empty() ? 0 : L.enc[0].in_w; }
+    long wplane_end() const { return L.enc.empty() ? 0 : L.encn_w; }
     // the optimizer just rewrote the arena (and, with planes, the planes with it)
     void params_stepped() {
         const unsigned long long g = bump_params_generation(buf.params);
