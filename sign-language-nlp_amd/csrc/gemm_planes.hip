@@ -127,7 +127,8 @@ __device__ unsigned g_ts_n;
 #define TS_MARK(slot) do { } while (0)
 #endif
 
-// One block's work: output tile (bx, by) of the job, K-tiles [kt0, kt1).
+// The K loop of one (passes, operand layouts) variant: accumulators (and A's row sums) of output tile (bm0, bn0) over ring steps
+// [kt0, kt1).  Inlined once per variant into plane_tile, whose tile decoding, split-K meeting and epilogue are the same code for all.
 //
 // Tile geometry (template): BM x BN output tile, 8 waves as 4 (M) x 2 (N), each wave a (BM/4) x (BN/2) sub-tile = MT x NT MFMA
 // tiles of 16 x 16; K-step BKS (64 or 32) through an NST-deep LDS ring.  An operand panel of BM rows is BM/64 plane images,
@@ -137,28 +138,14 @@ __device__ unsigned g_ts_n;
 //   128 x 128 x 64, 2 stages : 32 x 64 per wave -- 12 fragment reads for 24 MFMAs per 32-k, half the L2 -> LDS bytes per FLOP
 //                              (the measured wall of the 64 x 64 tile); 128 KiB, one workgroup per CU.
 //   128 x 128 x 32, 2 stages : the same tile in 64 KiB -- two workgroups per CU again, each other's cover during prologue / epilogue.
-// (256 x 128 tiles and a four-deep 32-k ring were built and measured too: slower -- DESIGN.md, Appendix C.)
-// Split-K, the meeting point and the epilogues are the same code for all; the K partition (in units of 64) does not depend on
-// the geometry, so every geometry accumulates every output element in the same order: identical bits.
+//   256 x 256 x 32, 2 stages : 64 x 128 per wave -- 24 fragment reads for 96 MFMAs, half the operand bytes per FLOP again; 128 KiB,
+//                              one workgroup per CU: launches of many K-steps per tile and several tiles per CU.
+// The K partition (in units of 64) does not depend on the geometry, so every geometry accumulates every output element in the
+// same order: identical bits.
 template <int NSPLIT, bool AK, bool BK, int BM, int BN, int BKS, int NST>
-__device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
-#if SLNLP_PROBE_FENCES == 128
-    unsigned long long ts[TS_W] = {0, 0, 0, 0, 0, 0, 0, 0};
-    struct TsFlush {
-        unsigned long long* t;
-        __device__ ~TsFlush() {
-            if (threadIdx.x == 0) {
-                t[4] = __builtin_amdgcn_s_memrealtime();
-                unsigned hw;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
-                t[5] = ((unsigned long long)hw << 32) | blockIdx.x;
-                const unsigned i = atomicAdd(&g_ts_n, 1u) & (unsigned)(TS_MAX - 1);   // a ring: the last TS_MAX workgroups
-                for (int k = 0; k < TS_W; ++k) g_ts[i][k] = t[k];
-            }
-        }
-    } ts_flush{ts};
-    TS_MARK(0);
-#endif
+__device__ __forceinline__ void plane_kloop(const slnlp_gemm_args& g, unsigned short* smem, int bm0, int bn0, int kt0, int kt1,
+                                            bool do_rowsum, f32x4 (&acc)[BM / 64][BN / 32], float (&rowsum)[BM / PT],
+                                            unsigned long long* ts) {
     // planes per operand: NSPLIT 3 = A_lo B_hi + A_hi B_lo + A_hi B_hi; NSPLIT 2 = A_hi (B_hi + B_lo) -- the A operand (the dY of a
     // gradient product) contributes its bf16 head only, a third less MFMA work and a quarter less staging; NSPLIT 1 = A_hi B_hi
     constexpr int NPA = NSPLIT == 3 ? 2 : 1, NPB = NSPLIT >= 2 ? 2 : 1;
@@ -168,39 +155,12 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
     constexpr int A_IMGS = NPA * SUBM, B_IMGS = NPB * SUBN;
     constexpr int STAGE = (A_IMGS + B_IMGS) * IMG_E;         // A planes then B planes
     constexpr int PIECES = (A_IMGS + B_IMGS) * BKS / 64;     // DMA instructions per wave and stage
-    constexpr int KSUB = PT / BKS;                           // ring steps per 64-k tile
     static_assert(BKS == 64 || (BM % 128 == 0 && BN % 128 == 0), "32-k stages move 128-row slabs");
-    const slnlp_gemm_args& g = job.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * (BM / 4), wn0 = (wave & 1) * (BN / 2);
-    const int nks = job.nks;
-    int bx, by, ks, tile;
-    {   // XCD-aware order (see gemm.hip): each XCD owns a contiguous run of (tile, split) units
-        const int nwg = job.tiles_x * job.tiles_y * nks;
-        const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
-        // split-major unit order: the units of one XCD share a K-slice, so its 4 MiB L2 holds that slice of a few
-        // A / B panels instead of whole panels (measured 5x over-fetch with tile-major order on the weight gradient)
-        const int ntiles = job.tiles_x * job.tiles_y;
-        ks = t / ntiles;
-        tile = t - ks * ntiles;
-        // tiles in groups of GR tile rows, column by column inside a group: the workgroups resident on an XCD at one time
-        // (32 at one per CU, 64 at two) then form a GR x (32 / GR) block of the tile grid whatever tiles_x is, and share its
-        // GR + 32 / GR operand panels through the XCD's L2 instead of fetching 32 + 1
-        constexpr int GR = BM >= 128 ? 4 : 8;
-        const int grp = tile / (GR * job.tiles_x), rem = tile - grp * (GR * job.tiles_x);
-        const int rows_here = min(GR, job.tiles_y - grp * GR);
-        bx = rem / rows_here;
-        by = grp * GR + (rem - bx * rows_here);
-        tile = by * job.tiles_x + bx;                          // (the id the partial tiles and arrival counters use)
-    }
-    const int bm0 = by * BM, bn0 = bx * BN;
-    const int M = g.M, N = g.N, K = g.K;
-    const int ktiles = (K + PT - 1) / PT;
-    const int kt0 = (int)((long)ktiles * ks / nks) * KSUB, kt1 = (int)((long)ktiles * (ks + 1) / nks) * KSUB;   // ring steps
     // planes are zero-padded to multiples of 64 rows; a wider panel may reach further: read the last padded block again
     // instead (its products land in rows >= M / columns >= N, which no epilogue stores)
-    const int am_last = ((M + PT - 1) / PT - 1) * PT, bn_last = ((N + PT - 1) / PT - 1) * PT;
+    const int am_last = ((g.M + PT - 1) / PT - 1) * PT, bn_last = ((g.N + PT - 1) / PT - 1) * PT;
 
     // this wave's DMA pieces of a stage: per operand panel piece a loop-invariant lane offset (bytes inside the plane; planes
     // are far below 4 GiB); the hi and the lo plane of an operand share it
@@ -233,16 +193,6 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         }
     };
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = (g.rowsum_a != nullptr) && (bx == 0);
-    float rowsum[SUBM];                                      // (64 k: one per image; 32 k: image pair p -> [2p] even steps, [2p + 1] odd steps)
-#pragma unroll
-    for (int i = 0; i < SUBM; ++i) rowsum[i] = 0.f;
-
     // NST-deep LDS ring: steps kt+1 .. kt+NST-1 are in flight while step kt is consumed (a K-step's MFMA work is
     // ~0.2 - 0.6 us, one DMA round trip ~1 us).  ONE barrier per step: the stage refilled at step kt was consumed at
     // step kt-1, which every wave has finished once it passes this step's barrier.
@@ -260,7 +210,9 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         const unsigned short* s = smem + (it % NST) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BKS / 32; ++kk) {
-            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+            // (B fragments JB tiles at a time: the 256-wide tile's 4 + 8 tiles x (hi, lo) at once would not leave room for its 128 accumulators)
+            constexpr int JB = NT > 4 ? 4 : NT;
+            bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = wm0 + 16 * i;              // a 16-row MFMA tile never straddles two 64-row images
@@ -273,24 +225,29 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int row = wn0 + 16 * j;
-                if constexpr (BKS == 64) {
-                    bh[j] = pfrag<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, kk, lane);
-                    if (NPB == 2) bl[j] = pfrag<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, kk, lane);
-                } else {
-                    bh[j] = pfrag32<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, lane);
-                    if (NPB == 2) bl[j] = pfrag32<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, lane);
+            for (int j0 = 0; j0 < NT; j0 += JB) {
+                bf16x8 bh[JB], bl[JB];
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    const int row = wn0 + 16 * (j0 + j);
+                    if constexpr (BKS == 64) {
+                        bh[j] = pfrag<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, kk, lane);
+                        if (NPB == 2) bl[j] = pfrag<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, kk, lane);
+                    } else {
+                        bh[j] = pfrag32<BK>(s + (A_IMGS + row / PT) * IMG_E, row % PT, lane);
+                        if (NPB == 2) bl[j] = pfrag32<BK>(s + (A_IMGS + SUBN + row / PT) * IMG_E, row % PT, lane);
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) {
+                        f32x4& c = acc[i][j0 + j];
+                        if (NPA == 2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
+                        if (NPB == 2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+                    }
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (NPA == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    if (NPB == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
         }
         if (do_rowsum) {
             // 64 k: thread = row (tid & 63) of every image, k-octet tid >> 6 of the step.  32 k: a step holds 4 octets, so the
@@ -314,6 +271,85 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 else rowsum[sm] += t;
             }
         }
+    }
+}
+
+// One block's work: output tile (bx, by) of the job, K-tiles [kt0, kt1) -- the K loop of the job's variant, then the split-K
+// meeting and the epilogue, which do not depend on the variant and exist ONCE per kernel.  (The code a workgroup walks through
+// after its K loop is straight-line and cold in the instruction cache -- 64 KiB per two CUs: when every variant carried its own
+// fully unrolled epilogues a 128 x 128 kernel was 316 KiB of code and its workgroups spent 6 us of a 19 us life there, a
+// 256 x 256 one 61 us.  Hence the rolled loops below: only what needs a STATIC accumulator register index is unrolled.)
+template <int NSPLIT, int BM, int BN, int BKS, int NST>
+__device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
+    unsigned long long* tsp = nullptr;
+#if SLNLP_PROBE_FENCES == 128
+    unsigned long long ts[TS_W] = {0, 0, 0, 0, 0, 0, 0, 0};
+    struct TsFlush {
+        unsigned long long* t;
+        __device__ ~TsFlush() {
+            if (threadIdx.x == 0) {
+                t[4] = __builtin_amdgcn_s_memrealtime();
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+                t[5] = ((unsigned long long)hw << 32) | blockIdx.x;
+                const unsigned i = atomicAdd(&g_ts_n, 1u) & (unsigned)(TS_MAX - 1);   // a ring: the last TS_MAX workgroups
+                for (int k = 0; k < TS_W; ++k) g_ts[i][k] = t[k];
+            }
+        }
+    } ts_flush{ts};
+    tsp = ts;
+    TS_MARK(0);
+#endif
+    constexpr int SUBM = BM / PT;                            // 64-row plane images per A panel
+    constexpr int MT = BM / 64, NT = BN / 32;                // 16 x 16 MFMA tiles per wave: (BM/4)/16 x (BN/2)/16
+    constexpr int KSUB = PT / BKS;                           // ring steps per 64-k tile
+    const slnlp_gemm_args& g = job.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * (BM / 4), wn0 = (wave & 1) * (BN / 2);
+    const int nks = job.nks;
+    int bx, by, ks, tile;
+    {   // XCD-aware order (see gemm.hip): each XCD owns a contiguous run of (tile, split) units
+        const int nwg = job.tiles_x * job.tiles_y * nks;
+        const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+        // split-major unit order: the units of one XCD share a K-slice, so its 4 MiB L2 holds that slice of a few
+        // A / B panels instead of whole panels (measured 5x over-fetch with tile-major order on the weight gradient)
+        const int ntiles = job.tiles_x * job.tiles_y;
+        ks = t / ntiles;
+        tile = t - ks * ntiles;
+        // tiles in groups of GR tile rows, column by column inside a group: the workgroups resident on an XCD at one time
+        // (32 at one per CU, 64 at two) then form a GR x (32 / GR) block of the tile grid whatever tiles_x is, and share its
+        // GR + 32 / GR operand panels through the XCD's L2 instead of fetching 32 + 1
+        constexpr int GR = BM >= 256 ? 2 : BM >= 128 ? 4 : 8;
+        const int grp = tile / (GR * job.tiles_x), rem = tile - grp * (GR * job.tiles_x);
+        const int rows_here = min(GR, job.tiles_y - grp * GR);
+        bx = rem / rows_here;
+        by = grp * GR + (rem - bx * rows_here);
+        tile = by * job.tiles_x + bx;                          // (the id the partial tiles and arrival counters use)
+    }
+    const int bm0 = by * BM, bn0 = bx * BN;
+    const int M = g.M, N = g.N, K = g.K;
+    const int ktiles = (K + PT - 1) / PT;
+    const int kt0 = (int)((long)ktiles * ks / nks) * KSUB, kt1 = (int)((long)ktiles * (ks + 1) / nks) * KSUB;   // ring steps
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (g.rowsum_a != nullptr) && (bx == 0);
+    float rowsum[SUBM];                                      // (64 k: one per image; 32 k: image pair p -> [2p] even steps, [2p + 1] odd steps)
+#pragma unroll
+    for (int i = 0; i < SUBM; ++i) rowsum[i] = 0.f;
+
+    // variants 3, 4 (launches of the split-bf16 family only): the gradient products of one dY with its bf16 head alone (precision 2)
+    // (a two-pass stage is 3/4 of a three-pass one: THREE of them fit where two of those do -- a prefetch distance of two K-steps)
+    if (job.variant == 0) plane_kloop<NSPLIT, true, true, BM, BN, BKS, NST>(g, smem, bm0, bn0, kt0, kt1, do_rowsum, acc, rowsum, tsp);
+    else if (job.variant == 1) plane_kloop<NSPLIT, true, false, BM, BN, BKS, NST>(g, smem, bm0, bn0, kt0, kt1, do_rowsum, acc, rowsum, tsp);
+    else if (job.variant == 2) plane_kloop<NSPLIT, false, false, BM, BN, BKS, NST>(g, smem, bm0, bn0, kt0, kt1, do_rowsum, acc, rowsum, tsp);
+    else if constexpr (NSPLIT == 3) {
+        if (job.variant == 3) plane_kloop<2, true, false, BM, BN, BKS, NST + 1>(g, smem, bm0, bn0, kt0, kt1, do_rowsum, acc, rowsum, tsp);
+        else plane_kloop<2, false, false, BM, BN, BKS, NST + 1>(g, smem, bm0, bn0, kt0, kt1, do_rowsum, acc, rowsum, tsp);
     }
     TS_MARK(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the dummy prefetches before LDS is reused / freed
@@ -355,7 +391,7 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), mine, ((i * NT + j) * PTHREADS + tid) * 16, 0, SC);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), mine, tid * 16, (i * NT + j) * PTHREADS * 16, SC);
         if (do_rowsum && tid < BM)
             __hip_atomic_store(job.part_rs + ((long)by * nks + ks) * BM + tid, rs_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -379,119 +415,164 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         rs_row = 0.f;
-        for (int s = 0; s < nks; ++s) {                      // fixed order: the result does not depend on arrival order
-            const __amdgpu_buffer_rsrc_t q =
-                __builtin_amdgcn_make_buffer_rsrc(job.part + ((long)tile * nks + s) * TILE_FLOATS, 0, TILE_FLOATS * 4, 0x00020000);
+        // fixed order: the result does not depend on arrival order.  (The widest tile adds its partials half a tile at a time: all 32
+        // loads of a split in flight beside the 128 accumulators would spill.)
+        constexpr int HALVES = MT * NT > 16 ? 2 : 1, MH = MT / HALVES;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int half = 0; half < HALVES; ++half) {
+#pragma unroll 1
+            for (int s = 0; s < nks; ++s) {
+                const __amdgpu_buffer_rsrc_t q =
+                    __builtin_amdgcn_make_buffer_rsrc(job.part + ((long)tile * nks + s) * TILE_FLOATS, 0, TILE_FLOATS * 4, 0x00020000);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(q, ((i * NT + j) * PTHREADS + tid) * 16, 0, SC);
-                    acc[i][j] += __builtin_bit_cast(f32x4, p);
-                }
-            if (do_rowsum && tid < BM)
-                rs_row += __hip_atomic_load(job.part_rs + ((long)by * nks + s) * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = half * MH; i < (half + 1) * MH; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(q, tid * 16, (i * NT + j) * PTHREADS * 16, SC);
+                        acc[i][j] += __builtin_bit_cast(f32x4, p);
+                    }
+                if (half == 0 && do_rowsum && tid < BM)
+                    rs_row += __hip_atomic_load(job.part_rs + ((long)by * nks + s) * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (tid == 0) __hip_atomic_store(job.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     if (do_rowsum && tid < BM && bm0 + tid < M) g.rowsum_a[bm0 + tid] = rs_row;
     TS_MARK(3);
 
-    // ---- epilogue: +bias -> activation -> gate -> dropout -> +resid ; fp32 store (+ optional bf16 planes)
+    // ---- epilogue: +bias -> activation -> gate -> dropout -> +resid ; fp32 store (+ optional bf16 planes), through an fp32 image
+    // of the tile in LDS, ER = 128 rows at a time (a 256 x 260 image would not fit): chunk `ch` is written by the waves that own its
+    // rows and stored by all eight.
+    //  (1a) the accumulators go to the image as they are (unrolled: static register indices, four ds_write each);
+    //  (1b) jobs with dropout (or tanh) only: in the accumulator layout still -- a lane holds 4 rows x 1 column of a 16 x 16 tile,
+    //       and one Philox call serves those 4 rows -- every lane takes its own values through bias, activation, gate and dropout
+    //       IN the image, one ROLLED loop over its MT x NT tiles (its own words: no barrier between 1a and 1b; the bias comes from
+    //       an LDS copy, a global load per iteration would put its latency on every one of them);
+    //  (2)  row-major: a thread takes 4 consecutive columns of a row -- bias, ReLU and gate here for the jobs that skipped 1b,
+    //       residual -- and writes ONE 16-byte fp32 store and two 8-byte plane stores (scalar pieces when the job's pointers /
+    //       strides do not allow vectors); gate and residual pieces of eight passes are requested up front.
+    // The element-wise arithmetic and its order are those of a plain per-element epilogue: results do not depend on the route.
+    constexpr int SLD = BN + 4, ER = BM > 128 ? 128 : BM, ECH = BM / ER;
     const int crow = (lane >> 4) << 2, ccol = lane & 15;
-    if (job.vec_out) {
-        // Two phases.  (1) In the accumulator layout (a lane holds 4 rows x 1 column): bias, activation, gate and dropout -- the
-        // Philox call serves the lane's 4 rows -- and the value goes to an LDS image of the tile.  (2) Row-major: each thread
-        // takes 4 consecutive columns of a row, adds the residual and writes ONE 16-byte fp32 store and two 8-byte plane
-        // stores.  The accumulator layout alone needs 8 dword + 16 short stores per lane in 64- / 32-byte row segments;
-        // the element-wise arithmetic and its order are the same, so results are bit-identical.
-        constexpr int SLD = BN + 4;
-        float* stg = reinterpret_cast<float*>(smem);
-        __syncthreads();                                     // every thread is done with the K-loop stages / the split-K flag
+    float* stg = reinterpret_cast<float*>(smem);
+    float* sbias = stg + ER * SLD;                           // [BN] behind the image (and behind the row-sum table / flag above)
+    const bool early = g.drop_p > 0.f || g.relu == 2;        // block-uniform
+    if (early && tid < BN) sbias[tid] = (g.bias && bn0 + tid < N) ? g.bias[bn0 + tid] : 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < ECH; ++ch) {
+        __syncthreads();                                     // every thread is done with the K-loop stages / the split-K flag / the last chunk
+        if (ECH == 1 || wm0 / ER == ch) {                    // (wave-uniform)
+            const int lr0 = wm0 - ch * ER + crow, lc0 = wn0 + ccol;     // this lane's rows / column inside the chunk's image, tile (0, 0)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int lm0 = wm0 + 16 * i + crow, ln = wn0 + 16 * j + ccol;
-                const int gm0 = bm0 + lm0, gn = bn0 + ln;
-                const bool live = gn < N && gm0 < M;
-                const float bias = (live && g.bias) ? g.bias[gn] : 0.f;
-                uint4 bits = make_uint4(0, 0, 0, 0);
-                if (live && g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gm = gm0 + r;
-                    float v = acc[i][j][r] + bias;
-                    if (g.relu == 1) v = fmaxf(v, 0.f);
-                    else if (g.relu == 2) v = tanhf(v);
-                    if (live && gm < M) {
-                        if (g.gate) {
-                            const float gt = g.gate[(long)gm * g.ldg + gn];
-                            v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
+                    for (int r = 0; r < 4; ++r) stg[(lr0 + 16 * i + r) * SLD + lc0 + 16 * j] = acc[i][j][r];
+            if (early) {
+#pragma unroll 1
+                for (int t = 0; t < MT * NT; ++t) {
+                    const int lm0 = lr0 + 16 * (t / NT), ln = lc0 + 16 * (t % NT);
+                    const int gm0 = bm0 + ch * ER + lm0, gn = bn0 + ln;
+                    if (gn >= N || gm0 >= M) continue;       // (never stored)
+                    const float bias = sbias[ln];
+                    uint4 bits = make_uint4(0, 0, 0, 0);
+                    if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gm = gm0 + r;
+                        float v = stg[(lm0 + r) * SLD + ln] + bias;
+                        if (g.relu == 1) v = fmaxf(v, 0.f);
+                        else if (g.relu == 2) v = tanhf(v);
+                        if (gm < M) {
+                            if (g.gate) {
+                                const float gt = g.gate[(long)gm * g.ldg + gn];
+                                v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
+                            }
+                            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
                         }
-                        if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                        stg[(lm0 + r) * SLD + ln] = v;
                     }
-                    stg[(lm0 + r) * SLD + ln] = v;
-                }
-            }
-        // the residual pieces of ALL passes are requested before the barrier: resid may alias C (an in-place add), so inside the
-        // store loop the compiler has to keep every load behind the previous pass's stores -- eight serialised round trips for a
-        // 128 x 128 tile; a thread only ever reads the elements it is about to write, so reading them all up front is safe
-        constexpr int NPASS = BM * BN / 4 / PTHREADS;
-        float4 rr[NPASS];
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int piece = pass * PTHREADS + tid, row = piece / (BN / 4), c4 = (piece % (BN / 4)) << 2;
-            const int gm = bm0 + row, gn = bn0 + c4;
-            rr[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.resid && gm < M && gn < N) rr[pass] = *reinterpret_cast<const float4*>(g.resid + (long)gm * g.ldr + gn);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int piece = pass * PTHREADS + tid, row = piece / (BN / 4), c4 = (piece % (BN / 4)) << 2;
-            const int gm = bm0 + row, gn = bn0 + c4;
-            if (gm >= M || gn >= N) continue;                 // N % 4 == 0 (vec_out): a live piece is 4 live columns
-            float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
-            if (g.resid) { v.x += rr[pass].x; v.y += rr[pass].y; v.z += rr[pass].z; v.w += rr[pass].w; }
-            if (g.C) *reinterpret_cast<float4*>(g.C + (long)gm * g.ldc + gn) = v;
-            if (g.C_hi) {
-                PlaneOut po;
-                po.hi = g.C_hi;
-                po.lo = g.C_lo;
-                if (g.C_lo) store_planes4(po, (long)gm * g.ldc_p + gn, v);
-                else {
-                    uint2 w;
-                    w.x = head_bf16(v.x) | ((unsigned)head_bf16(v.y) << 16);
-                    w.y = head_bf16(v.z) | ((unsigned)head_bf16(v.w) << 16);
-                    *reinterpret_cast<uint2*>(g.C_hi + (long)gm * g.ldc_p + gn) = w;
                 }
             }
         }
-        return;
-    }
+        const int gmc = bm0 + ch * ER;                       // first row of the chunk
+        const bool late_gate = !early && g.gate;
+        if (job.vec_out) {
+            // the residual (and gate) pieces of eight passes are requested before they are needed: resid may alias C (an in-place
+            // add), so inside the store loop the compiler has to keep every load behind the previous pass's stores -- eight
+            // serialised round trips for a 128 x 128 tile; a thread only ever reads the elements it is about to write, so reading
+            // them up front is safe.  (Eight at a time: 64 registers beside the accumulators the other chunk's waves still hold.)
+            constexpr int NPASS = ER * BN / 4 / PTHREADS, PB = NPASS > 8 ? 8 : NPASS;
+            static_assert(PTHREADS % (BN / 4) == 0, "a thread keeps its four columns over the passes");
+            const int c4 = (tid % (BN / 4)) << 2, gn = bn0 + c4, row0 = tid / (BN / 4);
+            constexpr int RSTEP = PTHREADS / (BN / 4);       // rows between a thread's passes
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!early && g.bias && gn < N) b4 = *reinterpret_cast<const float4*>(g.bias + gn);
+#pragma unroll 1
+            for (int pb = 0; pb < NPASS; pb += PB) {
+                float4 rr[PB], gg[PB];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int gm0 = bm0 + wm0 + 16 * i + crow;
-            const int gn = bn0 + wn0 + 16 * j + ccol;
-            if (gn >= N || gm0 >= M) continue;
-            const float bias = g.bias ? g.bias[gn] : 0.f;
-            uint4 bits = make_uint4(0, 0, 0, 0);
-            if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = gm0 + r;
-                if (gm >= M) break;
-                float v = acc[i][j][r] + bias;
-                if (g.relu == 1) v = fmaxf(v, 0.f);
-                else if (g.relu == 2) v = tanhf(v);
-                if (g.gate) {
-                    const float gt = g.gate[(long)gm * g.ldg + gn];
-                    v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
+                for (int pass = 0; pass < PB; ++pass) {
+                    const int gm = gmc + row0 + (pb + pass) * RSTEP;
+                    rr[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    gg[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.resid && gm < M && gn < N) rr[pass] = *reinterpret_cast<const float4*>(g.resid + (long)gm * g.ldr + gn);
+                    if (late_gate && gm < M && gn < N) gg[pass] = *reinterpret_cast<const float4*>(g.gate + (long)gm * g.ldg + gn);
                 }
-                if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                if (pb == 0) __syncthreads();
+#pragma unroll
+                for (int pass = 0; pass < PB; ++pass) {
+                    const int row = row0 + (pb + pass) * RSTEP, gm = gmc + row;
+                    if (gm >= M || gn >= N) continue;         // N % 4 == 0 (vec_out): a live piece is 4 live columns
+                    float4 v = *reinterpret_cast<const float4*>(stg + row * SLD + c4);
+                    if (!early) {
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                        if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (late_gate) {
+                            const float4 t = gg[pass];
+                            // (__fmul_rn: the product is rounded before the residual is added -- never contracted into an FMA with
+                            // it -- as on the route through the accumulator layout, where an LDS round trip separates the two)
+                            if (g.gate_mode == 1) {
+                                v.x = __fmul_rn(v.x, 1.f - t.x * t.x); v.y = __fmul_rn(v.y, 1.f - t.y * t.y);
+                                v.z = __fmul_rn(v.z, 1.f - t.z * t.z); v.w = __fmul_rn(v.w, 1.f - t.w * t.w);
+                            } else {
+                                v.x = t.x > 0.f ? __fmul_rn(v.x, g.gate_scale) : 0.f; v.y = t.y > 0.f ? __fmul_rn(v.y, g.gate_scale) : 0.f;
+                                v.z = t.z > 0.f ? __fmul_rn(v.z, g.gate_scale) : 0.f; v.w = t.w > 0.f ? __fmul_rn(v.w, g.gate_scale) : 0.f;
+                            }
+                        }
+                    }
+                    if (g.resid) { v.x += rr[pass].x; v.y += rr[pass].y; v.z += rr[pass].z; v.w += rr[pass].w; }
+                    if (g.C) *reinterpret_cast<float4*>(g.C + (long)gm * g.ldc + gn) = v;
+                    if (g.C_hi) {
+                        PlaneOut po;
+                        po.hi = g.C_hi;
+                        po.lo = g.C_lo;
+                        if (g.C_lo) store_planes4(po, (long)gm * g.ldc_p + gn, v);
+                        else {
+                            uint2 w;
+                            w.x = head_bf16(v.x) | ((unsigned)head_bf16(v.y) << 16);
+                            w.y = head_bf16(v.z) | ((unsigned)head_bf16(v.w) << 16);
+                            *reinterpret_cast<uint2*>(g.C_hi + (long)gm * g.ldc_p + gn) = w;
+                        }
+                    }
+                }
+            }
+        } else {
+            __syncthreads();
+#pragma unroll 1
+            for (int e = tid; e < ER * BN; e += PTHREADS) {
+                const int row = e / BN, col = e % BN, gm = gmc + row, gn = bn0 + col;
+                if (gm >= M || gn >= N) continue;
+                float v = stg[row * SLD + col];
+                if (!early) {
+                    if (g.bias) v += g.bias[gn];
+                    if (g.relu == 1) v = fmaxf(v, 0.f);
+                    if (g.gate) {
+                        const float gt = g.gate[(long)gm * g.ldg + gn];
+                        v = g.gate_mode == 1 ? __fmul_rn(v, 1.f - gt * gt) : (gt > 0.f ? __fmul_rn(v, g.gate_scale) : 0.f);
+                    }
+                }
                 if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
                 if (g.C) g.C[(long)gm * g.ldc + gn] = v;
                 if (g.C_hi) {
@@ -502,6 +583,7 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
                 }
             }
         }
+    }
 }
 
 // `tab` != nullptr: a merged (lockstep) launch -- the jobs of K fits in a device-resident table, blockmap[block] = job
@@ -693,8 +775,8 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
 
 // GEO: the launch's tile geometry (table below); every job of a launch uses it (the host picks it per launch: plane_geo_for()).
 struct GeoInfo { int bm, bn, bks, nst; };
-constexpr int NGEO = 3;
-constexpr GeoInfo GEO[NGEO] = {{64, 64, 64, 2}, {128, 128, 64, 2}, {128, 128, 32, 2}};
+constexpr int NGEO = 4;
+constexpr GeoInfo GEO[NGEO] = {{64, 64, 64, 2}, {128, 128, 64, 2}, {128, 128, 32, 2}, {256, 256, 32, 2}};
 
 template <int NSPLIT, int G>
 __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
@@ -715,13 +797,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupP
     if (lid >= job.tiles_x * job.tiles_y * job.nks) return;                 // padding block of a merged launch (jobs start on multiples of 8)
     constexpr GeoInfo g = GEO[G];
     probe_kernel_begin();
-    // variants 3, 4 (launches of the split-bf16 family only): the gradient products of one dY with its bf16 head alone (precision 2)
-    if (job.variant == 0) plane_tile<NSPLIT, true, true, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
-    else if (job.variant == 1) plane_tile<NSPLIT, true, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
-    else if (job.variant == 2) plane_tile<NSPLIT, false, false, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
-    // (a two-pass stage is 3/4 of a three-pass one: THREE of them fit where two of those do -- a prefetch distance of two K-steps)
-    else if (NSPLIT == 3 && job.variant == 3) plane_tile<2, true, false, g.bm, g.bn, g.bks, g.nst + 1>(job, lid, smem);
-    else if (NSPLIT == 3) plane_tile<2, false, false, g.bm, g.bn, g.bks, g.nst + 1>(job, lid, smem);
+    plane_tile<NSPLIT, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
     probe_kernel_end();
 }
 
@@ -732,7 +808,7 @@ constexpr size_t plane_lds(int geo) {
     const size_t ring3 = (size_t)GEO[geo].nst * 2 * (GEO[geo].bm + GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);
     const size_t ring2 = (size_t)(GEO[geo].nst + 1) * (GEO[geo].bm + 2 * GEO[geo].bn) * GEO[geo].bks * sizeof(unsigned short);   // two-pass jobs: one stage more
     const size_t ring = ring3 > ring2 ? ring3 : ring2;
-    const size_t image = (size_t)GEO[geo].bm * (GEO[geo].bn + 4) * sizeof(float);
+    const size_t image = ((size_t)(GEO[geo].bm > 128 ? 128 : GEO[geo].bm) * (GEO[geo].bn + 4) + GEO[geo].bn) * sizeof(float);   // (128 rows at a time, + the bias row)
     return ring > image ? ring : image;
 }
 constexpr int GROUP_COUNTERS = 4096;                       // ints at the head of the scratch buffer
@@ -793,7 +869,7 @@ static int splitk_mode() {
 }
 
 // ---- which geometry a launch uses.  -1 = automatic (plane_geo_for), 0 .. NGEO-1 = forced (slnlp_set_plane_tile: tuning, tests)
-static int geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 12832 ? 2 : -1; }
+static int geo_of_knob(int knob) { return knob == 64 ? 0 : knob == 128 ? 1 : knob == 12832 ? 2 : knob == 256 ? 3 : -1; }
 static std::atomic<int> g_plane_geo{[] { const char* e = getenv("SLNLP_PLANE_TILE"); return geo_of_knob(e ? atoi(e) : 0); }()};
 constexpr int BIG_TILE_MIN_UNITS = 200;    // a launch takes 128 x 128 tiles when it still has at least this many of them
 
@@ -876,14 +952,14 @@ static int check_plane_job(const slnlp_gemm_args& a) {
 }
 
 // split-K scratch: arrival counters, then per job its partial tiles [tile][split][bm x bn] and row sums [tile_y][split][bm].
-// Sized for whichever geometry the launch may take (M rounded up to 256, N to 128 cover all of them).
+// Sized for whichever geometry the launch may take (M and N rounded up to 256 cover all of them).
 size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
     size_t floats = 0;
     for (int i = 0; i < njobs; ++i) {
         const int nks = split_k ? split_k[i] : 1;
         if (nks <= 1) continue;
-        const size_t n128 = (size_t)ceil_div(jobs[i].N, 128) * 128, m256 = (size_t)ceil_div(jobs[i].M, 256) * 256;
-        floats += n128 * m256 * nks + m256 * nks;
+        const size_t n256 = (size_t)ceil_div(jobs[i].N, 256) * 256, m256 = (size_t)ceil_div(jobs[i].M, 256) * 256;
+        floats += n256 * m256 * nks + m256 * nks;
     }
     return GROUP_COUNTERS * sizeof(int) + floats * sizeof(float);
 }
@@ -932,9 +1008,9 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
             j.counters = reinterpret_cast<int*>(scratch) + ctr;
             ctr += tiles;
             j.part = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + off);
-            // region sizes do not depend on the geometry (M rounded up to 256, N to 128): a merged launch may re-tile the job
-            const size_t n128 = (size_t)ceil_div(a.N, 128) * 128, m256 = (size_t)ceil_div(a.M, 256) * 256;
-            off += n128 * m256 * nks * sizeof(float);
+            // region sizes do not depend on the geometry (M and N rounded up to 256): a merged launch may re-tile the job
+            const size_t n256 = (size_t)ceil_div(a.N, 256) * 256, m256 = (size_t)ceil_div(a.M, 256) * 256;
+            off += n256 * m256 * nks * sizeof(float);
             j.part_rs = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + off);
             off += m256 * nks * sizeof(float);
             SLNLP_CHECK_ARG(off <= scratch_bytes, "gemm_group: scratch too small (%zu > %zu bytes)", off, scratch_bytes);
@@ -1012,6 +1088,7 @@ static const void* kernel_of(int geo) {
     switch (geo) {
         case 1: return (const void*)gemm_planes_kernel<NSPLIT, 1>;
         case 2: return (const void*)gemm_planes_kernel<NSPLIT, 2>;
+        case 3: return (const void*)gemm_planes_kernel<NSPLIT, 3>;
         default: return (const void*)gemm_planes_kernel<NSPLIT, 0>;
     }
 }
@@ -1091,7 +1168,7 @@ extern "C" int slnlp_quant_rows_fp8(const float* x, int64_t ld, int R, int K, ui
 
 extern "C" int slnlp_set_plane_tile(int tile) {
     if (tile != 0 && slnlp::geo_of_knob(tile) < 0) {
-        slnlp::set_error("set_plane_tile: %d (0 = automatic, 64, 128, 12832 = 128 x 128 with 32-k stages)", tile);
+        slnlp::set_error("set_plane_tile: %d (0 = automatic, 64, 128, 12832 = 128 x 128 with 32-k stages, 256 = 256 x 256 with 32-k stages)", tile);
         return SLNLP_ERR_INVALID_ARG;
     }
     slnlp::g_plane_geo.store(slnlp::geo_of_knob(tile), std::memory_order_relaxed);

@@ -306,8 +306,8 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
     }
     {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
-        // (the weight gradients' partial tiles: [3E or F] x [E or F] outputs rounded up to the 128 x 128 tile, x MAX_SPLITK)
-        const size_t nx = ((E > F ? E : F) + 127) / 128 * 128, ny = ((3 * E > F ? 3 * E : F) + 255) / 256 * 256;
+        // (the weight gradients' partial tiles: [3E or F] x [E or F] outputs rounded up to the widest (256 x 256) tile, x MAX_SPLITK)
+        const size_t nx = ((E > F ? E : F) + 255) / 256 * 256, ny = ((3 * E > F ? 3 * E : F) + 255) / 256 * 256;
         w.gscr_bytes = 16384 + nx * ny * MAX_SPLITK * sizeof(float) + ny * MAX_SPLITK * sizeof(float);
         w.gscr_bytes = (w.gscr_bytes + 255) & ~(size_t)255;
         w.gscr[0] = b.take<char>(w.gscr_bytes);

@@ -389,6 +389,64 @@ def test_gemm_planes_epilogue_and_output_planes(ops):
     assert float(hi[M:].abs().max()) == 0 and float(hi[:, N:].abs().max()) == 0   # padding untouched
 
 
+@pytest.mark.parametrize("knob", [64, 128, 12832, 256])
+def test_plane_epilogue_is_the_per_element_composition_bit_for_bit(ops, knob):
+    """The plane GEMM's epilogue takes two routes through an LDS image of the tile -- bias / ReLU / gate / residual row-major for
+    jobs without dropout, everything up to the dropout in the accumulator layout for the others -- and both must be the plain
+    per-element chain  +bias -> ReLU -> gate -> dropout -> +residual  in fp32, one rounding per operation: held bit for bit
+    against that chain applied by torch to the kernel's own raw product, at every tile geometry, on vector and scalar stores
+    (N % 4 != 0), ragged edges, an in-place residual, and with the output planes equal to the split of the fp32 result."""
+    from slnlp._lib import load, check
+    import numpy as np
+    rng = ops.make_rng(seed=99, step=3)
+    p = 0.25
+    scale_d = torch.tensor(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))      # the kernel's 1 / (1 - p) in fp32
+    try:
+        check(load().slnlp_set_plane_tile(knob), "set_plane_tile")
+        for (M, N, K) in [(300, 200, 128), (700, 384, 192), (130, 70, 100), (520, 264, 64)]:
+            A, B, bias, R, G = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+            pad = lambda x: torch.nn.functional.pad(x, (0, (-x.shape[1]) % 4))
+            Ap, Bp = ops.split_planes(pad(A).cuda()), ops.split_planes(pad(B).cuda())
+            raw = ops.gemm_planes(Ap, Bp, M=M, N=N, K=K).clone()
+            biasc, Rc, Gc = bias.cuda(), R.cuda(), G.cuda()
+            mask = ops.dropout_mask(M, N, p, 6, rng) > 0
+            zero = torch.zeros((), device="cuda")
+            def run(**kw):
+                j, out = ops.plane_job(Ap, Bp, M=M, N=N, K=K, bias=kw.get("bias"), relu=kw.get("relu", False), resid=kw.get("resid"),
+                                       out=kw.get("out"))
+                if kw.get("gate") is not None:
+                    j.gate, j.ldg, j.gate_mode, j.gate_scale = kw["gate"].data_ptr(), kw["gate"].stride(0), kw.get("gate_mode", 0), 1.25
+                if kw.get("drop"):
+                    j.drop_p, j.drop_site, j.rng = p, 6, rng.data_ptr()
+                planes = None
+                if kw.get("planes") and N % 4 == 0:
+                    planes = ops.split_planes(torch.zeros(M, N).cuda())
+                    j.C_hi, j.C_lo, j.ldc_p = planes[0].data_ptr(), planes[1].data_ptr(), planes[0].stride(0)
+                ops.gemm_group([j], [1])
+                torch.cuda.synchronize()
+                return out, planes
+            # without dropout: bias -> ReLU -> gate (both modes) -> residual
+            out, planes = run(bias=biasc, relu=True, gate=Gc, resid=Rc, planes=True)
+            want = torch.where(Gc > 0, torch.relu(raw + biasc) * 1.25, zero) + Rc
+            assert torch.equal(out, want), (knob, M, N, K, "late route")
+            if planes is not None:
+                hi, lo = ops.split_planes(want)
+                assert torch.equal(planes[0][:M, :N], hi[:M, :N]) and torch.equal(planes[1][:M, :N], lo[:M, :N])
+            out, _ = run(gate=Gc, gate_mode=1, resid=Rc)
+            g_two_roundings, g_fused = 1.0 - Gc * Gc, (1.0 - Gc.double() * Gc.double()).float()      # 1 - g^2 with or without an FMA
+            assert torch.equal(out, raw * g_two_roundings + Rc) or torch.equal(out, raw * g_fused + Rc), (knob, M, N, K, "tanh gate")
+            # with dropout: the same chain, the mask of the dump kernel, 1 / (1 - p) in fp32
+            out, _ = run(bias=biasc, relu=True, gate=Gc, drop=True, resid=Rc)
+            want = torch.where(mask, torch.where(Gc > 0, torch.relu(raw + biasc) * 1.25, zero) * scale_d.cuda(), zero) + Rc
+            assert torch.equal(out, want), (knob, M, N, K, "dropout route")
+            # in-place residual: C += product
+            buf = Rc.clone()
+            run(bias=biasc, resid=buf, out=buf)
+            assert torch.equal(buf, (raw + biasc) + Rc)
+    finally:
+        load().slnlp_set_plane_tile(0)
+
+
 @pytest.mark.parametrize("split", [1, 4, 7])
 def test_gemm_group_dgrad_wgrad_one_launch(ops, split):
     """Data- and weight-gradient of one dY in ONE launch (gemm_planes.hip group kernel); the weight gradient's long
@@ -444,7 +502,7 @@ def test_gemm_group_large_shapes_split_k_and_epilogue(ops):
     assert rel((hi.view(torch.bfloat16).float() + lo.view(torch.bfloat16).float())[:M, :N], ref) < 1e-4
 
 
-@pytest.mark.parametrize("knob", [128, 12832])
+@pytest.mark.parametrize("knob", [128, 12832, 256])
 def test_plane_tile_geometries_return_the_bits_of_the_64_tile(ops, knob):
     """Every tile geometry of the plane GEMM (slnlp_set_plane_tile: 128 x 128 with 64-k or 32-k stages) accumulates
     every output element in the order of the 64 x 64 tile -- the K partition is the same -- so a launch may take whichever is
@@ -513,7 +571,7 @@ def test_two_pass_gradient_products_equal_the_product_with_the_bf16_head_of_dY(o
         return [dW.clone(), rs.clone(), dX.clone(), dX3.clone()]
     try:
         outs = {}
-        for knob in (64, 128, 12832):
+        for knob in (64, 128, 12832, 256):
             check(load().slnlp_set_plane_tile(knob), "set_plane_tile")
             outs[knob] = run()
     finally:
@@ -522,7 +580,7 @@ def test_two_pass_gradient_products_equal_the_product_with_the_bf16_head_of_dY(o
     assert rel(dW, dYh.T @ X.double()) < 1e-4 and rel(dX, dYh @ W.double()) < 1e-4 and rel(rs, dYh.sum(0)) < 1e-4
     assert rel(dX3, dY.double() @ W.double()) < 1e-4
     assert 1e-5 < rel(dW, dY.double().T @ X.double()) < 2e-3 and rel(dX, dY.double() @ W.double()) < 2e-3
-    for knob in (128, 12832):
+    for knob in (128, 12832, 256):
         for a, b in zip(outs[64], outs[knob]):
             assert torch.equal(a, b), f"geometry {knob} differs from the 64 x 64 tile"
 

@@ -84,8 +84,9 @@ keep = []
 import os
 WPASS, DPASS = [int(v) for v in os.environ.get("PLANE_PASSES", "3,3").split(",")]   # split-bf16 passes of the wgrad / dgrad jobs
 print(f"passes: wgrad {WPASS}, dgrad {DPASS} (FLOP/s are algorithmic: 2 m n k per product whatever the passes)")
-TILES = (64, 128, 12832)                    # slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages, 128 KiB), 128 x 128 (32-k x 2, 64 KiB)
-DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128)}
+# slnlp_set_plane_tile knobs: 64 x 64, 128 x 128 (64-k x 2 stages, 128 KiB), 128 x 128 (32-k x 2, 64 KiB), 256 x 256 (32-k x 2, 128 KiB)
+TILES = (64, 128, 12832, 256)
+DIMS = {64: (64, 64), 128: (128, 128), 12832: (128, 128), 256: (256, 256)}
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 big_only = len(sys.argv) > 1 and sys.argv[1] == "big"
 ok = True
@@ -97,6 +98,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "fwd":      # forward launches (no split
         ok &= fwd_case("15 fits in_proj 36000x1536x512" + tag, 36000, 1536, 512, pl)
         ok &= fwd_case("configs[4] FFN 16384x512x1024" + tag, 16384, 512, 1024, pl)
         ok &= fwd_case("configs[4] in_proj 16384x3072x1024" + tag, 16384, 3072, 1024, pl)
+        ok &= fwd_case("configs[4] FFN2 16384x1024x3072" + tag, 16384, 1024, 3072, pl)
+        ok &= fwd_case("ragged 1000x328x192" + tag, 1000, 328, 192, pl)
     print("ALL TILES BIT-IDENTICAL" if ok else "TILE MISMATCH")
     sys.exit(0 if ok else 1)
 if not big_only:
