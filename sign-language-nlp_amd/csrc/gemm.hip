@@ -340,41 +340,69 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * NT + j) * 4 + r) * 256 + tid];
     }
 
-    // ---- epilogue: +bias -> relu -> gate -> dropout -> +resid
-    const int crow = (lane >> 4) << 2, ccol = lane & 15;
+    // ---- epilogue: +bias -> relu -> gate -> dropout -> +resid, through an fp32 image of the tile in LDS (the stage images are free).
+    // Straight out of the accumulator layout -- MT x NT tiles x 4 rows unrolled, a Philox per tile (per ROW with per-head dropout) and
+    // a tanh per element inlined 16 times -- the epilogue was three quarters of this kernel's code (5100 of 6900 instructions at the
+    // 64-wide tile): straight-line code every workgroup walks once, cold in the instruction cache.  Now the accumulators go to the
+    // image as they are and ONE rolled loop takes "quads" -- 4 consecutive rows x 1 column, the unit one Philox call serves -- through
+    // the chain; consecutive lanes hold consecutive columns, so the stores are whole 64-float rows instead of 16-float segments.
+    // Same operations in the same order per element: the bits do not change.
+    constexpr int ILD = BNT + 4;
+    static_assert(tile_lds_elems<NSPLIT, AK, BK, BNT>() * 2 >= BM * ILD * 4, "the tile's image must fit the stage memory");
+    float* img = reinterpret_cast<float*>(smem_base);
+    if (KS == 1) lds_barrier();                  // (KS = 2: the hand-over above already put a barrier behind every wave's last fragment read)
+    {
+        const int crow = (lane >> 4) << 2, ccol = lane & 15;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int gm0 = bm0 + wm0 + i * 16 + crow;
-            const int gn = bn0 + wn0 + j * 16 + ccol;
-            if (gn >= N || gm0 >= M) continue;
-            const float bias = g.bias ? g.bias[gn] : 0.f;
-            uint4 bits = make_uint4(0, 0, 0, 0);
-            const bool per_head = g.drop_head_dim > 0;
-            if (g.drop_p > 0.f && !per_head) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = gm0 + r;
-                if (gm >= M) break;
-                if (g.drop_p > 0.f && per_head) {   // one keep/drop decision per (row, head), see slnlp.h
-                    const unsigned rh = (unsigned)gm * (unsigned)(N / g.drop_head_dim) + (unsigned)(gn / g.drop_head_dim);
+                for (int r = 0; r < 4; ++r) img[(wm0 + i * 16 + crow + r) * ILD + wn0 + j * 16 + ccol] = acc[i][j][r];
+    }
+    lds_barrier();                               // (group 1 of a KS = 2 workgroup has ended: the barrier counts the waves that are left)
+    const bool per_head = g.drop_head_dim > 0;
+#pragma unroll 1
+    for (int q = tid; q < (BM / 4) * BNT; q += 256) {
+        const int col = q % BNT, gm0 = bm0 + 4 * (q / BNT), gn = bn0 + col;
+        if (gn >= N || gm0 >= M) continue;
+        const float bias = g.bias ? g.bias[gn] : 0.f;
+        uint4 bits = make_uint4(0, 0, 0, 0);
+        if (g.drop_p > 0.f) {
+            if (!per_head) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+            else {                                // one keep/drop decision per (row, head), see slnlp.h
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned rh = (unsigned)(gm0 + r) * (unsigned)(N / g.drop_head_dim) + (unsigned)(gn / g.drop_head_dim);
                     const uint4 hb = dropout_bits4(g.rng, g.drop_site, rh >> 2, 0u);
                     const unsigned wsel = pick_word(hb, rh & 3);
-                    bits = make_uint4(wsel, wsel, wsel, wsel);
+                    if (r == 0) bits.x = wsel; else if (r == 1) bits.y = wsel; else if (r == 2) bits.z = wsel; else bits.w = wsel;
                 }
-                float v = acc[i][j][r] + bias;
-                if (g.relu == 1) v = fmaxf(v, 0.f);
-                else if (g.relu == 2) v = tanhf(v);
-                if (g.gate) {
-                    const float gt = g.gate[(long)gm * g.ldg + gn];
-                    v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
-                }
-                if (g.drop_p > 0.f) v = (pick_word(bits, r) >= p.drop_thr) ? v * p.drop_scale : 0.f;
-                if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
-                g.C[(long)gm * g.ldc + gn] = v;
             }
         }
+        const float* src = img + (gm0 - bm0) * ILD + col;
+        // the quad's gate and residual values are requested before its first store: resid may alias C (an in-place add), so a load
+        // written behind a store has to stay there -- four dependent round trips per quad instead of one
+        float gt[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = gm0 + r;
+            gt[r] = (g.gate && gm < M) ? g.gate[(long)gm * g.ldg + gn] : 0.f;
+            rs[r] = (g.resid && gm < M) ? g.resid[(long)gm * g.ldr + gn] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = gm0 + r;
+            if (gm >= M) break;
+            float v = src[r * ILD] + bias;
+            if (g.relu == 1) v = fmaxf(v, 0.f);
+            else if (g.relu == 2) v = tanhf(v);
+            if (g.gate) v = g.gate_mode == 1 ? v * (1.f - gt[r] * gt[r]) : (gt[r] > 0.f ? v * g.gate_scale : 0.f);
+            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= p.drop_thr) ? v * p.drop_scale : 0.f;
+            if (g.resid) v += rs[r];
+            g.C[(long)gm * g.ldc + gn] = v;
+        }
+    }
 }
 
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>

@@ -61,11 +61,9 @@ __device__ __forceinline__ void launder(slnlp_gemm_args& a) {
 
 // kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)
 const void* gemm_group_kernel_ptr(int precision, int ks = 1);
-// tile geometries of the plane GEMM (gemm_planes.hip, GEO[]): 0 = 64 x 64, 1 = 128 x 128 (64-k stages), 2 = 128 x 128 (32-k stages)
+// tile geometries of the plane GEMM (gemm_planes.hip, GEO[]): 0 = 64 x 64, 1 = 128 x 128 (64-k stages), 2 = 128 x 128 (32-k stages), 3 = 256 x 256 (32-k stages)
 const void* gemm_planes_kernel_ptr(int precision, int geo);
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs);   // the geometry a launch of these jobs takes
-int plane_geo_auto(long units128, int min_k, bool fp8);                           // ... from its 128 x 128 tile count and shortest K loop
-long plane_units128(const slnlp_gemm_args& a, int nks);
 void plane_job_retile(PlaneJob& j, int geo);
 void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, const void** fn, size_t* lds);
 

@@ -884,25 +884,38 @@ constexpr int BIG_TILE_MIN_UNITS = 200;    // a launch takes 128 x 128 tiles whe
 //   * 64-k x 2 stages (128 KiB, one workgroup per CU) for launches of about one tile per CU (cfg2 in_proj, 228 tiles: 20.6 against
 //     21.3 us; at K = 512 the 32-k ring pays twice the barriers and has no second workgroup to hide them behind).
 constexpr int TWO_PER_CU_UNITS = 300;    // (a 4-fit lockstep step, 496- and 320-tile launches: 6.83 -> 6.36 ms on the 32-k ring; 2 fits, 248 tiles: equal)
-int plane_geo_auto(long units128, int min_k, bool fp8) {
-    if (fp8) return 0;                                       // (fp8 launches have their own geometries: q8_geo_auto)
+//   * 256 x 256 x 32 (128 KiB, one workgroup per CU, half the operand bytes per FLOP of the 128-wide tiles) for FORWARD launches --
+//     both operands k-major, no split-K -- whose K loops are at least 1024 long and whose tiles fill the 256 CUs' rounds to 85 %:
+//     configs[4] in_proj [16384 x 1024] x [1024 x 3072], 768 tiles: 285 -> 255 us (405 TFLOP/s); FFN2 [16384 x 3072] x [3072 x 1024],
+//     256 tiles: 290 -> 236 us (436 TFLOP/s).  Not below: at K = 512 the tile's longer fill / drain is not paid back (846 tiles:
+//     185 against 183 us; 282 tiles: 88 against 67), half-empty rounds lose outright (128 tiles: 77 against 52 us), and the merged
+//     gradient groups (split-K partial tiles of 256 KiB, two-pass rings) stay 7 % ahead on the 128 x 128 x 32 ring.
+struct LaunchShape {
+    long units128 = 0, units256 = 0;     // workgroups the launch would have at 128 x 128 / 256 x 256 tiles
+    int min_k = 1 << 30;                 // shortest K loop (per split)
+    bool forward = true;                 // every job: both operands k-major, no split-K
+};
+static void shape_add(LaunchShape& s, const slnlp_gemm_args& a, int nks) {
+    if (nks < 1) nks = 1;
+    s.units128 += (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) * nks;
+    s.units256 += (long)ceil_div(a.M, 256) * ceil_div(a.N, 256) * nks;
+    s.min_k = std::min(s.min_k, a.K / nks);
+    s.forward = s.forward && a.a_kmajor && a.b_kmajor && nks == 1 && a.precision != 2;
+}
+static int plane_geo_auto(const LaunchShape& s) {
     const int forced = g_plane_geo.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
-    if (units128 < BIG_TILE_MIN_UNITS) return 0;
-    return (min_k >= 1024 || units128 >= TWO_PER_CU_UNITS) ? 2 : 1;
+    if (s.units128 < BIG_TILE_MIN_UNITS) return 0;
+    if (s.forward && s.min_k >= 1024 && s.units256 * 100 >= (s.units256 + 255) / 256 * 256 * 85) return 3;
+    return (s.min_k >= 1024 || s.units128 >= TWO_PER_CU_UNITS) ? 2 : 1;
 }
-long plane_units128(const slnlp_gemm_args& a, int nks) { return (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) * (nks < 1 ? 1 : nks); }
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
-    long units = 0;
-    int min_k = 1 << 30;
-    bool fp8 = false;
+    LaunchShape s;
     for (int i = 0; i < njobs; ++i) {
-        const int nks = split_k && split_k[i] > 1 ? split_k[i] : 1;
-        fp8 = fp8 || jobs[i].precision == 8;
-        units += plane_units128(jobs[i], nks);
-        min_k = std::min(min_k, jobs[i].K / nks);
+        if (jobs[i].precision == 8) return 0;                // (fp8 launches have their own geometries: q8_geo_auto)
+        shape_add(s, jobs[i], split_k ? split_k[i] : 1);
     }
-    return plane_geo_auto(units, min_k, fp8);
+    return plane_geo_auto(s);
 }
 
 // set the kernels' LDS attribute up front (plan creation) so it never lands inside a graph capture
@@ -1071,13 +1084,9 @@ void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, co
     int prec = 1;
     for (int geo = 0; geo < NGEO; ++geo)
         if (recorded_fn == gemm_planes_kernel_ptr(3, geo)) prec = 3;
-    long units = 0;
-    int min_k = 1 << 30;
-    for (int i = 0; i < njobs; ++i) {
-        units += plane_units128(jobs[i].a, jobs[i].nks);
-        min_k = std::min(min_k, jobs[i].a.K / (jobs[i].nks > 1 ? jobs[i].nks : 1));
-    }
-    const int geo = plane_geo_auto(units, min_k, false);
+    LaunchShape shape;
+    for (int i = 0; i < njobs; ++i) shape_add(shape, jobs[i].a, jobs[i].nks);
+    const int geo = plane_geo_auto(shape);
     for (int i = 0; i < njobs; ++i) plane_job_retile(jobs[i], geo);
     *fn = gemm_planes_kernel_ptr(prec, geo);
     *lds = plane_lds(geo);
