@@ -36,6 +36,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#if SLNLP_PROBE_FENCES == 256
+// timeline probe build (tools/probes/probe_gemm_timeline.py): every workgroup records 100 MHz timestamps of its phases
+constexpr int GTS_MAX = 1 << 14, GTS_W = 6;   // words: entry, first K tile in LDS, K loop done, image written, end, {grid, block}
+__device__ unsigned long long g_gts[GTS_MAX][GTS_W];
+__device__ unsigned g_gts_n;
+#define GTS_MARK(slot) do { if (threadIdx.x == 0) gts[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GTS_MARK(slot) do { } while (0)
+#endif
+
 constexpr int BM = 64, BKT = 64;
 constexpr int KLD = BKT;      // [row][k] image: 64 bf16 = 128-B rows, 16-B slots XOR-swizzled by (row & 7)
 
@@ -192,6 +202,21 @@ constexpr int tile_lds_elems() {
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bid_y, int grid_x, int grid_y,
                                           unsigned short* __restrict__ smem_base) {
+#if SLNLP_PROBE_FENCES == 256
+    unsigned long long gts[GTS_W] = {0, 0, 0, 0, 0, 0};
+    struct GtsFlush {
+        unsigned long long* t; int gx, bx;
+        __device__ ~GtsFlush() {
+            if (threadIdx.x == 0) {
+                t[4] = __builtin_amdgcn_s_memrealtime();
+                t[5] = ((unsigned long long)gx << 32) | (unsigned)bx;
+                const unsigned i = atomicAdd(&g_gts_n, 1u) & (unsigned)(GTS_MAX - 1);
+                for (int k = 0; k < GTS_W; ++k) g_gts[i][k] = t[k];
+            }
+        }
+    } gts_flush{gts, grid_x * grid_y, bid_y * grid_x + bid_x};
+    GTS_MARK(0);
+#endif
     const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
     unsigned short* __restrict__ smem = smem_base + grp * tile_lds_elems<NSPLIT, AK, BK, BNT>();
     using TA = TileIO<AK, BM>;
@@ -236,13 +261,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     // last one when the number of tiles is odd
     const int trips = KS == 2 ? (ktiles + 1) / 2 : ktiles;
     const int k0 = grp * trips, k1 = (KS == 2 && grp == 0) ? trips : ktiles;
-    float4 ra0[TA::NV], ra1[TA::NV], rb0[TB::NV], rb1[TB::NV];
-    TA::template fetch<VEC>(g.A, g.lda, bm0, M, k0 * BKT, K, tid, ra0);
-    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, k0 * BKT, K, tid, rb0);
-    // prefetches are UNCONDITIONAL (past-the-end tiles read a clamped, valid address and are never
+    // DEPTH K tiles in flight in registers.  (Four for the 16-wide tile of the decoder's 50-row products -- with KS = 2 all eight
+    // tiles of a K = 512 product requested at kernel entry -- was measured with per-workgroup timelines, tools/probes/
+    // probe_gemm_timeline.py: the K loop of 4 steps stayed at 2.6 us, it is the steps' own convert / barrier / MFMA chain and not a
+    // wait for loads, and the first tile arrived 0.6 us (warm) to 1.5 us (cold) LATER behind the twenty requests.)
+    // Prefetches are UNCONDITIONAL (past-the-end tiles read a clamped, valid address and are never
     // stashed): a guard would add a join point and make hipcc fall back to conservative vmcnt counts.
-    TA::template fetch<VEC>(g.A, g.lda, bm0, M, (k0 + 1) * BKT, K, tid, ra1);
-    TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (k0 + 1) * BKT, K, tid, rb1);
+    constexpr int DEPTH = 2;
+    // (Requesting the 16-wide tile's bias / gate / residual values here, in front of the K tiles, was measured too: the epilogue got
+    // 0.15 - 0.3 us shorter and the first tile arrived 0.4 us later behind the nine extra requests -- a net loss.)
+    float4 ra[DEPTH][TA::NV], rb[DEPTH][TB::NV];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        TA::template fetch<VEC>(g.A, g.lda, bm0, M, (k0 + d) * BKT, K, tid, ra[d]);
+        TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (k0 + d) * BKT, K, tid, rb[d]);
+    }
 
     auto consume = [&]() {
 #pragma unroll
@@ -278,35 +311,33 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
         }
     };
 
-    // two K-steps per trip so the prefetch registers keep compile-time names
+    // DEPTH K-steps per trip so the prefetch registers keep compile-time names
     auto mainloop = [&](auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        for (int it = 0; it < trips; it += 2) {
-            const int kt = k0 + it;
-            lds_barrier();
-            if (KS == 1 || kt < k1) {
-                TA::template stash<NSPLIT, EDGE>(As, tid, ra0, bm0, M, kt * BKT, K);
-                TB::template stash<NSPLIT, EDGE>(Bs, tid, rb0, bn0, N, kt * BKT, K);
+        for (int it = 0; it < trips; it += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (d > 0 && it + d >= trips) break;
+                const int kt = k0 + it + d;
+                lds_barrier();
+                if (KS == 1 || kt < k1) {
+                    TA::template stash<NSPLIT, EDGE>(As, tid, ra[d], bm0, M, kt * BKT, K);
+                    TB::template stash<NSPLIT, EDGE>(Bs, tid, rb[d], bn0, N, kt * BKT, K);
+                }
+                lds_barrier();
+#if SLNLP_PROBE_FENCES == 256
+                if (it + d == 0) GTS_MARK(1);
+#endif
+                TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + DEPTH) * BKT, K, tid, ra[d]);
+                TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + DEPTH) * BKT, K, tid, rb[d]);
+                if (KS == 1 || kt < k1) consume();
             }
-            lds_barrier();
-            TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 2) * BKT, K, tid, ra0);
-            TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 2) * BKT, K, tid, rb0);
-            if (KS == 1 || kt < k1) consume();
-            if (it + 1 >= trips) break;
-            lds_barrier();
-            if (KS == 1 || kt + 1 < k1) {
-                TA::template stash<NSPLIT, EDGE>(As, tid, ra1, bm0, M, (kt + 1) * BKT, K);
-                TB::template stash<NSPLIT, EDGE>(Bs, tid, rb1, bn0, N, (kt + 1) * BKT, K);
-            }
-            lds_barrier();
-            TA::template fetch<VEC>(g.A, g.lda, bm0, M, (kt + 3) * BKT, K, tid, ra1);
-            TB::template fetch<VEC>(g.B, g.ldb, bn0, N, (kt + 3) * BKT, K, tid, rb1);
-            if (KS == 1 || kt + 1 < k1) consume();
         }
     };
     // interior tile (block-uniform): no bounds masks in the conversion
     if (bm0 + BM <= M && bn0 + BNT <= N && (K % BKT) == 0) mainloop(std::false_type{});
     else mainloop(std::true_type{});
+    GTS_MARK(2);
     if (do_rowsum) {
         rsum[tid >> 6][tid & 63] = rowsum;
         __syncthreads();
@@ -361,6 +392,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
                 for (int r = 0; r < 4; ++r) img[(wm0 + i * 16 + crow + r) * ILD + wn0 + j * 16 + ccol] = acc[i][j][r];
     }
     lds_barrier();                               // (group 1 of a KS = 2 workgroup has ended: the barrier counts the waves that are left)
+    GTS_MARK(3);
     const bool per_head = g.drop_head_dim > 0;
 #pragma unroll 1
     for (int q = tid; q < (BM / 4) * BNT; q += 256) {
@@ -460,9 +492,11 @@ static int pick_ks(const slnlp_gemm_args* jobs, int njobs, int blocks) {
     // LSTM step with KS = 2 but lost 15 % at 16 lockstep fits, where the merged launch is throughput-bound -- and a fit must run
     // the same kernel alone and in lockstep (bit-identical results), so the rule cannot look at the merged size.
     if (blocks > 128) return 1;
-    for (int i = 0; i < njobs; ++i)
-        if (ceil_div(jobs[i].K, BKT) < 4) return 1;       // (also splitting groups with one short job was measured: no gain)
-    return 2;
+    // the longest K loop decides: a decoder weight gradient (K = the batch's 50 rows, one tile -- its second thread group idles) shares
+    // its launch with the data gradient (K = 512: 8 steps -> 4), and the launch lasts as long as that chain (cfg2 step 2.78 -> 2.75 ms)
+    int longest = 0;
+    for (int i = 0; i < njobs; ++i) longest = std::max(longest, ceil_div(jobs[i].K, BKT));
+    return longest >= 4 ? 2 : 1;
 }
 
 template <int NSPLIT, bool AK, bool BK, bool VEC>
@@ -1275,3 +1309,18 @@ extern "C" int slnlp_gemm(const slnlp_gemm_args* args, void* stream) {
     }
     return slnlp::gemm(*args, (hipStream_t)stream);
 }
+
+#if SLNLP_PROBE_FENCES == 256
+// probe build only: copy the recorded workgroup timelines to the host and reset the recorder; returns the number recorded
+extern "C" int slnlp_probe_gemm_ts(unsigned long long* dst, int max_entries) {
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(slnlp::g_gts_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > (unsigned)slnlp::GTS_MAX) n = slnlp::GTS_MAX;
+    if ((int)n > max_entries) n = max_entries;
+    if (n && hipMemcpyFromSymbol(dst, HIP_SYMBOL(slnlp::g_gts), (size_t)n * slnlp::GTS_W * sizeof(unsigned long long)) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(slnlp::g_gts_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif

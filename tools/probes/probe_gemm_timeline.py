@@ -1,0 +1,60 @@
+"""Where a workgroup of the fp32-operand GEMM (the decoder's 50-row products) spends its time: per-workgroup timestamps (100 MHz)
+of kernel entry, first K tile in LDS, K loop done, image written, epilogue done -- from the probe build (make PROBE=256 in
+sign-language-nlp_amd/).  Each shape is timed WARM (back-to-back launches of the same kernel) and COLD (behind a pass over 1 GiB
+that evicts L2 / MALL and other kernels that evict the instruction cache), as it runs inside a train step.
+
+    SLNLP_PROBE_LIB=256 python tools/probes/probe_gemm_timeline.py
+"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sign-language-nlp_amd")]
+os.environ.setdefault("SLNLP_PROBE_LIB", "256")
+import numpy as np, torch
+from slnlp import ops
+from slnlp._lib import load
+lib = load()
+lib.slnlp_probe_gemm_ts.restype = C.c_int
+lib.slnlp_probe_gemm_ts.argtypes = [C.c_void_p, C.c_int]
+buf = np.zeros((1 << 14, 6), dtype=np.uint64)
+
+def read():
+    n = lib.slnlp_probe_gemm_ts(buf.ctypes.data, buf.shape[0])
+    assert n >= 0
+    return buf[:n].astype(np.int64).copy()
+
+big = torch.empty(256 << 20, dtype=torch.float32, device="cuda")      # 1 GiB
+other_x = torch.randn(4096, 512, device="cuda")
+def evict():
+    big.add_(1.0)                                                       # L2 / MALL
+    torch.nn.functional.layer_norm(other_x, (512,)); torch.softmax(other_x, -1); other_x @ other_x.T    # other code through the I-cache
+    torch.cuda.synchronize()
+
+def report(name, launch):
+    for _ in range(20): launch()
+    torch.cuda.synchronize(); read()
+    launch(); warm = read()
+    cold = []
+    for _ in range(8):
+        evict(); read(); launch(); cold.append(read())
+    cold = np.concatenate(cold)
+    for tag, t in (("warm", warm), ("cold", cold)):
+        us = lambda a: a / 100.0
+        ph = [us(t[:, i + 1] - t[:, i]) for i in range(4)]
+        q = lambda a: "%5.2f %5.2f %5.2f" % tuple(np.percentile(a, [10, 50, 90]))
+        span = us(t[:, 4].max() - t[:, 0].min()) if tag == "warm" else float("nan")
+        print(f"{name:44s} {tag}: {len(t):4d} wg | entry->first tile {q(ph[0])} | K loop {q(ph[1])} | reduce+image {q(ph[2])} | epilogue {q(ph[3])} | "
+              f"total {q(us(t[:, 4] - t[:, 0]))} | span {span:5.2f}", flush=True)
+
+g = torch.Generator().manual_seed(0)
+rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+rng = ops.make_rng(seed=1, step=1)
+B, E, F = 50, 512, 512
+x, W, bias, R = rnd(B, E), rnd(E, E), rnd(E), rnd(B, E)
+out = torch.empty(B, E, device="cuda")
+report("linear [50x512]x[512x512] bias",            lambda: ops.gemm(x, W, M=B, N=E, K=E, bias=bias, out=out))
+report("linear ... + dropout + residual",           lambda: ops.gemm(x, W, M=B, N=E, K=E, bias=bias, drop_p=0.1, drop_site=3, rng=rng, resid=R, out=out))
+report("linear ... + relu + dropout (FFN1)",        lambda: ops.gemm(x, W, M=B, N=E, K=E, bias=bias, relu=True, drop_p=0.1, drop_site=3, rng=rng, out=out))
+Wt = W.T.contiguous()
+report("dgrad [50x512]x[512x512] (W m-major) +res", lambda: ops.gemm(x, Wt, M=B, N=E, K=E, b_kmajor=False, resid=R, out=out))
+W3 = rnd(3 * E, E); out3 = torch.empty(B, 3 * E, device="cuda")
+report("linear [50x512]x[512x1536]",                lambda: ops.gemm(x, W3, M=B, N=3 * E, K=E, out=out3))
