@@ -104,10 +104,16 @@ int slnlp_gemm(const slnlp_gemm_args* args, void* stream);
  * library leaves them zero); one scratch buffer must not serve two launches that may run concurrently. */
 int64_t slnlp_gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs);
 /* Output tile of the plane-GEMM launches: 0 = automatic (128 x 128 once a launch holds >= 200 of them -- merged lockstep
- * launches, the configs[4] shapes, cfg2's in_proj gradients -- else 64 x 64); forced: 64, 128 (128 x 128, 64-k stages),
- * 12832 (128 x 128, 32-k stages).  A tuning / test knob: results do not depend on it (the K partition, hence every element's
- * accumulation order, is the same for every geometry). */
+ * launches, the configs[4] shapes, cfg2's in_proj gradients -- 256 x 256 for forward launches with K >= 1024 that fill the
+ * chip's rounds, else 64 x 64); forced: 64, 128 (128 x 128, 64-k stages), 12832 (128 x 128, 32-k stages), 256 (256 x 256,
+ * 32-k stages).  A tuning / test knob: results do not depend on it (the K partition, hence every element's accumulation
+ * order, is the same for every geometry). */
 int slnlp_set_plane_tile(int tile);
+/* Thread groups per workgroup of the fp32-operand GEMM launches (slnlp_gemm, fp32 jobs of slnlp_gemm_group, the plans' 50-row
+ * products): 0 = automatic (two -- each walks one half of the K tiles -- for launches of <= 128 workgroups with at least four K
+ * tiles; one for everything larger, merged lockstep launches included), 1 or 2 forced.  A tuning / test knob: the K sum is
+ * defined as (first half of the tiles) + (second half) whichever way it is scheduled, so results do not depend on it. */
+int slnlp_set_gemm_ks(int ks);
 /* the same knob for precision-8 launches: 0 = automatic (128 x 128 once the launch holds >= 512 of them), 64 or 128 */
 int slnlp_set_fp8_tile(int tile);
 int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,

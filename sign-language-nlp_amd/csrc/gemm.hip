@@ -24,6 +24,7 @@
 // projections / nn.LSTM / nn.GRU that the reference reaches at
 // /root/reference/model/transformer.py:40-48 and
 // /root/reference/model/base/encoder_decoder_attn_bkp.py:95-100,186-200.
+#include <atomic>
 #include <type_traits>
 
 #include "common.hpp"
@@ -195,10 +196,17 @@ constexpr int tile_lds_elems() {
 }
 
 // One workgroup's tile: block (bid_x, bid_y) of a (grid_x, grid_y) grid over C.
-// KS = 2: the workgroup has two groups of 256 threads; group g runs the K loop over its own half of the K tiles with its own
-// stage images (all loads of both halves are in flight together, the dependent chain of K steps is half as long), group 1 hands
-// its accumulators over through LDS and group 0 adds them and runs the epilogue.  For launches that cannot fill the chip anyway
-// (the decoder's 50-row GEMMs: 32 ... 96 workgroups of 8 K tiles, whose duration IS the K chain).
+// The K sum of every output element is DEFINED as two halves -- K tiles [0, T) and [T, ktiles), T = ceil(ktiles / 2), each
+// accumulated in tile order from zero -- added at the end (first + second).  How the halves are computed is then a scheduling
+// choice that does not touch the result:
+//   KS = 2: the workgroup has two groups of 256 threads; group g runs the K loop over its own half of the K tiles with its own
+//           stage images (all loads of both halves are in flight together, the dependent chain of K steps is half as long),
+//           group 1 hands its accumulators over through LDS and group 0 adds them and runs the epilogue.  For launches that
+//           cannot fill the chip anyway (the decoder's 50-row GEMMs: 32 ... 96 workgroups of 8 K tiles, whose duration IS the
+//           K chain);
+//   KS = 1: one group walks both halves and parks the first half's accumulators when it reaches tile T -- half the threads and a
+//           quarter less registers per workgroup: the merged launches of a lockstep group (throughput-bound), which therefore
+//           need not run the kernel a solo fit runs to return its bits.
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bid_y, int grid_x, int grid_y,
                                           unsigned short* __restrict__ smem_base) {
@@ -259,8 +267,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     const int ktiles = (K + BKT - 1) / BKT;
     // this group's K tiles [k0, k1); both groups make `trips` K steps (the barriers are the workgroup's), group 1 idles in its
     // last one when the number of tiles is odd
-    const int trips = KS == 2 ? (ktiles + 1) / 2 : ktiles;
+    const int half = (ktiles + 1) / 2;           // T: the second half of the K sum starts at this tile
+    const int trips = KS == 2 ? half : ktiles;
     const int k0 = grp * trips, k1 = (KS == 2 && grp == 0) ? trips : ktiles;
+    f32x4 acc_first[MT][NT];                     // KS = 1: the first half's sums, parked at tile T
+    float rowsum_first = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc_first[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // DEPTH K tiles in flight in registers.  (Four for the 16-wide tile of the decoder's 50-row products -- with KS = 2 all eight
     // tiles of a K = 512 product requested at kernel entry -- was measured with per-workgroup timelines, tools/probes/
     // probe_gemm_timeline.py: the K loop of 4 steps stayed at 2.6 us, it is the steps' own convert / barrier / MFMA chain and not a
@@ -319,6 +334,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
             for (int d = 0; d < DEPTH; ++d) {
                 if (d > 0 && it + d >= trips) break;
                 const int kt = k0 + it + d;
+                if (KS == 1 && kt == half) {     // (block-uniform; never taken when there is one tile)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) { acc_first[i][j] = acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    rowsum_first = rowsum;
+                    rowsum = 0.f;
+                }
                 lds_barrier();
                 if (KS == 1 || kt < k1) {
                     TA::template stash<NSPLIT, EDGE>(As, tid, ra[d], bm0, M, kt * BKT, K);
@@ -338,17 +361,40 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     if (bm0 + BM <= M && bn0 + BNT <= N && (K % BKT) == 0) mainloop(std::false_type{});
     else mainloop(std::true_type{});
     GTS_MARK(2);
+    if (KS == 1 && ktiles <= half) {             // a single tile: it IS the first half (the loop never reached tile T)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { acc_first[i][j] = acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        rowsum_first = rowsum;
+        rowsum = 0.f;
+    }
     if (do_rowsum) {
-        rsum[tid >> 6][tid & 63] = rowsum;
-        __syncthreads();
+        // row sums of A: per half the four k-quarters of the threads, (q0 + q1) + (q2 + q3); first half + second half
         if (KS == 2) {
+            rsum[tid >> 6][tid & 63] = rowsum;
+            __syncthreads();
             float (*rs1)[BM] = reinterpret_cast<float (*)[BM]>(smem_base + tile_lds_elems<NSPLIT, AK, BK, BNT>() + NP * (TA::PLANE + TB::PLANE));
             float (*rs0)[BM] = reinterpret_cast<float (*)[BM]>(smem_base + NP * (TA::PLANE + TB::PLANE));
             if (grp == 0 && tid < 64 && bm0 + tid < M)
                 g.rowsum_a[bm0 + tid] = ((rs0[0][tid] + rs0[1][tid]) + (rs0[2][tid] + rs0[3][tid])) + ((rs1[0][tid] + rs1[1][tid]) + (rs1[2][tid] + rs1[3][tid]));
-        } else if (tid < 64 && bm0 + tid < M) {
-            g.rowsum_a[bm0 + tid] = rsum[0][tid] + rsum[1][tid] + rsum[2][tid] + rsum[3][tid];
+        } else {
+            lds_barrier();                       // (the last K step's fragment reads: rsum may overlap nothing, but keep the phases apart)
+            rsum[tid >> 6][tid & 63] = rowsum_first;
+            __syncthreads();
+            float s_first = 0.f;
+            if (tid < 64) s_first = (rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]);
+            __syncthreads();
+            rsum[tid >> 6][tid & 63] = rowsum;
+            __syncthreads();
+            if (tid < 64 && bm0 + tid < M) g.rowsum_a[bm0 + tid] = s_first + ((rsum[0][tid] + rsum[1][tid]) + (rsum[2][tid] + rsum[3][tid]));
         }
+    }
+    if (KS == 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = acc_first[i][j] + acc[i][j];
     }
     if (KS == 2) {   // group 1's half of the K sum -> LDS -> group 0 (its stage images are free now)
         float* red = reinterpret_cast<float*>(smem_base + tile_lds_elems<NSPLIT, AK, BK, BNT>());
@@ -485,18 +531,24 @@ __global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupPar
     probe_kernel_end();
 }
 
-// KS = 2 (two K halves per workgroup) for launches that cannot fill the chip and whose duration is the chain of K steps;
-// one rule for single launches, grouped launches and recorded (lockstep) ones, so a fit computes the same bits everywhere
+// KS = 2 (the two K halves on two thread groups) for launches that cannot fill the chip and whose duration is the chain of K steps.
+// Results do not depend on KS (gemm_tile: the K sum is two halves either way), so the rule may look at whatever it likes -- a merged
+// lockstep launch picks again for its own size (gemm_group_ks, lockstep.hip).  -1 = automatic; 1 / 2 forced (slnlp_set_gemm_ks: tests).
+static std::atomic<int> g_gemm_ks{[] { const char* e = getenv("SLNLP_GEMM_KS"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 ? v : -1; }()};
+int gemm_group_ks(int blocks, int longest_ktiles) {
+    const int forced = g_gemm_ks.load(std::memory_order_relaxed);
+    if (forced > 0) return forced;
+    // <= 256 workgroups: the decoder's 50-row products (32 ... 128) and the RNN's recurrent data-gradient group (256: a solo LSTM step
+    // gains 2.6 %); a merged launch of 4 Transformer fits is past that and throughput-bound (two thread groups per workgroup cost
+    // it 3 %, 15 fits 2 %, 16 LSTM fits 15 %).  The longest K loop decides: a decoder weight gradient (K = the batch's 50 rows, one
+    // tile -- its second thread group idles) shares its launch with the data gradient (K = 512: 8 steps -> 4), and the launch lasts
+    // as long as that chain (cfg2 step 2.78 -> 2.75 ms).
+    return blocks <= 256 && longest_ktiles >= 4 ? 2 : 1;
+}
 static int pick_ks(const slnlp_gemm_args* jobs, int njobs, int blocks) {
-    // <= 128 workgroups: the decoder's 50-row products.  The RNN's recurrent dgrad group (256 workgroups) gained 2.6 % of a solo
-    // LSTM step with KS = 2 but lost 15 % at 16 lockstep fits, where the merged launch is throughput-bound -- and a fit must run
-    // the same kernel alone and in lockstep (bit-identical results), so the rule cannot look at the merged size.
-    if (blocks > 128) return 1;
-    // the longest K loop decides: a decoder weight gradient (K = the batch's 50 rows, one tile -- its second thread group idles) shares
-    // its launch with the data gradient (K = 512: 8 steps -> 4), and the launch lasts as long as that chain (cfg2 step 2.78 -> 2.75 ms)
     int longest = 0;
     for (int i = 0; i < njobs; ++i) longest = std::max(longest, ceil_div(jobs[i].K, BKT));
-    return longest >= 4 ? 2 : 1;
+    return gemm_group_ks(blocks, longest);
 }
 
 template <int NSPLIT, bool AK, bool BK, bool VEC>
@@ -948,21 +1000,33 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P
         hpv[r] = d.h_in[(long)bb * Hd + jj];
         cpv[r] = LSTM ? d.c[(long)bb * Hd + jj] : 0.f;
     }
+    // the K sum in two halves, tiles [0, T) and [T, ktiles), first + second: gemm_tile's definition (bit-identical to GEMM + cell)
+    const int half = (ktiles + 1) / 2;
+    f32x4 acc_first[G];
+    auto park = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g) { acc_first[g] = acc[g]; acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    };
     fetch(0, ra0, rb0);
     fetch(1, ra1, rb1);
     for (int kt = 0; kt < ktiles; kt += 2) {
+        if (kt == half) park();
         lds_barrier();
         stash(kt, ra0, rb0);
         lds_barrier();
         fetch(kt + 2, ra0, rb0);
         consume();
         if (kt + 1 >= ktiles) break;
+        if (kt + 1 == half) park();
         lds_barrier();
         stash(kt + 1, ra1, rb1);
         lds_barrier();
         fetch(kt + 3, ra1, rb1);
         consume();
     }
+    if (ktiles <= half) park();
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = acc_first[g] + acc[g];
 
     // ---- cell (same arithmetic and order as rnn_cell_fwd_kernel)
     if (j >= Hd) return;
@@ -1162,19 +1226,31 @@ __global__ __launch_bounds__(256) void rnn_layer_fwd_kernel(const RnnLayerParams
                 }
             }
         };
+        // the K sum in two halves, tiles [0, T) and [T, ktiles), first + second: gemm_tile's definition
+        const int half = (ktiles + 1) / 2;
+        f32x4 acc_first[G];
+        auto park = [&]() {
+#pragma unroll
+            for (int g = 0; g < G; ++g) { acc_first[g] = acc[g]; acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        };
         for (int kt = 0; kt < ktiles; kt += 2) {
+            if (kt == half) park();
             lds_barrier();
             TA::template stash<NSPLIT, false>(As, tid, ra0, 0, B, kt * BKT, K);
             lds_barrier();
             TA::template fetch<true>(h_in, Hd, 0, B, (kt + 2) * BKT, K, tid, ra0);
             consume(kt);
             if (kt + 1 >= ktiles) break;
+            if (kt + 1 == half) park();
             lds_barrier();
             TA::template stash<NSPLIT, false>(As, tid, ra1, 0, B, (kt + 1) * BKT, K);
             lds_barrier();
             TA::template fetch<true>(h_in, Hd, 0, B, (kt + 3) * BKT, K, tid, ra1);
             consume(kt + 1);
         }
+        if (ktiles <= half) park();
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = acc_first[g] + acc[g];
         // ---- cell (same arithmetic and order as rnn_cell_fwd_kernel)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1324,3 +1400,12 @@ extern "C" int slnlp_probe_gemm_ts(unsigned long long* dst, int max_entries) {
     return (int)n;
 }
 #endif
+
+extern "C" int slnlp_set_gemm_ks(int ks) {
+    if (ks != 0 && ks != 1 && ks != 2) {
+        slnlp::set_error("set_gemm_ks: %d (0 = automatic, 1 or 2 thread groups per workgroup)", ks);
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    slnlp::g_gemm_ks.store(ks == 0 ? -1 : ks, std::memory_order_relaxed);
+    return 0;
+}

@@ -243,6 +243,15 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
                 job.block_begin = (int)map.size();
                 map.insert(map.end(), job.gx * job.gy * (job.p.a.batch > 1 ? job.p.a.batch : 1), (int)j);
             }
+            {   // thread groups per workgroup for the MERGED size: a fit's own 96-workgroup launch is a latency chain and splits its
+                // K loop over two groups, fifteen of them fill the chip and run one group (gemm.hip gemm_tile: same bits either way)
+                int longest = 0;
+                for (const GemmJob& job : jobs) longest = std::max(longest, (job.p.a.K + 63) / 64);
+                const int prec = (o0.fn == gemm_group_kernel_ptr(3, 1) || o0.fn == gemm_group_kernel_ptr(3, 2)) ? 3 : 1;
+                const int ks = gemm_group_ks((int)map.size(), longest);
+                m.fn = gemm_group_kernel_ptr(prec, ks);
+                m.block = dim3(256 * ks);
+            }
             m.tab = (void*)(blob.add(jobs.data(), jobs.size() * sizeof(GemmJob)) + 1);
             m.blockmap = (int*)(blob.add(map.data(), map.size() * sizeof(int)) + 1);
             m.grid = dim3((unsigned)map.size());

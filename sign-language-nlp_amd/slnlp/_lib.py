@@ -163,6 +163,7 @@ SIGNATURES = {
     "slnlp_launch_timer_start": (i32, [i32]),
     "slnlp_launch_timer_stop": (i32, [C.POINTER(TimedLaunch), i32]),
     "slnlp_set_plane_tile": (i32, [i32]),
+    "slnlp_set_gemm_ks": (i32, [i32]),
     "slnlp_set_fp8_tile": (i32, [i32]),
     "slnlp_tf_lockstep_workspace_bytes": (i64, [vp, i32]),
     "slnlp_tf_lockstep_create": (i32, [vp, i32, vp, i64, vp, vp]),

@@ -49,6 +49,37 @@ def test_gemm_layouts(ops, layout, M, N, K, prec):
     assert rel(out, ref) < TOL[prec] * max(1.0, math.sqrt(K / 64))
 
 
+def test_gemm_thread_groups_do_not_change_the_bits(ops):
+    """The fp32-operand GEMM defines its K sum as (tiles [0, T)) + (tiles [T, ktiles)), T = ceil(ktiles / 2); one thread group walks
+    both halves (KS = 1: merged lockstep launches) or two groups take one each (KS = 2: a solo fit's latency-bound launches) --
+    slnlp_set_gemm_ks -- and every output, the fused bias-gradient row sums included, must come out bit for bit the same: all
+    layouts, narrow and wide tiles, one / odd / even numbers of K tiles, ragged edges, the epilogue chain."""
+    from slnlp._lib import load, check
+    rng = ops.make_rng(seed=5, step=2)
+    def run():
+        outs = []
+        for (M, N, K) in [(50, 512, 512), (50, 200, 64), (50, 96, 448), (300, 200, 320), (130, 72, 1000), (64, 64, 128)]:
+            A, B, bias, R = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2).cuda(), rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+            outs.append(ops.gemm(A, B, M=M, N=N, K=K, bias=bias, relu=True, drop_p=0.2, drop_site=4, rng=rng, resid=R).clone())
+            outs.append(ops.gemm(A, B.T.contiguous(), M=M, N=N, K=K, b_kmajor=False, resid=R).clone())                       # dgrad layout
+            rs = torch.empty(M, device="cuda")
+            outs.append(ops.gemm(A.T.contiguous(), B.T.contiguous(), M=M, N=N, K=K, a_kmajor=False, b_kmajor=False, rowsum_a=rs).clone())
+            outs.append(rs.clone())
+        torch.cuda.synchronize()
+        return outs
+    try:
+        check(load().slnlp_set_gemm_ks(1), "set_gemm_ks")
+        one = run()
+        check(load().slnlp_set_gemm_ks(2), "set_gemm_ks")
+        two = run()
+    finally:
+        load().slnlp_set_gemm_ks(0)
+    for i, (a, b) in enumerate(zip(one, two)):
+        assert torch.equal(a, b), f"output {i} differs between one and two thread groups"
+    A, B = rnd(50, 512, seed=1), rnd(512, 512, seed=2)
+    assert rel(one[0][:1] * 0 + ops.gemm(A.cuda(), B.cuda(), M=50, N=512, K=512)[:1], (A.double() @ B.double().T)[:1]) < 1e-4
+
+
 def test_gemm_padded_ld_and_views(ops):
     # generator backward shapes: dlogits [B, Vp=204] with V=202 valid columns, garbage (NaN) in the pad
     Bt, V, Vp, E = 50, 202, 204, 512
