@@ -933,8 +933,10 @@ int rnn_step_bwd(int lstm, const slnlp_rnn_step_bwd_dir* dirs, int ndir, int B, 
 }
 
 // grid (Hd / 16, ndir x row tiles, fit): `tab` != nullptr is a lockstep launch, fit z takes tab[z] (launch.hpp)
-template <int NSPLIT, bool LSTM, bool EDGE>
-__global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P0, const RnnStepParams* __restrict__ tab) {
+// KS = 2: two groups of 256 threads, one half of the K tiles each (gemm_tile's scheme: the K sum is two halves by definition, so the
+// bits do not depend on KS) -- a solo fit's 64-workgroup launch is a chain of 8 K steps, a merged lockstep launch takes KS = 1.
+template <int NSPLIT, bool LSTM, bool EDGE, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void rnn_step_fwd_kernel(const RnnStepParams P0, const RnnStepParams* __restrict__ tab) {
     RnnStepParams P;
     if (tab) P = tab[blockIdx.z];
     else P = P0;
@@ -944,11 +946,15 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P
     constexpr int NP = NSPLIT == 3 ? 2 : 1;
     using TA = TileIO<true, BM>;
     using TB = TileIO<true, 16>;
-    __shared__ __attribute__((aligned(16))) unsigned short As[NP * TA::PLANE];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[G * NP * TB::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short As_all[KS * NP * TA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs_all[KS * G * NP * TB::PLANE];
+    __shared__ f32x4 red[KS == 2 ? G * 256 : 1];               // group 1's half of the K sum on its way to group 0
+    const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
+    unsigned short* As = As_all + grp * NP * TA::PLANE;
+    unsigned short* Bs = Bs_all + grp * G * NP * TB::PLANE;
     const int dir = blockIdx.y % P.ndir;
     const slnlp_rnn_step_dir d = as_global(dir == 0 ? P.d[0] : P.d[1]);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int B = P.B, Hd = P.Hd, j0 = blockIdx.x * 16, bm0 = (blockIdx.y / P.ndir) * BM;
     const int K = Hd, ktiles = (K + BKT - 1) / BKT;
 
@@ -1002,31 +1008,61 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P
     }
     // the K sum in two halves, tiles [0, T) and [T, ktiles), first + second: gemm_tile's definition (bit-identical to GEMM + cell)
     const int half = (ktiles + 1) / 2;
-    f32x4 acc_first[G];
-    auto park = [&]() {
+    if constexpr (KS == 1) {
+        f32x4 acc_first[G];
+        auto park = [&]() {
 #pragma unroll
-        for (int g = 0; g < G; ++g) { acc_first[g] = acc[g]; acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    };
-    fetch(0, ra0, rb0);
-    fetch(1, ra1, rb1);
-    for (int kt = 0; kt < ktiles; kt += 2) {
-        if (kt == half) park();
-        lds_barrier();
-        stash(kt, ra0, rb0);
-        lds_barrier();
-        fetch(kt + 2, ra0, rb0);
-        consume();
-        if (kt + 1 >= ktiles) break;
-        if (kt + 1 == half) park();
-        lds_barrier();
-        stash(kt + 1, ra1, rb1);
-        lds_barrier();
-        fetch(kt + 3, ra1, rb1);
-        consume();
+            for (int g = 0; g < G; ++g) { acc_first[g] = acc[g]; acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        };
+        fetch(0, ra0, rb0);
+        fetch(1, ra1, rb1);
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            if (kt == half) park();
+            lds_barrier();
+            stash(kt, ra0, rb0);
+            lds_barrier();
+            fetch(kt + 2, ra0, rb0);
+            consume();
+            if (kt + 1 >= ktiles) break;
+            if (kt + 1 == half) park();
+            lds_barrier();
+            stash(kt + 1, ra1, rb1);
+            lds_barrier();
+            fetch(kt + 3, ra1, rb1);
+            consume();
+        }
+        if (ktiles <= half) park();
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = acc_first[g] + acc[g];
+    } else {
+        // group g: tiles [k0, k1); both groups make `half` steps (the barriers are the workgroup's), group 1 idles in its last one
+        // when the number of tiles is odd; past-the-end prefetches read a clamped, valid tile and are never stashed
+        const int k0 = grp * half, k1 = grp == 0 ? half : ktiles;
+        fetch(k0, ra0, rb0);
+        fetch(k0 + 1, ra1, rb1);
+        for (int it = 0; it < half; it += 2) {
+            const int kt = k0 + it;
+            lds_barrier();
+            if (kt < k1) stash(kt, ra0, rb0);
+            lds_barrier();
+            fetch(kt + 2, ra0, rb0);
+            if (kt < k1) consume();
+            if (it + 1 >= half) break;
+            lds_barrier();
+            if (kt + 1 < k1) stash(kt + 1, ra1, rb1);
+            lds_barrier();
+            fetch(kt + 3, ra1, rb1);
+            if (kt + 1 < k1) consume();
+        }
+        if (grp == 1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) red[g * 256 + tid] = acc[g];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = acc[g] + red[g * 256 + tid];
     }
-    if (ktiles <= half) park();
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = acc_first[g] + acc[g];
 
     // ---- cell (same arithmetic and order as rnn_cell_fwd_kernel)
     if (j >= Hd) return;
@@ -1070,6 +1106,28 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(const RnnStepParams P
     }
 }
 
+// The kernel a MERGED launch of `blocks` workgroups runs in place of the recorded forward-step kernel `fn` (nullptr: `fn` is not one
+// of them, or is the right one already): same results, the thread-group count of the merged size.
+const void* rnn_step_fwd_for_blocks(const void* fn, const void* recorded_args, int blocks, int* threads) {
+    const void* pairs[8][2] = {
+        {(const void*)rnn_step_fwd_kernel<3, true, true, 1>, (const void*)rnn_step_fwd_kernel<3, true, true, 2>},
+        {(const void*)rnn_step_fwd_kernel<3, true, false, 1>, (const void*)rnn_step_fwd_kernel<3, true, false, 2>},
+        {(const void*)rnn_step_fwd_kernel<3, false, true, 1>, (const void*)rnn_step_fwd_kernel<3, false, true, 2>},
+        {(const void*)rnn_step_fwd_kernel<3, false, false, 1>, (const void*)rnn_step_fwd_kernel<3, false, false, 2>},
+        {(const void*)rnn_step_fwd_kernel<1, true, true, 1>, (const void*)rnn_step_fwd_kernel<1, true, true, 2>},
+        {(const void*)rnn_step_fwd_kernel<1, true, false, 1>, (const void*)rnn_step_fwd_kernel<1, true, false, 2>},
+        {(const void*)rnn_step_fwd_kernel<1, false, true, 1>, (const void*)rnn_step_fwd_kernel<1, false, true, 2>},
+        {(const void*)rnn_step_fwd_kernel<1, false, false, 1>, (const void*)rnn_step_fwd_kernel<1, false, false, 2>}};
+    for (auto& pr : pairs)
+        for (int k = 0; k < 2; ++k)
+            if (fn == pr[k]) {
+                const int ks = gemm_group_ks(blocks, ceil_div(static_cast<const RnnStepParams*>(recorded_args)->Hd, BKT));
+                *threads = 256 * ks;
+                return pr[ks - 1] == fn ? nullptr : pr[ks - 1];
+            }
+    return nullptr;
+}
+
 int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int Hd, const int64_t* lengths, float fill,
                  int64_t ld_out, float drop_p, int drop_site, const unsigned long long* rng, int precision, hipStream_t st) {
     SLNLP_CHECK_ARG(dirs && (ndir == 1 || ndir == 2) && B > 0 && Hd > 0 && Hd % 4 == 0, "rnn_step_fwd: bad args (Hd %% 4 == 0)");
@@ -1091,10 +1149,18 @@ int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int 
     const bool edge = (Hd % BKT) != 0;
     const bool rec = recording();
     int rrc = 0;
+    // two thread groups per workgroup while the launch is a latency chain (gemm_group_ks: the rule of the 50-row GEMMs); a merged
+    // lockstep launch swaps the kernel for its one-group twin when it is past that size (rnn_step_fwd_for_blocks, lockstep.hip)
+    const bool two = gemm_group_ks((int)(grid.x * grid.y), ceil_div(Hd, BKT)) == 2;
 #define SLNLP_STEP(NS, L, E)                                                                                                    \
     do {                                                                                                                        \
-        if (rec) rrc = record_op((const void*)rnn_step_fwd_kernel<NS, L, E>, grid, dim3(256), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd"); \
-        else hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E>), grid, dim3(256), 0, st, P, (const RnnStepParams*)nullptr);      \
+        if (two) {                                                                                                              \
+            if (rec) rrc = record_op((const void*)rnn_step_fwd_kernel<NS, L, E, 2>, grid, dim3(512), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd"); \
+            else hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E, 2>), grid, dim3(512), 0, st, P, (const RnnStepParams*)nullptr); \
+        } else {                                                                                                                \
+            if (rec) rrc = record_op((const void*)rnn_step_fwd_kernel<NS, L, E, 1>, grid, dim3(256), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd"); \
+            else hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E, 1>), grid, dim3(256), 0, st, P, (const RnnStepParams*)nullptr); \
+        }                                                                                                                       \
     } while (0)
     if (precision == 3) {
         if (lstm) { if (edge) SLNLP_STEP(3, true, true); else SLNLP_STEP(3, true, false); }

@@ -197,6 +197,14 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
             for (int f = 0; f < K; ++f) memcpy(tab.data() + (size_t)f * o0.args.size(), recs[f].ops[i].args.data(), o0.args.size());
             m.tab = (void*)(blob.add(tab.data(), tab.size()) + 1);          // offset + 1 until the blob is uploaded
             m.grid = dim3(o0.grid.x, o0.grid.y, K);
+            {   // the recurrent forward step splits its K loop over two thread groups while a launch is a latency chain; K fits side
+                // by side fill the chip and take the one-group twin (same bits: gemm.hip)
+                int threads = 0;
+                if (const void* twin = rnn_step_fwd_for_blocks(o0.fn, o0.args.data(), (int)(o0.grid.x * o0.grid.y) * K, &threads)) {
+                    m.fn = twin;
+                    m.block = dim3(threads);
+                }
+            }
         } else if (o0.kind == REC_PLANE_GROUP) {
             std::vector<PlaneJob> jobs;
             std::vector<int> map;
