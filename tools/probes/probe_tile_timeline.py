@@ -76,4 +76,5 @@ report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 64)
 report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 12832)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 128)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 12832)
+report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 256)
 report("configs[4] in_proj grads 16384x3072x1024 split 6", grads(16384, 3072, 1024, 6), 12832)
