@@ -483,8 +483,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     }
 }
 
+// (two 256-thread workgroups per CU must fit: at most 256 registers a lane -- the scalar-load build of the 64-wide tile sits at the edge)
 template <int NSPLIT, bool AK, bool BK, int BNT, bool VEC, int KS = 1>
-__global__ __launch_bounds__(256 * KS) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short smem[KS * tile_lds_elems<NSPLIT, AK, BK, BNT>()];
     probe_kernel_begin();
     gemm_tile<NSPLIT, AK, BK, BNT, VEC, KS>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
