@@ -38,7 +38,6 @@ def report(name, launch, tile):
     ghz = (hot[ok, 7] - hot[ok, 6]) / dt[ok] * 0.1
     launch()
     t = read()
-    check(lib.slnlp_set_plane_tile(0), "tile")
     if ok.any():
         print(f"{name} tile {tile}: held shader clock over the K loop after {SUSTAIN:.0f} s ({n_l} launches): "
               f"p10/p50/p90 {np.percentile(ghz, 10):.3f} {np.percentile(ghz, 50):.3f} {np.percentile(ghz, 90):.3f} GHz ({ok.sum()} workgroups)")
@@ -50,8 +49,26 @@ def report(name, launch, tile):
     print(f"{name} tile {tile}: {len(t)} workgroups, launch span {us(t[:, 4].max() - t0):7.2f} us")
     print(f"    p10/p50/p90 us: first K-step landed {q(fill)} | K loop {q(loop)} | drain+meeting {q(meet)} | epilogue {q(epi)} | total {q(tot)}")
     print(f"    workgroup start times: p10/p50/p90 {q(start)}; started within 2 us of the first: {(start < 2).sum()}")
+    if COLD:
+        # the same launch behind evicted caches (a pass over 1 GiB, other kernels through the instruction cache), as inside a train step
+        spans, rows = [], []
+        for _ in range(6):
+            evict(); read(); launch(); c = read()
+            spans.append(us(c[:, 4].max() - c[:, 0].min())); rows.append(c)
+        c = np.concatenate(rows)
+        ph = [us(c[:, i + 1] - c[:, i]) for i in range(4)] + [us(c[:, 4] - c[:, 0])]
+        ph[2] = ph[2][np.abs(ph[2]) < 1e6]; ph[3] = ph[3][np.abs(ph[3]) < 1e6]          # (workgroups that left at the split-K meeting carry no mark 3)
+        print(f"    COLD, 6 launches: span {np.mean(spans):7.2f} us | first K-step landed {q(ph[0])} | K loop {q(ph[1])} | drain+meeting {q(ph[2])} | epilogue {q(ph[3])} | total {q(ph[4])}")
+    check(lib.slnlp_set_plane_tile(0), "tile")
 
 SUSTAIN = float(os.environ.get("PROBE_SUSTAIN_S", "2"))
+COLD = os.environ.get("PROBE_COLD", "0") == "1"
+_big = torch.empty(256 << 20, dtype=torch.float32, device="cuda") if COLD else None      # 1 GiB
+_other = torch.randn(4096, 512, device="cuda") if COLD else None
+def evict():
+    _big.add_(1.0)
+    torch.nn.functional.layer_norm(_other, (512,)); torch.softmax(_other, -1); _other @ _other.T
+    torch.cuda.synchronize()
 g = torch.Generator().manual_seed(0)
 def fwd(M, N, K):
     X, W = [torch.randn(*s, generator=g).cuda() for s in ((M, K), (N, K))]
@@ -74,6 +91,10 @@ report("cfg2 dgrad+wgrad (split 3)       ", grads(2400, 512, 512, 3), 64)
 report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 128)
 report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 64)
 report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 12832)
+if os.environ.get("PROBE_EXTRA"):
+    report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 256)
+    report("15 fits' in_proj 36000x1536x512  ", fwd(36000, 1536, 512), 12832)
+    report("15 fits' in_proj 36000x1536x512  ", fwd(36000, 1536, 512), 256)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 128)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 12832)
 report("configs[4] in_proj 16384x3072x1024", fwd(16384, 3072, 1024), 256)
