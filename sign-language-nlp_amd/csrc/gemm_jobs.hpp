@@ -1,6 +1,7 @@
 // gemm_jobs.hpp -- job descriptors of the grouped GEMM kernels (gemm.hip, gemm_planes.hip), shared with the lockstep
 // driver (lockstep.hip), which concatenates the job lists of K fits into one device-resident table per launch.
 #pragma once
+#include <vector>
 #include "common.hpp"
 #include "launch.hpp"
 
@@ -68,5 +69,7 @@ const void* gemm_planes_kernel_ptr(int precision, int geo);
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs);   // the geometry a launch of these jobs takes
 void plane_job_retile(PlaneJob& j, int geo);
 void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, const void** fn, size_t* lds);
+// the block map of a merged plane-GEMM launch: units of all jobs placed on the XCDs (false: fp8 launch, keep the per-job layout)
+bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map);
 
 }  // namespace slnlp

@@ -15,6 +15,9 @@
 //      k-major image [row][64 k]  : 16-B slot ^= (row & 7)            -> conflict-free ds_read_b128
 //      m-major image [k][64 rows] : 16-B slot ^= 2*(k>>1 & 1 | k>>3 & 1 << 1) -> ds_read_b64_tr_b16
 //  * padding makes every tile interior: no bounds logic anywhere in the loop.
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 #include "gemm_jobs.hpp"
 
@@ -280,7 +283,7 @@ __device__ __forceinline__ void plane_kloop(const slnlp_gemm_args& g, unsigned s
 // fully unrolled epilogues a 128 x 128 kernel was 316 KiB of code and its workgroups spent 6 us of a 19 us life there, a
 // 256 x 256 one 61 us.  Hence the rolled loops below: only what needs a STATIC accumulator register index is unrolled.)
 template <int NSPLIT, int BM, int BN, int BKS, int NST>
-__device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigned short* smem) {
+__device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, bool placed, unsigned short* smem) {
     unsigned long long* tsp = nullptr;
 #if SLNLP_PROBE_FENCES == 128
     unsigned long long ts[TS_W] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -311,7 +314,8 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, unsigne
     {   // XCD-aware order (see gemm.hip): each XCD owns a contiguous run of (tile, split) units
         const int nwg = job.tiles_x * job.tiles_y * nks;
         const int xcd = lid & 7, q = nwg >> 3, r = nwg & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+        // (a merged launch: `lid` IS the unit -- the host laid the units of all jobs out over the XCDs)
+        const int t = placed ? lid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
         // split-major unit order: the units of one XCD share a K-slice, so its 4 MiB L2 holds that slice of a few
         // A / B panels instead of whole panels (measured 5x over-fetch with tile-major order on the weight gradient)
         const int ntiles = job.tiles_x * job.tiles_y;
@@ -773,6 +777,9 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
         }
 }
 
+// block map entry of a merged launch: job index | unit << PLACE_JOB_BITS (-1: padding)
+constexpr int PLACE_JOB_BITS = 10, PLACE_JOBS = 1 << PLACE_JOB_BITS;
+
 // GEO: the launch's tile geometry (table below); every job of a launch uses it (the host picks it per launch: plane_geo_for()).
 struct GeoInfo { int bm, bn, bks, nst; };
 constexpr int NGEO = 4;
@@ -783,21 +790,28 @@ __global__ __launch_bounds__(PTHREADS) void gemm_planes_kernel(const PlaneGroupP
                                                                const int* __restrict__ blockmap) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // the LDS ring (+ scratch after the loop)
     PlaneJob job;
+    int lid;
+    bool placed = false;
     if (tab) {
-        job = tab[blockmap[blockIdx.x]];
+        // a merged launch's block map holds (job, unit of the job) per block, units placed on the XCDs by the host (plane_merge_place)
+        const int m = blockmap[blockIdx.x];
+        if (m < 0) return;                                                  // padding block (the XCDs' unit lists differ in length)
+        job = tab[m & (PLACE_JOBS - 1)];
+        lid = m >> PLACE_JOB_BITS;
+        placed = true;
     } else {
         int j = 0;
         for (int t = 1; t < P.njobs; ++t)
             if ((int)blockIdx.x >= P.job[t].block_begin) j = t;             // block-uniform
         job = P.job[j];
+        lid = blockIdx.x - job.block_begin;
     }
     launder(job.a);
     job.part = as_global(job.part); job.part_rs = as_global(job.part_rs); job.counters = as_global(job.counters);
-    const int lid = blockIdx.x - job.block_begin;
-    if (lid >= job.tiles_x * job.tiles_y * job.nks) return;                 // padding block of a merged launch (jobs start on multiples of 8)
+    if (lid >= job.tiles_x * job.tiles_y * job.nks) return;
     constexpr GeoInfo g = GEO[G];
     probe_kernel_begin();
-    plane_tile<NSPLIT, g.bm, g.bn, g.bks, g.nst>(job, lid, smem);
+    plane_tile<NSPLIT, g.bm, g.bn, g.bks, g.nst>(job, lid, placed, smem);
     probe_kernel_end();
 }
 
@@ -1090,6 +1104,63 @@ void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, co
     for (int i = 0; i < njobs; ++i) plane_job_retile(jobs[i], geo);
     *fn = gemm_planes_kernel_ptr(prec, geo);
     *lds = plane_lds(geo);
+}
+
+// The block map of a merged plane-GEMM launch (lockstep.hip): entry b = (job, unit of the job) of workgroup b, which runs on XCD
+// b % 8 (each with a private 4 MiB L2) in order b / 8.  A solo launch gives every XCD a contiguous run of ITS job's units
+// (plane_tile); the K fits of a merged launch are as many small jobs -- a fit's weight gradient is 16 tiles x 3 K-slices -- and
+// dealing each job's units over all eight XCDs made every XCD fetch a part of every job's operand panels (the weight-gradient
+// workgroups of a 15-fit launch ran 2.1 us per K-step on HBM traffic: profiles/r04_lockstep_plane_timeline.txt).  From two full
+// rounds of workgroups on (1024 units) the units of ALL jobs, in job order, are cut into eight contiguous runs of equal WORK
+// (units x K-steps) instead: an XCD then holds a few whole jobs and a panel is fetched by one L2 (15-fit gradient groups 168 ->
+// 149 us).  Smaller launches keep the per-job layout: with less than a round or two per XCD the slots, not the bytes, decide.
+// Which workgroup computes a unit has no bearing on its result.
+constexpr long PLACE_MIN_UNITS = 1024;
+bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map) {
+    int geo = -1;
+    for (int g = 0; g < NGEO; ++g)
+        if (merged_fn == gemm_planes_kernel_ptr(1, g) || merged_fn == gemm_planes_kernel_ptr(3, g)) geo = g;
+    if (geo < 0 || njobs > PLACE_JOBS) return false;       // (fp8 launches keep their own layout)
+    long total = 0, work = 0;
+    std::vector<long> ksteps(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        const PlaneJob& J = jobs[j];
+        const long units = (long)J.tiles_x * J.tiles_y * J.nks;
+        if (units >= (1L << (31 - PLACE_JOB_BITS))) return false;
+        ksteps[j] = (J.a.K / (J.nks > 0 ? J.nks : 1) + GEO[geo].bks - 1) / GEO[geo].bks + 6;      // (+ fill, meeting, epilogue)
+        total += units;
+        work += units * ksteps[j];
+    }
+    map.clear();
+    if (total < PLACE_MIN_UNITS) {
+        // per job, as a solo launch lays it out: jobs start on multiples of 8, block lid of a job -> XCD lid % 8 -> the unit plane_tile's
+        // own mapping would give it
+        for (int j = 0; j < njobs; ++j) {
+            const int units = jobs[j].tiles_x * jobs[j].tiles_y * jobs[j].nks, padded = (units + 7) & ~7, q = units >> 3, r = units & 7;
+            for (int lid = 0; lid < padded; ++lid) {
+                const int xcd = lid & 7, t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+                map.push_back(lid < units ? (j | (t << PLACE_JOB_BITS)) : -1);
+            }
+        }
+        return true;
+    }
+    std::vector<int> units[8];
+    long done = 0;                                          // work placed so far
+    int x = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const int n = jobs[j].tiles_x * jobs[j].tiles_y * jobs[j].nks;
+        for (int t = 0; t < n; ++t) {
+            while (x < 7 && done * 8 >= work * (x + 1)) ++x;
+            units[x].push_back(j | (t << PLACE_JOB_BITS));
+            done += ksteps[j];
+        }
+    }
+    size_t longest = 0;
+    for (int k = 0; k < 8; ++k) longest = std::max(longest, units[k].size());
+    map.assign(longest * 8, -1);
+    for (int k = 0; k < 8; ++k)
+        for (size_t i = 0; i < units[k].size(); ++i) map[i * 8 + k] = units[k][i];
+    return true;
 }
 
 template <int NSPLIT>

@@ -216,11 +216,13 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
             // times it takes them (fewer operand bytes per FLOP through L2 -> LDS, gemm_planes.hip).  The K partition of every
             // job stays, so each fit's results keep the bits of its solo launch whatever the geometry.
             plane_merge_geometry(o0.fn, jobs.data(), (int)jobs.size(), &m.fn, &m.lds);
-            for (size_t j = 0; j < jobs.size(); ++j) {
-                PlaneJob& job = jobs[j];
-                const int blocks = job.tiles_x * job.tiles_y * job.nks, padded = (blocks + 7) & ~7;
-                job.block_begin = (int)map.size();
-                map.insert(map.end(), padded, (int)j);
+            if (!plane_merge_place(m.fn, jobs.data(), (int)jobs.size(), map)) {
+                for (size_t j = 0; j < jobs.size(); ++j) {          // fp8 launches: a job's blocks in a row, jobs on multiples of 8
+                    PlaneJob& job = jobs[j];
+                    const int blocks = job.tiles_x * job.tiles_y * job.nks, padded = (blocks + 7) & ~7;
+                    job.block_begin = (int)map.size();
+                    map.insert(map.end(), padded, (int)j);
+                }
             }
             m.tab = (void*)(blob.add(jobs.data(), jobs.size() * sizeof(PlaneJob)) + 1);
             m.blockmap = (int*)(blob.add(map.data(), map.size() * sizeof(int)) + 1);
