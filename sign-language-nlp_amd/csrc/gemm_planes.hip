@@ -1155,6 +1155,11 @@ bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, s
             done += ksteps[j];
         }
     }
+    // inside an XCD's run the units with the longest K loops go first (a fit's weight-gradient slices before its data-gradient tiles):
+    // the launch ends when the last long workgroup does, so none of them should start late
+    for (int k = 0; k < 8; ++k)
+        std::stable_sort(units[k].begin(), units[k].end(),
+                         [&](int a, int b) { return ksteps[a & (PLACE_JOBS - 1)] > ksteps[b & (PLACE_JOBS - 1)]; });
     size_t longest = 0;
     for (int k = 0; k < 8; ++k) longest = std::max(longest, units[k].size());
     map.assign(longest * 8, -1);
