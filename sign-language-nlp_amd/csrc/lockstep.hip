@@ -25,6 +25,8 @@
 #include <map>
 #include <tuple>
 
+#include <algorithm>
+
 #include "gemm_jobs.hpp"
 #include "tf_plan.hpp"
 
@@ -248,6 +250,9 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
             if (blocks >= gemm_group_retile_min())
                 for (GemmJob& job : jobs)
                     if ((job.variant & 1) && job.p.a.N > 16) { job.variant -= 1; job.gx = (job.p.a.N + 63) / 64; }
+            // jobs with the longest K loops first (the fits' 8-step data gradients before their one-step weight gradients): the launch
+            // ends when the last long workgroup does, so none of them should start late.  (Job order has no bearing on results.)
+            std::stable_sort(jobs.begin(), jobs.end(), [](const GemmJob& a, const GemmJob& b) { return a.p.a.K > b.p.a.K; });
             for (size_t j = 0; j < jobs.size(); ++j) {
                 GemmJob& job = jobs[j];
                 job.block_begin = (int)map.size();
