@@ -1110,12 +1110,14 @@ void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, co
 // b % 8 (each with a private 4 MiB L2) in order b / 8.  A solo launch gives every XCD a contiguous run of ITS job's units
 // (plane_tile); the K fits of a merged launch are as many small jobs -- a fit's weight gradient is 16 tiles x 3 K-slices -- and
 // dealing each job's units over all eight XCDs made every XCD fetch a part of every job's operand panels (the weight-gradient
-// workgroups of a 15-fit launch ran 2.1 us per K-step on HBM traffic: profiles/r04_lockstep_plane_timeline.txt).  From two full
-// rounds of workgroups on (1024 units) the units of ALL jobs, in job order, are cut into eight contiguous runs of equal WORK
-// (units x K-steps) instead: an XCD then holds a few whole jobs and a panel is fetched by one L2 (15-fit gradient groups 168 ->
-// 149 us).  Smaller launches keep the per-job layout: with less than a round or two per XCD the slots, not the bytes, decide.
+// workgroups of a 15-fit launch ran 2.1 us per K-step on HBM traffic: profiles/r04_lockstep_plane_timeline.txt).  With at least
+// four jobs and 256 units the units of ALL jobs, in job order, are cut into eight contiguous runs of equal WORK (units x K-steps)
+// instead: an XCD then holds a few whole jobs and a panel is fetched by one L2 (15-fit gradient groups 168 -> 142 us; a lockstep
+// step of 3 / 4 / 8 / 15 fits 4.97 / 5.71 / 9.68 / 16.5 -> 4.87 / 5.63 / 9.18 / 15.9 ms).  One fit's own two jobs keep the per-job
+// layout (2.80 ms against 2.90: a long weight-gradient slice per XCD beside XCDs with short tiles only).
 // Which workgroup computes a unit has no bearing on its result.
-constexpr long PLACE_MIN_UNITS = 1024;
+constexpr long PLACE_MIN_UNITS = 256;
+constexpr int PLACE_MIN_JOBS = 4;
 bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map) {
     int geo = -1;
     for (int g = 0; g < NGEO; ++g)
@@ -1132,7 +1134,7 @@ bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, s
         work += units * ksteps[j];
     }
     map.clear();
-    if (total < PLACE_MIN_UNITS) {
+    if (total < PLACE_MIN_UNITS || njobs < PLACE_MIN_JOBS) {
         // per job, as a solo launch lays it out: jobs start on multiples of 8, block lid of a job -> XCD lid % 8 -> the unit plane_tile's
         // own mapping would give it
         for (int j = 0; j < njobs; ++j) {
