@@ -28,7 +28,7 @@ def _engines(c, K, dropouts, B=None):
 
 
 @pytest.mark.parametrize("name,dropouts", [("tiny", (0.0, 0.0, 0.0)), ("tiny", (0.1, 0.3, 0.2)), ("cfg1", (0.1, 0.5, 0.1, 0.3)),
-                                            ("cfg2", (0.1, 0.1))])
+                                            ("cfg2", (0.1, 0.1)), ("cfg2", (0.1, 0.3, 0.2, 0.1))])
 def test_lockstep_steps_are_bit_identical_to_solo_steps(name, dropouts):
     """Engines with their own weights / lr / dropout rate / seed and their own data: train steps (full and ragged last
     batch) and an eval pass in lockstep == the same calls on each engine alone."""
@@ -168,7 +168,8 @@ def _rnn_engines(c, K, dropouts):
 
 
 @pytest.mark.parametrize("rnn_type,name,dropouts", [("lstm", "tiny", (0.0, 0.0, 0.0)), ("gru", "tiny", (0.2, 0.1, 0.4)), ("lstm", "mid", (0.1, 0.3)),
-                                                     ("gru", "mid", (0.1, 0.3)), ("lstm", "cfg3", (0.1, 0.1))])
+                                                     ("gru", "mid", (0.1, 0.3)), ("lstm", "cfg3", (0.1, 0.1)),
+                                                     ("gru", "cfg3", (0.1, 0.3, 0.2, 0.1))])
 def test_rnn_lockstep_steps_are_bit_identical_to_solo_steps(rnn_type, name, dropouts):
     """slnlp_rnn_lockstep_*: LSTM / GRU encoder-decoder fits with their own weights, lr, dropout rate, seed, data and sequence
     lengths -- train steps (full and ragged last batch) and an eval pass in lockstep == the same calls on each engine alone."""
