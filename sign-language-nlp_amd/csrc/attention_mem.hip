@@ -176,15 +176,20 @@ SLNLP_ZKERNEL(xmem_bwd_kernel, 256, xmem_bwd_body)
 constexpr int XMEM_MAX_HEADS = 64;      // heads per sequence the d-memory kernel keeps in LDS (xmem_check rejects more)
 
 // ------------------------------------------------------------------------------------ backward, per memory row ----
-// d mem[s*B+b, :] (+)= sum_h ( p_s(b,h) d mbar(b,h,:) + d score_s(b,h) qk(b,h,:) ),  p after dropout; heads in fixed order
+// d mem[s*B+b, :] (+)= sum_h ( p_s(b,h) d mbar(b,h,:) + d score_s(b,h) qk(b,h,:) ),  p after dropout; heads in fixed order.
+// A workgroup takes DMEM_ROWS rows s of ONE sequence b: the 2 H head vectors d mbar(b,h,:), qk(b,h,:) -- 32 KB at cfg2 -- are what it
+// streams, so one row per workgroup read them S times per sequence (77 MB through the L2 per launch, 1.2 GB for 15 fits in
+// lockstep); eight rows share one pass.  A thread holds 4 columns of its rows; the sum over h runs in head order per row as before.
+constexpr int DMEM_ROWS = 8;
 __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, const float* __restrict__ dsc, const float* __restrict__ dmbar,
                                                const float* __restrict__ qk, int B, int S, int H, int E, float* __restrict__ dmem,
                                                int accumulate, float drop_p, unsigned drop_thr, int drop_site,
                                                const unsigned long long* __restrict__ rng, const float* __restrict__ dcp,
                                                float* __restrict__ dbv) {
-    __shared__ float ph[XMEM_MAX_HEADS], dh_[XMEM_MAX_HEADS];   // this row's p_s (after dropout) and d score_s per head: computed once
-    if ((int)blockIdx.x >= S * B) {                      // the launch's last ceil(E / 256) workgroups: d bv = column sums of dcp, in row
-        const int c = ((int)blockIdx.x - S * B) * 256 + threadIdx.x;   // order (was a launch of its own: 5 us of dispatch for 100 KB)
+    __shared__ float ph[DMEM_ROWS][XMEM_MAX_HEADS], dh_[DMEM_ROWS][XMEM_MAX_HEADS];   // p_s (after dropout), d score_s per (row, head)
+    const int chunks = (S + DMEM_ROWS - 1) / DMEM_ROWS, tid = threadIdx.x;
+    if ((int)blockIdx.x >= chunks * B) {                 // the launch's last ceil(E / 256) workgroups: d bv = column sums of dcp, in row
+        const int c = ((int)blockIdx.x - chunks * B) * 256 + tid;      // order (was a launch of its own: 5 us of dispatch for 100 KB)
         if (c < E) {
             float a = 0.f;
 #pragma unroll 8
@@ -193,25 +198,50 @@ __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, 
         }
         return;
     }
-    const int m = blockIdx.x, s = m / B, b = m % B;
-    if (threadIdx.x < H) {
-        const long bh = (long)b * H + threadIdx.x;
-        float p = probs[bh * S + s];
-        if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)s, drop_thr) ? p / (1.f - drop_p) : 0.f;
-        ph[threadIdx.x] = p;
-        dh_[threadIdx.x] = dsc[bh * S + s];
+    const int b = blockIdx.x / chunks, s0 = (blockIdx.x % chunks) * DMEM_ROWS;
+    for (int i = tid; i < DMEM_ROWS * H; i += 256) {
+        const int r = i / H, h = i - r * H, s_ = s0 + r;
+        const long bh = (long)b * H + h;
+        float p = 0.f, d = 0.f;
+        if (s_ < S) {
+            p = probs[bh * S + s_];
+            if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)s_, drop_thr) ? p / (1.f - drop_p) : 0.f;
+            d = dsc[bh * S + s_];
+        }
+        ph[r][h] = p;
+        dh_[r][h] = d;
     }
     __syncthreads();
-    for (int e = threadIdx.x * 4; e < E; e += 1024) {
-        float4 a = accumulate ? *reinterpret_cast<const float4*>(dmem + (long)m * E + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+    // thread -> (row set, 4 columns): with E / 4 < 256 column chunks the spare threads take other rows of the workgroup
+    const int per = E >> 2, sets = per >= 256 ? 1 : 256 / per;
+    const int set = sets == 1 ? 0 : tid / per, c0 = sets == 1 ? tid : tid - set * per;
+    if (set >= sets) return;
+    for (int e = c0 * 4; e < E; e += (sets == 1 ? 1024 : E)) {
+        float4 a[DMEM_ROWS];
+#pragma unroll
+        for (int i = 0; i < DMEM_ROWS; ++i) {
+            const int r = set + i * sets, s_ = s0 + r;
+            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (accumulate && r < DMEM_ROWS && s_ < S) a[i] = *reinterpret_cast<const float4*>(dmem + ((long)s_ * B + b) * E + e);
+        }
+#pragma unroll 2
         for (int h = 0; h < H; ++h) {
             const long bh = (long)b * H + h;
-            const float p = ph[h], d = dh_[h];
             const float4 g = *reinterpret_cast<const float4*>(dmbar + bh * E + e), k = *reinterpret_cast<const float4*>(qk + bh * E + e);
-            a.x += p * g.x + d * k.x; a.y += p * g.y + d * k.y; a.z += p * g.z + d * k.z; a.w += p * g.w + d * k.w;
+#pragma unroll
+            for (int i = 0; i < DMEM_ROWS; ++i) {
+                const int r = set + i * sets;
+                if (r < DMEM_ROWS) {
+                    const float p = ph[r][h], d = dh_[r][h];
+                    a[i].x += p * g.x + d * k.x; a[i].y += p * g.y + d * k.y; a[i].z += p * g.z + d * k.z; a[i].w += p * g.w + d * k.w;
+                }
+            }
         }
-        *reinterpret_cast<float4*>(dmem + (long)m * E + e) = a;
+#pragma unroll
+        for (int i = 0; i < DMEM_ROWS; ++i) {
+            const int r = set + i * sets, s_ = s0 + r;
+            if (r < DMEM_ROWS && s_ < S) *reinterpret_cast<float4*>(dmem + ((long)s_ * B + b) * E + e) = a[i];
+        }
     }
 }
 SLNLP_ZKERNEL(xmem_dmem_kernel, 256, xmem_dmem_body)
@@ -227,6 +257,209 @@ __device__ __forceinline__ void xmem_colsum_body(const float* __restrict__ in, i
 }
 SLNLP_ZKERNEL(xmem_colsum_kernel, 256, xmem_colsum_body)
 
+// ------------------------------------------------------------------------------- HP heads per workgroup ----
+// The kernels above stream the S memory rows of their sequence twice per (sequence, head) workgroup, and the H heads of a sequence
+// stream the SAME rows: 2 x S x E x 4 bytes through the L2 per head -- 78 MB per launch at cfg2, 1.2 GB for 15 fits in lockstep,
+// where that traffic is the kernels' time.  Here a workgroup serves HP heads of one sequence from ONE pass over the rows: a row
+// chunk is loaded once and used for the HP dot products (and later the HP weighted sums).  Per output element the arithmetic
+// and its order are those of the kernels above (same lane partition of every dot product, same sequential sums over s): the
+// results are bit-identical, HP is a scheduling choice (xmem_heads_per_wg).
+__device__ __forceinline__ float dot4(const float4& q4, const float4& m4) { return q4.x * m4.x + q4.y * m4.y + q4.z * m4.z + q4.w * m4.w; }
+
+// dots of the HP LDS vectors v[hp][E] (stride vs) with memory rows s = wave, wave + 4, ... : four rows per trip, each row chunk
+// loaded once for all HP heads
+template <int HP, class F>
+__device__ __forceinline__ void row_dots_multi(const float* __restrict__ v, int vs, const float* __restrict__ mem, int B, int b, int S, int E,
+                                               int lane, int wave, F&& put) {
+    for (int s0 = wave; s0 < S; s0 += 16) {
+        float a[4][HP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int hp = 0; hp < HP; ++hp) a[u][hp] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 4 * u;
+            if (s < S) {
+                const float* mr = mem + ((long)s * B + b) * E;
+                for (int e = lane * 4; e < E; e += 256) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mr + e);
+#pragma unroll
+                    for (int hp = 0; hp < HP; ++hp) a[u][hp] += dot4(*reinterpret_cast<const float4*>(v + (long)hp * vs + e), m4);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int hp = 0; hp < HP; ++hp) {
+                const float r = wave_sum(a[u][hp]);
+                if (lane == 0 && s0 + 4 * u < S) put(hp, s0 + 4 * u, r);
+            }
+    }
+}
+
+// LDS per head: v[E], sc[S padded to 4], 4 scalar slots
+__device__ __forceinline__ int xm_head_floats(int S, int E) { return E + ((S + 3) & ~3) + 4; }
+
+template <int HP>
+__device__ __forceinline__ void xmem_fwd_multi_body(const float* __restrict__ qk, const float* __restrict__ mem, const float* __restrict__ bv,
+                                                    int B, int S, int H, int dh, float* __restrict__ mbar_out, float* __restrict__ psum_out,
+                                                    float* __restrict__ probs, float* __restrict__ ctx0, float drop_p, unsigned drop_thr,
+                                                    int drop_site, const unsigned long long* __restrict__ rng) {
+    extern __shared__ __attribute__((aligned(16))) float xm_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = H * dh, groups = H / HP;
+    const int wg = xcd_local(blockIdx.x, gridDim.x), b = wg / groups, h0 = (wg % groups) * HP;
+    const int hf = xm_head_floats(S, E), sp = (S + 3) & ~3;
+    float* heads = xm_lds;
+    for (int i = tid * 4; i < HP * E; i += 1024) {
+        const int hp = i / E, e = i - hp * E;
+        *reinterpret_cast<float4*>(heads + (long)hp * hf + e) = *reinterpret_cast<const float4*>(qk + ((long)b * H + h0 + hp) * E + e);
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
+    row_dots_multi<HP>(heads, hf, mem, B, b, S, E, lane, wave, [&](int hp, int s_, float r) { heads[(long)hp * hf + E + s_] = r * scale; });
+    __syncthreads();
+    for (int hp = wave; hp < HP; hp += 4) {              // softmax + dropout of one head per wave (xmem_fwd_body's wave-0 block)
+        float* sc = heads + (long)hp * hf + E;
+        const long bh = (long)b * H + h0 + hp;
+        float m = -INFINITY;
+        for (int s_ = lane; s_ < S; s_ += 64) m = fmaxf(m, sc[s_]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int s_ = lane; s_ < S; s_ += 64) sum += expf(sc[s_] - m);
+        sum = wave_sum(sum);
+        float tot = 0.f;
+        for (int s_ = lane; s_ < S; s_ += 64) {
+            float p = expf(sc[s_] - m) / sum;
+            probs[bh * S + s_] = p;
+            if (drop_p > 0.f) p = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)s_, drop_thr) ? p * inv_keep : 0.f;
+            sc[s_] = p;
+            tot += p;
+        }
+        tot = wave_sum(tot);
+        if (lane == 0) {
+            sc[sp] = tot;
+            psum_out[bh] = tot;
+        }
+    }
+    __syncthreads();
+    for (int e = tid * 4; e < E; e += 1024) {            // mbar = sum_s p_s mem_s, every row chunk loaded once for the HP heads
+        float4 a[HP];
+#pragma unroll
+        for (int hp = 0; hp < HP; ++hp) a[hp] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int s_ = 0; s_ < S; ++s_) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s_ * B + b) * E + e);
+#pragma unroll
+            for (int hp = 0; hp < HP; ++hp) {
+                const float p = heads[(long)hp * hf + E + s_];
+                a[hp].x += p * m4.x; a[hp].y += p * m4.y; a[hp].z += p * m4.z; a[hp].w += p * m4.w;
+            }
+        }
+#pragma unroll
+        for (int hp = 0; hp < HP; ++hp) *reinterpret_cast<float4*>(mbar_out + ((long)b * H + h0 + hp) * E + e) = a[hp];
+    }
+    for (int i = tid; i < HP * dh; i += 256) {
+        const int hp = i / dh, j = i - hp * dh, h = h0 + hp;
+        ctx0[(long)b * E + h * dh + j] = bv[h * dh + j] * heads[(long)hp * hf + E + sp];
+    }
+}
+__device__ __forceinline__ void xmem_fwd_h2_body(const float* qk, const float* mem, const float* bv, int B, int S, int H, int dh, float* mbar_out,
+                                                 float* psum_out, float* probs, float* ctx0, float drop_p, unsigned drop_thr, int drop_site,
+                                                 const unsigned long long* rng) {
+    xmem_fwd_multi_body<2>(qk, mem, bv, B, S, H, dh, mbar_out, psum_out, probs, ctx0, drop_p, drop_thr, drop_site, rng);
+}
+__device__ __forceinline__ void xmem_fwd_h4_body(const float* qk, const float* mem, const float* bv, int B, int S, int H, int dh, float* mbar_out,
+                                                 float* psum_out, float* probs, float* ctx0, float drop_p, unsigned drop_thr, int drop_site,
+                                                 const unsigned long long* rng) {
+    xmem_fwd_multi_body<4>(qk, mem, bv, B, S, H, dh, mbar_out, psum_out, probs, ctx0, drop_p, drop_thr, drop_site, rng);
+}
+SLNLP_ZKERNEL(xmem_fwd_h2_kernel, 256, xmem_fwd_h2_body)
+SLNLP_ZKERNEL(xmem_fwd_h4_kernel, 256, xmem_fwd_h4_body)
+
+template <int HP>
+__device__ __forceinline__ void xmem_bwd_multi_body(const float* __restrict__ mem, const float* __restrict__ bv, const float* __restrict__ probs,
+                                                    const float* __restrict__ psum, const float* __restrict__ dmbar,
+                                                    const float* __restrict__ dctx, int B, int S, int H, int dh, float* __restrict__ dsc_out,
+                                                    float* __restrict__ dqk_out, float* __restrict__ dcp, float drop_p, unsigned drop_thr,
+                                                    int drop_site, const unsigned long long* __restrict__ rng) {
+    extern __shared__ __attribute__((aligned(16))) float xm_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = H * dh, groups = H / HP;
+    const int wg = xcd_local(blockIdx.x, gridDim.x), b = wg / groups, h0 = (wg % groups) * HP;
+    const int hf = xm_head_floats(S, E), sp = (S + 3) & ~3;
+    float* heads = xm_lds;
+    for (int i = tid * 4; i < HP * E; i += 1024) {
+        const int hp = i / E, e = i - hp * E;
+        *reinterpret_cast<float4*>(heads + (long)hp * hf + e) = *reinterpret_cast<const float4*>(dmbar + ((long)b * H + h0 + hp) * E + e);
+    }
+    for (int hp = wave; hp < HP; hp += 4) {              // c = d ctx_h . bv_h; d ctx * sum_s p_s (xmem_bwd_body's wave-0 block)
+        const int h = h0 + hp;
+        const float ps = psum[(long)b * H + h];
+        float c = 0.f;
+        for (int j = lane; j < dh; j += 64) {
+            const float g = dctx[(long)b * E + h * dh + j];
+            c += g * bv[h * dh + j];
+            dcp[(long)b * E + h * dh + j] = g * ps;
+        }
+        c = wave_sum(c);
+        if (lane == 0) heads[(long)hp * hf + E + sp] = c;
+    }
+    __syncthreads();
+    row_dots_multi<HP>(heads, hf, mem, B, b, S, E, lane, wave,
+                       [&](int hp, int s_, float r) { heads[(long)hp * hf + E + s_] = r + heads[(long)hp * hf + E + sp]; });
+    __syncthreads();
+    const float scale = rsqrtf((float)dh), inv_keep = 1.f / (1.f - drop_p);
+    for (int hp = wave; hp < HP; hp += 4) {              // through the dropout mask and the softmax
+        float* t = heads + (long)hp * hf + E;
+        const long bh = (long)b * H + h0 + hp;
+        float dot = 0.f;
+        for (int s_ = lane; s_ < S; s_ += 64) {
+            float dp = t[s_];
+            if (drop_p > 0.f) dp = dropout_keep(rng, drop_site, (unsigned)bh, (unsigned)s_, drop_thr) ? dp * inv_keep : 0.f;
+            t[s_] = dp;
+            dot += probs[bh * S + s_] * dp;
+        }
+        dot = wave_sum(dot);
+        for (int s_ = lane; s_ < S; s_ += 64) {
+            const float v = probs[bh * S + s_] * (t[s_] - dot) * scale;
+            t[s_] = v;
+            dsc_out[bh * S + s_] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid * 4; e < E; e += 1024) {            // d qk = sum_s d score_s mem_s
+        float4 a[HP];
+#pragma unroll
+        for (int hp = 0; hp < HP; ++hp) a[hp] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int s_ = 0; s_ < S; ++s_) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s_ * B + b) * E + e);
+#pragma unroll
+            for (int hp = 0; hp < HP; ++hp) {
+                const float w = heads[(long)hp * hf + E + s_];
+                a[hp].x += w * m4.x; a[hp].y += w * m4.y; a[hp].z += w * m4.z; a[hp].w += w * m4.w;
+            }
+        }
+#pragma unroll
+        for (int hp = 0; hp < HP; ++hp) *reinterpret_cast<float4*>(dqk_out + ((long)b * H + h0 + hp) * E + e) = a[hp];
+    }
+}
+__device__ __forceinline__ void xmem_bwd_h2_body(const float* mem, const float* bv, const float* probs, const float* psum, const float* dmbar,
+                                                 const float* dctx, int B, int S, int H, int dh, float* dsc_out, float* dqk_out, float* dcp,
+                                                 float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* rng) {
+    xmem_bwd_multi_body<2>(mem, bv, probs, psum, dmbar, dctx, B, S, H, dh, dsc_out, dqk_out, dcp, drop_p, drop_thr, drop_site, rng);
+}
+__device__ __forceinline__ void xmem_bwd_h4_body(const float* mem, const float* bv, const float* probs, const float* psum, const float* dmbar,
+                                                 const float* dctx, int B, int S, int H, int dh, float* dsc_out, float* dqk_out, float* dcp,
+                                                 float drop_p, unsigned drop_thr, int drop_site, const unsigned long long* rng) {
+    xmem_bwd_multi_body<4>(mem, bv, probs, psum, dmbar, dctx, B, S, H, dh, dsc_out, dqk_out, dcp, drop_p, drop_thr, drop_site, rng);
+}
+SLNLP_ZKERNEL(xmem_bwd_h2_kernel, 256, xmem_bwd_h2_body)
+SLNLP_ZKERNEL(xmem_bwd_h4_kernel, 256, xmem_bwd_h4_body)
+
 // ------------------------------------------------------------------------------------------------ launchers ----
 static int xmem_init() {                  // dynamic LDS beyond 64 KiB is only needed for S in the thousands; raise once per device
     static DeviceOnce once;
@@ -239,6 +472,15 @@ static int xmem_init() {                  // dynamic LDS beyond 64 KiB is only n
         }
         return 0;
     });
+}
+
+// heads per workgroup (1: the kernels above).  env SLNLP_XMEM_HEADS = 1 / 2 / 4 forces it (A / B runs).
+static int xmem_heads_per_wg(int B, int S, int H, int dh) {
+    static const int forced = [] { const char* e = getenv("SLNLP_XMEM_HEADS"); return e ? atoi(e) : 0; }();
+    const int want = forced ? forced : 2;
+    for (int hp = want; hp >= 2; hp >>= 1)
+        if (H % hp == 0 && (size_t)hp * (H * dh + ((S + 3) & ~3) + 4) * sizeof(float) <= 65536) return hp;
+    return 1;
 }
 
 static int xmem_check(const char* who, int B, int S, int H, int dh) {
@@ -254,6 +496,13 @@ int xmem_fwd(const float* qk, const float* mem, const float* bv, int B, int S, i
     SLNLP_TRY(xmem_check("xmem_fwd", B, S, H, dh));
     SLNLP_CHECK_ARG(qk && mem && bv && mbar && psum && probs && ctx0, "xmem_fwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "xmem_fwd: bad dropout args");
+    if (const int hp = xmem_heads_per_wg(B, S, H, dh); hp > 1) {
+        const size_t l = (size_t)hp * (H * dh + ((S + 3) & ~3) + 4) * sizeof(float);
+        if (hp == 4) return zlaunch(xmem_fwd_h4_kernel, dim3(B * (H / 4)), 256, l, st, "xmem_fwd", qk, mem, bv, B, S, H, dh, mbar, psum, probs, ctx0,
+                                    drop_p, dropout_threshold(drop_p), drop_site, rng);
+        return zlaunch(xmem_fwd_h2_kernel, dim3(B * (H / 2)), 256, l, st, "xmem_fwd", qk, mem, bv, B, S, H, dh, mbar, psum, probs, ctx0, drop_p,
+                       dropout_threshold(drop_p), drop_site, rng);
+    }
     const size_t lds = (size_t)(H * dh + S + 8) * sizeof(float);
     if (lds > 65536) SLNLP_TRY(xmem_init());
     return zlaunch(xmem_fwd_kernel, dim3(B * H), 256, lds, st, "xmem_fwd", qk, mem, bv, B, S, H, dh, mbar, psum, probs, ctx0, drop_p,
@@ -268,11 +517,19 @@ int xmem_bwd(const float* mem, const float* bv, const float* probs, const float*
     SLNLP_CHECK_ARG(mem && bv && probs && psum && qk && dmbar && dctx && dsc && dqk && dcp && dbv && dmem, "xmem_bwd: null pointer");
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "xmem_bwd: bad dropout args");
     const int E = H * dh;
-    const size_t lds = (size_t)(E + S + 8) * sizeof(float);
-    if (lds > 65536) SLNLP_TRY(xmem_init());
-    SLNLP_TRY(zlaunch(xmem_bwd_kernel, dim3(B * H), 256, lds, st, "xmem_bwd", mem, bv, probs, psum, dmbar, dctx, B, S, H, dh, dsc, dqk, dcp,
-                      drop_p, dropout_threshold(drop_p), drop_site, rng));
-    return zlaunch(xmem_dmem_kernel, dim3(S * B + ceil_div(E, 256)), 256, 0, st, "xmem_dmem", probs, (const float*)dsc, dmbar, qk, B, S, H, E, dmem,
+    if (const int hp = xmem_heads_per_wg(B, S, H, dh); hp > 1) {
+        const size_t l = (size_t)hp * (E + ((S + 3) & ~3) + 4) * sizeof(float);
+        if (hp == 4) SLNLP_TRY(zlaunch(xmem_bwd_h4_kernel, dim3(B * (H / 4)), 256, l, st, "xmem_bwd", mem, bv, probs, psum, dmbar, dctx, B, S, H, dh,
+                                       dsc, dqk, dcp, drop_p, dropout_threshold(drop_p), drop_site, rng));
+        else SLNLP_TRY(zlaunch(xmem_bwd_h2_kernel, dim3(B * (H / 2)), 256, l, st, "xmem_bwd", mem, bv, probs, psum, dmbar, dctx, B, S, H, dh, dsc,
+                               dqk, dcp, drop_p, dropout_threshold(drop_p), drop_site, rng));
+    } else {
+        const size_t lds = (size_t)(E + S + 8) * sizeof(float);
+        if (lds > 65536) SLNLP_TRY(xmem_init());
+        SLNLP_TRY(zlaunch(xmem_bwd_kernel, dim3(B * H), 256, lds, st, "xmem_bwd", mem, bv, probs, psum, dmbar, dctx, B, S, H, dh, dsc, dqk, dcp,
+                          drop_p, dropout_threshold(drop_p), drop_site, rng));
+    }
+    return zlaunch(xmem_dmem_kernel, dim3(ceil_div(S, DMEM_ROWS) * B + ceil_div(E, 256)), 256, 0, st, "xmem_dmem", probs, (const float*)dsc, dmbar, qk, B, S, H, E, dmem,
                    accumulate, drop_p, dropout_threshold(drop_p), drop_site, rng, (const float*)dcp, dbv);
 }
 
