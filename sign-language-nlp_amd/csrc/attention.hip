@@ -101,6 +101,38 @@ __device__ __forceinline__ void put_planes(unsigned short* __restrict__ T, int o
     T[ATILE + off] = l;
 }
 
+// This wave's 16 rows x dc columns of an output tile, as hi / lo planes, through ITS rows of a free LDS tile T: the accumulator
+// layout holds a row's 64 columns in four pieces of 16 lanes, so storing from it takes 2 x 16 two-byte stores per lane in 32-byte
+// segments (and a 64-bit address each); from the tile a lane copies 16 bytes of a row.  Wave-local: only this wave writes and
+// reads these rows, LDS operations of a wave execute in order.  Same values as store_planes1 (split_bf16).
+__device__ __forceinline__ void store_rows_via_lds(unsigned short* __restrict__ T, const f32x4 (&o)[4], int wave, int lane, int S, int dc,
+                                                   const PlaneOut& po, long row_stride, long col0, int B, int b) {
+    const int jc = lane & 15, i0 = wave * 16 + ((lane >> 4) << 2);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put_planes(T, (i0 + r) * ALD + 16 * n + jc, o[n][r]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = wave * 16 + pass * 8 + (lane >> 3), c8 = (lane & 7) << 3;
+        if (row < S && c8 < dc) {
+            const uint4 vh = *reinterpret_cast<const uint4*>(T + row * ALD + c8), vl = *reinterpret_cast<const uint4*>(T + ATILE + row * ALD + c8);
+            const long at = ((long)row * B + b) * row_stride + col0 + c8;
+            *reinterpret_cast<uint4*>(po.hi + at) = vh;
+            *reinterpret_cast<uint4*>(po.lo + at) = vl;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                         // (the rows may be reused by this wave's next output)
+}
+// planes only (no fp32 copy, no fp8 plane), 16-byte aligned row pieces
+__device__ __forceinline__ bool planes_rows_ok(const PlaneOut& po, const void* fp32_out, int dh, long row_stride) {
+    return po.hi && po.lo && !po.q8 && !fp32_out && (dh & 7) == 0 && (row_stride & 7) == 0 &&
+           (((unsigned long long)po.hi | (unsigned long long)po.lo) & 15ull) == 0;
+}
+
 __device__ __forceinline__ void attn_self_fwd_mfma_body(
     const float* __restrict__ qkv, const long* __restrict__ ids, long ld_ids, long pad_idx, int causal, int B,
     int S, int H, int dh, float* __restrict__ ctx, float* __restrict__ probs, float drop_p, unsigned drop_thr,
@@ -197,6 +229,10 @@ __device__ __forceinline__ void attn_self_fwd_mfma_body(
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TV, 16 * n, kk, lane), frag_cols(TV + ATILE, 16 * n, kk, lane), acc[n]);
+        }
+        if (planes_rows_ok(po, ctx, dh, E)) {               // (K's tile is free since the scores; this wave's rows of it)
+            store_rows_via_lds(TK, acc, wave, lane, S, dc, po, E, (long)h * dh + d0, B, b);
+            continue;
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -347,9 +383,18 @@ __device__ __forceinline__ void attn_self_bwd_mfma_body(
             for (int n = 0; n < 4; ++n)
                 if (n < nd) acc[n] = mfma3(ah, al, frag_cols(TO, 16 * n, kk, lane), frag_cols(TO + ATILE, 16 * n, kk, lane), acc[n]);
         }
-        store(acc, 2);
+        // outputs as row pieces through this wave's rows of a tile nobody reads any more: Pd's (single chunk: dead after dV) or this
+        // chunk's dO tile (several chunks: dead after dV too, one more barrier)
+        const bool rows_out = planes_rows_ok(po, dqkv, dh, ld);
+        unsigned short* TR = nch == 1 ? TV : TO;
+        if (!rows_out) store(acc, 2);
+        if (nch > 1 && rows_out) {
+            __syncthreads();                                 // every wave is done with this chunk's dO
+            store_rows_via_lds(TR, acc, wave, lane, S, dc, po, ld, 2L * E + h * dh + d0, B, b);
+        }
         if (nch == 1) {   // dS takes dO's tile
             __syncthreads();
+            if (rows_out) store_rows_via_lds(TR, acc, wave, lane, S, dc, po, ld, 2L * E + h * dh + d0, B, b);   // (every wave is done with Pd)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -370,8 +415,13 @@ __device__ __forceinline__ void attn_self_bwd_mfma_body(
                     acc[n] = mfma3(kh, kl, frag_cols(TQ, 16 * n, kk, lane), frag_cols(TQ + ATILE, 16 * n, kk, lane), acc[n]);
                 }
         }
-        store(acq, 0);
-        store(acc, 1);
+        if (rows_out) {
+            store_rows_via_lds(TR, acq, wave, lane, S, dc, po, ld, (long)h * dh + d0, B, b);
+            store_rows_via_lds(TR, acc, wave, lane, S, dc, po, ld, (long)E + h * dh + d0, B, b);
+        } else {
+            store(acq, 0);
+            store(acc, 1);
+        }
     }
 }
 SLNLP_ZKERNEL(attn_self_bwd_mfma_kernel, 256, attn_self_bwd_mfma_body)
