@@ -69,7 +69,8 @@ const void* gemm_planes_kernel_ptr(int precision, int geo);
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs);   // the geometry a launch of these jobs takes
 void plane_job_retile(PlaneJob& j, int geo);
 void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, const void** fn, size_t* lds);
-// the block map of a merged plane-GEMM launch: units of all jobs placed on the XCDs (false: fp8 launch, keep the per-job layout)
-bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map);
+// the block map of a merged plane-GEMM launch: units of all jobs placed on the XCDs (1; 0: fp8 launch, keep the per-job layout;
+// -1: more jobs / units than a map entry can name)
+int plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map);
 
 }  // namespace slnlp

@@ -778,7 +778,7 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
 }
 
 // block map entry of a merged launch: job index | unit << PLACE_JOB_BITS (-1: padding)
-constexpr int PLACE_JOB_BITS = 10, PLACE_JOBS = 1 << PLACE_JOB_BITS;
+constexpr int PLACE_JOB_BITS = 12, PLACE_JOBS = 1 << PLACE_JOB_BITS;
 
 // GEO: the launch's tile geometry (table below); every job of a launch uses it (the host picks it per launch: plane_geo_for()).
 struct GeoInfo { int bm, bn, bks, nst; };
@@ -1118,17 +1118,18 @@ void plane_merge_geometry(const void* recorded_fn, PlaneJob* jobs, int njobs, co
 // Which workgroup computes a unit has no bearing on its result.
 constexpr long PLACE_MIN_UNITS = 256;
 constexpr int PLACE_MIN_JOBS = 4;
-bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map) {
+int plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, std::vector<int>& map) {
     int geo = -1;
     for (int g = 0; g < NGEO; ++g)
         if (merged_fn == gemm_planes_kernel_ptr(1, g) || merged_fn == gemm_planes_kernel_ptr(3, g)) geo = g;
-    if (geo < 0 || njobs > PLACE_JOBS) return false;       // (fp8 launches keep their own layout)
+    if (geo < 0) return 0;                                  // (fp8 launches keep their own layout)
+    if (njobs > PLACE_JOBS) return -1;
     long total = 0, work = 0;
     std::vector<long> ksteps(njobs);
     for (int j = 0; j < njobs; ++j) {
         const PlaneJob& J = jobs[j];
         const long units = (long)J.tiles_x * J.tiles_y * J.nks;
-        if (units >= (1L << (31 - PLACE_JOB_BITS))) return false;
+        if (units >= (1L << (31 - PLACE_JOB_BITS))) return -1;
         ksteps[j] = (J.a.K / (J.nks > 0 ? J.nks : 1) + GEO[geo].bks - 1) / GEO[geo].bks + 6;      // (+ fill, meeting, epilogue)
         total += units;
         work += units * ksteps[j];
@@ -1144,7 +1145,7 @@ bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, s
                 map.push_back(lid < units ? (j | (t << PLACE_JOB_BITS)) : -1);
             }
         }
-        return true;
+        return 1;
     }
     std::vector<int> units[8];
     long done = 0;                                          // work placed so far
@@ -1167,7 +1168,7 @@ bool plane_merge_place(const void* merged_fn, const PlaneJob* jobs, int njobs, s
     map.assign(longest * 8, -1);
     for (int k = 0; k < 8; ++k)
         for (size_t i = 0; i < units[k].size(); ++i) map[i * 8 + k] = units[k][i];
-    return true;
+    return 1;
 }
 
 template <int NSPLIT>

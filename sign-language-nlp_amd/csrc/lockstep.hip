@@ -218,7 +218,10 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
             // times it takes them (fewer operand bytes per FLOP through L2 -> LDS, gemm_planes.hip).  The K partition of every
             // job stays, so each fit's results keep the bits of its solo launch whatever the geometry.
             plane_merge_geometry(o0.fn, jobs.data(), (int)jobs.size(), &m.fn, &m.lds);
-            if (!plane_merge_place(m.fn, jobs.data(), (int)jobs.size(), map)) {
+            const int placed = plane_merge_place(m.fn, jobs.data(), (int)jobs.size(), map);
+            SLNLP_CHECK_ARG(placed >= 0, "lockstep: call site %zu (%s) merges %zu plane-GEMM jobs -- more than a block-map entry can name", i, o0.what,
+                            jobs.size());
+            if (!placed) {
                 for (size_t j = 0; j < jobs.size(); ++j) {          // fp8 launches: a job's blocks in a row, jobs on multiples of 8
                     PlaneJob& job = jobs[j];
                     const int blocks = job.tiles_x * job.tiles_y * job.nks, padded = (blocks + 7) & ~7;
