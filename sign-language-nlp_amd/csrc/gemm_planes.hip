@@ -901,7 +901,9 @@ constexpr int TWO_PER_CU_UNITS = 300;    // (a 4-fit lockstep step, 496- and 320
 //   * 256 x 256 x 32 (128 KiB, one workgroup per CU, half the operand bytes per FLOP of the 128-wide tiles) for FORWARD launches --
 //     both operands k-major, no split-K -- whose K loops are at least 1024 long and whose tiles fill the 256 CUs' rounds to 85 %:
 //     configs[4] in_proj [16384 x 1024] x [1024 x 3072], 768 tiles: 285 -> 255 us (405 TFLOP/s); FFN2 [16384 x 3072] x [3072 x 1024],
-//     256 tiles: 290 -> 236 us (436 TFLOP/s).  Not below: at K = 512 the tile's longer fill / drain is not paid back (846 tiles:
+//     256 tiles: 290 -> 236 us (436 TFLOP/s).  A single round of them needs K >= 2048: configs[4]'s out_proj (256 tiles, K = 1024) wins
+//     back to back (88 against 102 us) and loses inside the train step, where nothing covers its one workgroup per CU behind the
+//     previous kernel (step 15.00 -> 14.90 ms without it).  Not below: at K = 512 the tile's longer fill / drain is not paid back (846 tiles:
 //     185 against 183 us; 282 tiles: 88 against 67), half-empty rounds lose outright (128 tiles: 77 against 52 us), and the merged
 //     gradient groups (split-K partial tiles of 256 KiB, two-pass rings) stay 7 % ahead on the 128 x 128 x 32 ring.
 struct LaunchShape {
@@ -920,7 +922,7 @@ static int plane_geo_auto(const LaunchShape& s) {
     const int forced = g_plane_geo.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
     if (s.units128 < BIG_TILE_MIN_UNITS) return 0;
-    if (s.forward && s.min_k >= 1024 && s.units256 * 100 >= (s.units256 + 255) / 256 * 256 * 85) return 3;
+    if (s.forward && s.min_k >= 1024 && (s.units256 >= 512 || s.min_k >= 2048) && s.units256 * 100 >= (s.units256 + 255) / 256 * 256 * 85) return 3;
     return (s.min_k >= 1024 || s.units128 >= TWO_PER_CU_UNITS) ? 2 : 1;
 }
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
