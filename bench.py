@@ -513,6 +513,7 @@ def main():
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="hipGraph replay, plain stream launches, or time both during warmup and keep the faster (default)")
     ap.add_argument("--eager", action="store_true", help="same as --launch eager")
+    ap.add_argument("--dropout", type=float, default=None, help="override the workload's dropout rate (0: what the dropout epilogues cost)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -543,6 +544,8 @@ def main():
 
     from slnlp import synth, tf_engine as te
     c = dict(WORKLOADS[args.workload], precision=args.precision)
+    if args.dropout is not None:
+        c["dropout"] = args.dropout
     B, S = c["B"], c["S"]
     cfg, sd = build_sd(c, seed=1 + rank)
     if "rnn" in c:

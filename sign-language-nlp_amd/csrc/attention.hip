@@ -80,17 +80,21 @@ __device__ __forceinline__ f32x4 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 b
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
 // reductions over the 16 lanes that hold one accumulator row: row16_max / row16_sum of common.hpp (DPP, no LDS crossbar)
-// keep flags of rows row0..row0+3 at column col of a dropout site (one Philox call when row0 % 4 == 0)
-__device__ __forceinline__ unsigned keep_mask4(const unsigned long long* rng, int site, unsigned row0, unsigned col,
-                                               unsigned thr) {
+// keep flags of rows row0..row0+3 at columns col and col + 16 (bit 4 of col clear) of a dropout site: the 4 x 2 block one Philox call
+// serves when row0 % 4 == 0 (common.hpp); bits 0-3 = column col, bits 4-7 = column col + 16
+__device__ __forceinline__ unsigned keep_mask8(const DropKey& key, unsigned row0, unsigned col, unsigned thr) {
     unsigned m = 0;
     if ((row0 & 3u) == 0u) {
-        const uint4 bits = dropout_bits4(rng, site, row0 >> 2, col);
+        const uint4 bits = dropout_bits8(key, row0 >> 2, drop_cc(col));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m |= (pick_word(bits, r) >= thr ? 1u : 0u) << r;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m |= (pick_lot(bits, h, r) >= thr ? 1u : 0u) << (4 * h + r);
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m |= (dropout_keep(rng, site, row0 + r, col, thr) ? 1u : 0u) << r;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m |= (dropout_keep(key, row0 + r, col + 16 * h, thr) ? 1u : 0u) << (4 * h + r);
     }
     return m;
 }
@@ -184,7 +188,16 @@ __device__ __forceinline__ void attn_self_fwd_mfma_body(
     for (int n = 0; n < 4; ++n) {
         const int j = 16 * n + jc;
         kblock[n] = j >= S || (ids && idv[n] == pad_idx);
-        if (drop_p > 0.f && j < S && i0 < S) keep[n] = keep_mask4(rng, drop_site, (unsigned)prow0, (unsigned)j, drop_thr);
+    }
+    if (drop_p > 0.f && i0 < S) {
+        const DropKey dkey = dropout_key(rng, drop_site);
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+            if (32 * np + jc >= S) continue;     // (the pair's second column may lie past S: its flags are never used)
+            const unsigned m = keep_mask8(dkey, (unsigned)prow0, (unsigned)(32 * np + jc), drop_thr);
+            keep[2 * np] = m & 15u;
+            keep[2 * np + 1] = m >> 4;
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -315,9 +328,14 @@ __device__ __forceinline__ void attn_self_bwd_mfma_body(
     {
         unsigned keep[4] = {15u, 15u, 15u, 15u};
         if (drop_p > 0.f) {
+            const DropKey dkey = dropout_key(rng, drop_site);
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if (16 * n + jc < S && i0 < S) keep[n] = keep_mask4(rng, drop_site, (unsigned)prow0, (unsigned)(16 * n + jc), drop_thr);
+            for (int np = 0; np < 2; ++np) {
+                if (32 * np + jc >= S || i0 >= S) continue;
+                const unsigned m = keep_mask8(dkey, (unsigned)prow0, (unsigned)(32 * np + jc), drop_thr);
+                keep[2 * np] = m & 15u;
+                keep[2 * np + 1] = m >> 4;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

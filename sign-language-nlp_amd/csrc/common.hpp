@@ -83,52 +83,94 @@ __device__ __forceinline__ void probe_kernel_end() {
 }
 
 // ------------------------------------------------------------- dropout ------
-// Counter-based Philox4x32-10.  A dropout site is a logical [R, C] tensor;
-// element (r, c) takes word (r & 3) of philox(counter = {c, r >> 2, site, 0},
-// key = {seed + step}).  One call therefore serves the 4 consecutive rows one
-// lane owns in a 16x16 MFMA accumulator column.  Masks are never stored: the
-// backward kernels regenerate them from (seed, step, site, r, c).
+// Counter-based Threefry4x32-12 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11 -- the
+// 12-round form is the shortest Threefry-4x32 the paper reports as passing BigCrush; known-answer vectors of the 20-round form
+// pin the numpy restatement in tests/test_dropout_cpu.py, which the GPU masks are compared with bit for bit).  A dropout site
+// is a logical [R, C] tensor.  One call yields 128 bits = EIGHT 16-bit lots and serves the 4 x 2 block of elements
+// {rows 4 r4 .. 4 r4 + 3} x {columns c, c + 16} (bit 4 of c clear):
+//     element (r, c):  counter = {cc, r >> 2, 0, 0},  cc = c without its bit 4 = ((c >> 5) << 4) | (c & 15)
+//                      key     = {seed + phi * step (low, high word), site, 0}
+//                      lot     = 16-bit field 4 * (c >> 4 & 1) + (r & 3) of the 128 bits (field f = half f & 1 of word f >> 1)
+//                      kept iff lot >= thr16,  thr16 = round(p * 65536):  P[drop] = thr16 / 65536, within 2^-17 of p
+// -- the 4 rows of a 16 x 16 MFMA accumulator column AND the same rows of the column tile next to it, which the lane that owns
+// the first also owns in every MFMA kernel here (two column tiles per wave at least), so a call is spent on eight elements.
+// History (rounds 1-4): Philox4x32-10, 32-bit lots, four elements per call -- 40 quarter-rate 32-bit multiplies per call; the
+// dropout epilogue was a third of a forward plane-GEMM workgroup's life in a lockstep step (profiles/r04_lockstep_plane_timeline.txt).
+// Threefry is adds, rotates and xors only (88 full-rate instructions per call).  The kept values are scaled by 1 / (1 - p)
+// exactly as nn.Dropout does (the reference: positional_encoding.py:25,49, nn.Transformer's dropout at transformer.py:40-45);
+// nothing pins the reference's stream (CPU mt19937 there).  Masks are never stored: the backward kernels regenerate them from
+// (seed, step, site, r, c); slnlp_dropout_mask materialises any site's mask.
 struct RngState {
     unsigned long long seed;
     unsigned long long step;
 };
 
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const unsigned W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+// the Threefry key schedule of (seed, step, site): ONE 16-byte load of the device-resident {seed, step} and a handful of scalar
+// operations.  Kernels that draw in a loop make it once in front of the loop: written inside, the load sits in every iteration
+// with a full wait behind it (the loop's LDS stores may alias the state as far as the compiler knows).
+struct DropKey { unsigned ks[5]; };
+__device__ __forceinline__ DropKey dropout_key(const unsigned long long* rng, int site) {
+    const unsigned long long k = rng[0] + 0x9E3779B97F4A7C15ull * rng[1];
+    DropKey K;
+    K.ks[0] = (unsigned)k; K.ks[1] = (unsigned)(k >> 32); K.ks[2] = (unsigned)site; K.ks[3] = 0u;
+    K.ks[4] = 0x1BD11BDAu ^ K.ks[0] ^ K.ks[1] ^ K.ks[2] ^ K.ks[3];
+    return K;
+}
+
+#ifndef SLNLP_THREEFRY_ROUNDS
+#define SLNLP_THREEFRY_ROUNDS 12
+#endif
+__device__ __forceinline__ uint4 threefry4x32(unsigned c0, unsigned c1, const DropKey& K) {
+    constexpr int ROT[8][2] = {{10, 26}, {11, 21}, {13, 27}, {23, 5}, {6, 20}, {17, 11}, {25, 10}, {18, 20}};
+    unsigned x0 = c0 + K.ks[0], x1 = c1 + K.ks[1], x2 = K.ks[2], x3 = K.ks[3];      // counter words 2, 3 are zero
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        unsigned hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-        unsigned hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += W0;
-        key.y += W1;
+    for (int r = 0; r < SLNLP_THREEFRY_ROUNDS; ++r) {
+        if ((r & 1) == 0) {
+            x0 += x1; x1 = __builtin_rotateleft32(x1, ROT[r & 7][0]) ^ x0;
+            x2 += x3; x3 = __builtin_rotateleft32(x3, ROT[r & 7][1]) ^ x2;
+        } else {
+            x0 += x3; x3 = __builtin_rotateleft32(x3, ROT[r & 7][0]) ^ x0;
+            x2 += x1; x1 = __builtin_rotateleft32(x1, ROT[r & 7][1]) ^ x2;
+        }
+        if ((r & 3) == 3) {
+            const int s = (r + 1) >> 2;
+            x0 += K.ks[s % 5]; x1 += K.ks[(s + 1) % 5]; x2 += K.ks[(s + 2) % 5]; x3 += K.ks[(s + 3) % 5] + (unsigned)s;
+        }
     }
-    return ctr;
+    return make_uint4(x0, x1, x2, x3);
 }
 
-__device__ __forceinline__ uint4 dropout_bits4(const unsigned long long* rng, int site,
-                                               unsigned r4, unsigned c) {
-    unsigned long long k = rng[0] + 0x9E3779B97F4A7C15ull * rng[1];
-    return philox4x32_10(make_uint4(c, r4, (unsigned)site, 0u),
-                         make_uint2((unsigned)k, (unsigned)(k >> 32)));
-}
+// the call's column coordinate of column c (bit 4 of c removed) and which half of the call's lots c takes (bit 4 of c)
+__device__ __forceinline__ unsigned drop_cc(unsigned c) { return ((c >> 5) << 4) | (c & 15u); }
+__device__ __forceinline__ int drop_half(unsigned c) { return (int)((c >> 4) & 1u); }
 
-// keep-threshold: keep iff bits >= thr  (P[drop] = thr / 2^32 = p)
+// the eight lots of rows 4 r4 .. 4 r4 + 3 x columns {c, c + 16} with cc = drop_cc(c)
+__device__ __forceinline__ uint4 dropout_bits8(const DropKey& key, unsigned r4, unsigned cc) { return threefry4x32(cc, r4, key); }
+
+// keep-threshold: keep iff lot >= thr  (P[drop] = thr / 2^16)
 __host__ __device__ __forceinline__ unsigned dropout_threshold(float p) {
-    double t = (double)p * 4294967296.0;
-    return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    const double t = (double)p * 65536.0 + 0.5;
+    return t >= 65535.0 ? 65535u : (unsigned)t;
 }
 
-__device__ __forceinline__ unsigned pick_word(const uint4& v, int i) {
-    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+// lot of (row r & 3, column half `half`): field 4 * half + r.  Written as a 64-bit shift on purpose: a chain of selects over the
+// vector's elements is turned into a dynamically indexed extract by the optimiser, which the backend then serves from scratch or
+// LDS (every kernel that called it with a runtime row grew a private segment and ran a fifth slower); with static arguments the
+// shift folds into one v_lshrrev / v_and.
+__device__ __forceinline__ unsigned pick_lot(const uint4& v, int half, int r) {
+    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    return (unsigned)((half ? hi : lo) >> (16 * (r & 3))) & 0xFFFFu;
 }
 
 // single-element form (non-MFMA kernels)
+__device__ __forceinline__ bool dropout_keep(const DropKey& key, unsigned r, unsigned c, unsigned thr) {
+    const uint4 b = dropout_bits8(key, r >> 2, drop_cc(c));
+    return pick_lot(b, drop_half(c), (int)(r & 3u)) >= thr;
+}
 __device__ __forceinline__ bool dropout_keep(const unsigned long long* rng, int site,
                                              unsigned r, unsigned c, unsigned thr) {
-    uint4 b = dropout_bits4(rng, site, r >> 2, c);
-    return pick_word(b, r & 3) >= thr;
+    return dropout_keep(dropout_key(rng, site), r, c, thr);
 }
 
 // ------------------------------------------------------- bf16 plane sinks ----

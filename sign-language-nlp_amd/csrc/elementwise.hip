@@ -391,6 +391,8 @@ __device__ __forceinline__ void layernorm_bwd_rows(
     const bool drop = want_drop && drop_p > 0.f;
     const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * GS;   // one group per wave: the launch covers ceil(rows / GS) waves
     if (row0 >= rows) return;
+    DropKey dkey = {};
+    if (drop) dkey = dropout_key(rng, drop_site);
     float4 g[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -430,16 +432,18 @@ __device__ __forceinline__ void layernorm_bwd_rows(
             s1[i] = wave_sum(a1) * invE;
             s2[i] = wave_sum(a2) * invE;
         }
-        // phase 2, per column slot: the dropout bits of the slot's 4 columns (one Philox call per column serves the group's
-        // four rows -- its four words are the four rows' bits, common.hpp) live only here, then every row's outputs for the slot
+        // phase 2, per column slot: the dropout lots of the slot's 4 columns (one Philox call per column serves the group's
+        // four rows -- and the same rows 16 columns on, which belong to lane ^ 4: this HBM-bound kernel does not share them,
+        // common.hpp) live only here, then every row's outputs for the slot
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = lane * 4 + u * 256;
             if (c >= E) continue;
             uint4 kb[4];
+            const int half = drop_half((unsigned)c);                           // (c % 4 == 0: the slot's four columns share bit 4)
             if (drop) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) kb[e] = dropout_bits4(rng, drop_site, (unsigned)(row0 + i0) >> 2, (unsigned)(c + e));
+                for (int e = 0; e < 4; ++e) kb[e] = dropout_bits8(dkey, (unsigned)(row0 + i0) >> 2, drop_cc((unsigned)(c + e)));
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
@@ -460,10 +464,10 @@ __device__ __forceinline__ void layernorm_bwd_rows(
                 store_planes4(po_dx, (long)row * E + c, o);
                 if (want_drop) {
                     if (drop) {
-                        o.x = pick_word(kb[0], wsel) >= drop_thr ? o.x * ik : 0.f;
-                        o.y = pick_word(kb[1], wsel) >= drop_thr ? o.y * ik : 0.f;
-                        o.z = pick_word(kb[2], wsel) >= drop_thr ? o.z * ik : 0.f;
-                        o.w = pick_word(kb[3], wsel) >= drop_thr ? o.w * ik : 0.f;
+                        o.x = pick_lot(kb[0], half, wsel) >= drop_thr ? o.x * ik : 0.f;
+                        o.y = pick_lot(kb[1], half, wsel) >= drop_thr ? o.y * ik : 0.f;
+                        o.z = pick_lot(kb[2], half, wsel) >= drop_thr ? o.z * ik : 0.f;
+                        o.w = pick_lot(kb[3], half, wsel) >= drop_thr ? o.w * ik : 0.f;
                     }
                     if (dx_drop) *reinterpret_cast<float4*>(dx_drop + (long)row * E + c) = o;
                     store_planes4(po_drop, (long)row * E + c, o);

@@ -440,21 +440,27 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
     lds_barrier();                               // (group 1 of a KS = 2 workgroup has ended: the barrier counts the waves that are left)
     GTS_MARK(3);
     const bool per_head = g.drop_head_dim > 0;
+    DropKey dkey = {};                           // the step's Threefry key, made ONCE in front of the loop (common.hpp: dropout_key)
+    if (g.drop_p > 0.f) dkey = dropout_key(g.rng, g.drop_site);
 #pragma unroll 1
     for (int q = tid; q < (BM / 4) * BNT; q += 256) {
         const int col = q % BNT, gm0 = bm0 + 4 * (q / BNT), gn = bn0 + col;
         if (gn >= N || gm0 >= M) continue;
         const float bias = g.bias ? g.bias[gn] : 0.f;
-        uint4 bits = make_uint4(0, 0, 0, 0);
+        unsigned lot[4] = {0u, 0u, 0u, 0u};       // the quad's four 16-bit lots (common.hpp: one call serves 4 rows x columns {c, c ^ 16})
         if (g.drop_p > 0.f) {
-            if (!per_head) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
-            else {                                // one keep/drop decision per (row, head), see slnlp.h
+            if (!per_head) {
+                const uint4 bits = dropout_bits8(dkey, (unsigned)gm0 >> 2, drop_cc((unsigned)gn));
+                const int half = drop_half((unsigned)gn);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lot[r] = pick_lot(bits, half, r);
+            } else {                              // one keep/drop decision per (row, head), see slnlp.h
 #pragma unroll 1
                 for (int r = 0; r < 4; ++r) {
                     const unsigned rh = (unsigned)(gm0 + r) * (unsigned)(N / g.drop_head_dim) + (unsigned)(gn / g.drop_head_dim);
-                    const uint4 hb = dropout_bits4(g.rng, g.drop_site, rh >> 2, 0u);
-                    const unsigned wsel = pick_word(hb, rh & 3);
-                    if (r == 0) bits.x = wsel; else if (r == 1) bits.y = wsel; else if (r == 2) bits.z = wsel; else bits.w = wsel;
+                    const uint4 hb = dropout_bits8(dkey, rh >> 2, 0u);
+                    const unsigned wsel = pick_lot(hb, 0, (int)(rh & 3u));
+                    if (r == 0) lot[0] = wsel; else if (r == 1) lot[1] = wsel; else if (r == 2) lot[2] = wsel; else lot[3] = wsel;
                 }
             }
         }
@@ -476,7 +482,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
             if (g.relu == 1) v = fmaxf(v, 0.f);
             else if (g.relu == 2) v = tanhf(v);
             if (g.gate) v = g.gate_mode == 1 ? v * (1.f - gt[r] * gt[r]) : (gt[r] > 0.f ? v * g.gate_scale : 0.f);
-            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= p.drop_thr) ? v * p.drop_scale : 0.f;
+            if (g.drop_p > 0.f) v = (lot[r] >= p.drop_thr) ? v * p.drop_scale : 0.f;
             if (g.resid) v += rs[r];
             g.C[(long)gm * g.ldc + gn] = v;
         }

@@ -124,10 +124,21 @@ constexpr int TS_MAX = 1 << 16;
 constexpr int TS_W = 8;                // words per record: 5 stamps (100 MHz), {XCC id, block}, shader-clock stamps at marks 1 and 2
 __device__ unsigned long long g_ts[TS_MAX][TS_W];
 __device__ unsigned g_ts_n;
+#ifdef SLNLP_PROBE_EPI
+#define TS_CLK(slot) do { } while (0)
+#else
+#define TS_CLK(slot) do { if (slot == 1) ts[6] = __builtin_amdgcn_s_memtime(); if (slot == 2) ts[7] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #define TS_MARK(slot) do { if (threadIdx.x == 0) { ts[slot] = __builtin_amdgcn_s_memrealtime(); \
-        if (slot == 1) ts[6] = __builtin_amdgcn_s_memtime(); if (slot == 2) ts[7] = __builtin_amdgcn_s_memtime(); } } while (0)
+        TS_CLK(slot); } } while (0)
 #else
 #define TS_MARK(slot) do { } while (0)
+#endif
+#if SLNLP_PROBE_FENCES == 128 && defined(SLNLP_PROBE_EPI)
+// epilogue phases instead of the two shader-clock stamps: words 6 / 7 = 100 MHz stamps behind (1b) and behind the barrier in front of (2)
+#define TS_EPI(slot) do { if (threadIdx.x == 0) ts[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TS_EPI(slot) do { } while (0)
 #endif
 
 // The K loop of one (passes, operand layouts) variant: accumulators (and A's row sums) of output tile (bm0, bn0) over ring steps
@@ -462,6 +473,8 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, bool pl
     float* sbias = stg + ER * SLD;                           // [BN] behind the image (and behind the row-sum table / flag above)
     const bool early = g.drop_p > 0.f || g.relu == 2;        // block-uniform
     if (early && tid < BN) sbias[tid] = (g.bias && bn0 + tid < N) ? g.bias[bn0 + tid] : 0.f;
+    DropKey dkey = {};                                       // the step's Threefry key, made ONCE (common.hpp: dropout_key)
+    if (g.drop_p > 0.f) dkey = dropout_key(g.rng, g.drop_site);
 #pragma unroll 1
     for (int ch = 0; ch < ECH; ++ch) {
         __syncthreads();                                     // every thread is done with the K-loop stages / the split-K flag / the last chunk
@@ -473,33 +486,57 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, bool pl
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) stg[(lr0 + 16 * i + r) * SLD + lc0 + 16 * j] = acc[i][j][r];
+#if defined(SLNLP_PROBE_EPI) && SLNLP_PROBE_EPI == 2
+            if (ch == 0) TS_EPI(6);
+#endif
             if (early) {
+                // a lane's column tiles come in pairs 16 columns apart (wn0 and bn0 are multiples of 32): the 4 rows x 2 columns ONE
+                // Philox call serves (common.hpp).  The pair's eight values (and gate values) are READ FIRST, then taken through the
+                // chain, then written: element by element the compiler must keep every image read behind the previous image write
+                // (same array, runtime indices) -- eight dependent LDS round trips per pair, which, not the Philox, was two thirds
+                // of the dropout epilogue's 12 us (r05 timeline with a one-round Philox: 8.8 us).  Values of rows >= M / columns >= N
+                // are computed like the others and never stored by phase 2.
+                static_assert(NT % 2 == 0, "column tiles in pairs");
 #pragma unroll 1
-                for (int t = 0; t < MT * NT; ++t) {
-                    const int lm0 = lr0 + 16 * (t / NT), ln = lc0 + 16 * (t % NT);
-                    const int gm0 = bm0 + ch * ER + lm0, gn = bn0 + ln;
-                    if (gn >= N || gm0 >= M) continue;       // (never stored)
-                    const float bias = sbias[ln];
-                    uint4 bits = make_uint4(0, 0, 0, 0);
-                    if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+                for (int t = 0; t < MT * (NT / 2); ++t) {
+                    const int lm0 = lr0 + 16 * (t / (NT / 2)), ln0 = lc0 + 32 * (t % (NT / 2));
+                    const int gm0 = bm0 + ch * ER + lm0, gn0 = bn0 + ln0;
+                    if (gn0 >= N || gm0 >= M) continue;      // (never stored)
+                    float v[2][4], gt[2][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gm = gm0 + r;
-                        float v = stg[(lm0 + r) * SLD + ln] + bias;
-                        if (g.relu == 1) v = fmaxf(v, 0.f);
-                        else if (g.relu == 2) v = tanhf(v);
-                        if (gm < M) {
-                            if (g.gate) {
-                                const float gt = g.gate[(long)gm * g.ldg + gn];
-                                v = g.gate_mode == 1 ? v * (1.f - gt * gt) : (gt > 0.f ? v * g.gate_scale : 0.f);
-                            }
-                            if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[h][r] = stg[(lm0 + r) * SLD + ln0 + 16 * h];
+                            gt[h][r] = 1.f;
+                            if (g.gate && gm0 + r < M && gn0 + 16 * h < N) gt[h][r] = g.gate[(long)(gm0 + r) * g.ldg + gn0 + 16 * h];
                         }
-                        stg[(lm0 + r) * SLD + ln] = v;
-                    }
+                    const float bias[2] = {sbias[ln0], sbias[ln0 + 16]};
+                    uint4 bits = make_uint4(0, 0, 0, 0);
+                    if (g.drop_p > 0.f) bits = dropout_bits8(dkey, (unsigned)gm0 >> 2, drop_cc((unsigned)gn0));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = v[h][r] + bias[h];
+                            if (g.relu == 1) x = fmaxf(x, 0.f);
+                            else if (g.relu == 2) x = tanhf(x);
+                            if (g.gate) x = g.gate_mode == 1 ? x * (1.f - gt[h][r] * gt[h][r]) : (gt[h][r] > 0.f ? x * g.gate_scale : 0.f);
+                            if (g.drop_p > 0.f) x = (pick_lot(bits, h, r) >= job.drop_thr) ? x * job.drop_scale : 0.f;
+                            v[h][r] = x;
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stg[(lm0 + r) * SLD + ln0 + 16 * h] = v[h][r];
                 }
             }
         }
+#if defined(SLNLP_PROBE_EPI) && SLNLP_PROBE_EPI == 2
+        if (ch == 0) TS_EPI(7);
+#else
+        if (ch == 0) TS_EPI(6);
+#endif
         const int gmc = bm0 + ch * ER;                       // first row of the chunk
         const bool late_gate = !early && g.gate;
         if (job.vec_out) {
@@ -525,6 +562,9 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, bool pl
                     if (late_gate && gm < M && gn < N) gg[pass] = *reinterpret_cast<const float4*>(g.gate + (long)gm * g.ldg + gn);
                 }
                 if (pb == 0) __syncthreads();
+#if !defined(SLNLP_PROBE_EPI) || SLNLP_PROBE_EPI != 2
+                if (pb == 0 && ch == 0) TS_EPI(7);
+#endif
 #pragma unroll
                 for (int pass = 0; pass < PB; ++pass) {
                     const int row = row0 + (pb + pass) * RSTEP, gm = gmc + row;
@@ -712,14 +752,14 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
                         const int gm0 = bm0 + ch * PT + lm0, gn = bn0 + ln;
                         const bool live = gn < N && gm0 < M;
                         const float cs = (live && g.col_scale) ? g.col_scale[gn] : 1.f, bias = (live && g.bias) ? g.bias[gn] : 0.f;
-                        uint4 bits = make_uint4(0, 0, 0, 0);
-                        if (live && g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+                        uint4 bits = make_uint4(0, 0, 0, 0);     // (the call of an odd column tile is its left neighbour's: the compiler merges them)
+                        if (live && g.drop_p > 0.f) bits = dropout_bits8(dropout_key(g.rng, g.drop_site), (unsigned)gm0 >> 2, drop_cc((unsigned)gn));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[i][j][r] * cs + bias;
                             if (g.relu == 1) v = fmaxf(v, 0.f);
                             else if (g.relu == 2) v = tanhf(v);
-                            if (live && gm0 + r < M && g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                            if (live && gm0 + r < M && g.drop_p > 0.f) v = (pick_lot(bits, j & 1, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
                             stg[(lm0 + r) * SLD + ln] = v;
                         }
                     }
@@ -755,7 +795,7 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
             if (gn >= N || gm0 >= M) continue;
             const float cs = g.col_scale ? g.col_scale[gn] : 1.f, bias = g.bias ? g.bias[gn] : 0.f;
             uint4 bits = make_uint4(0, 0, 0, 0);
-            if (g.drop_p > 0.f) bits = dropout_bits4(g.rng, g.drop_site, (unsigned)gm0 >> 2, (unsigned)gn);
+            if (g.drop_p > 0.f) bits = dropout_bits8(dropout_key(g.rng, g.drop_site), (unsigned)gm0 >> 2, drop_cc((unsigned)gn));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = gm0 + r;
@@ -763,7 +803,7 @@ __device__ __forceinline__ void q8_tile(const PlaneJob& job, int lid, unsigned c
                 float v = acc[i][j][r] * cs + bias;
                 if (g.relu == 1) v = fmaxf(v, 0.f);
                 else if (g.relu == 2) v = tanhf(v);
-                if (g.drop_p > 0.f) v = (pick_word(bits, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
+                if (g.drop_p > 0.f) v = (pick_lot(bits, j & 1, r) >= job.drop_thr) ? v * job.drop_scale : 0.f;
                 if (g.resid) v += g.resid[(long)gm * g.ldr + gn];
                 if (g.C) g.C[(long)gm * g.ldc + gn] = v;
                 if (g.C_hi) {

@@ -132,6 +132,17 @@ def test_dropout_mask_statistics(ops):
     assert torch.equal(m, ops.dropout_mask(2048, 512, 0.1, 3, rng))   # deterministic
 
 
+@pytest.mark.parametrize("R,C,p,site,seed,step", [(64, 64, 0.1, 3, 99, 0), (50, 202, 0.5, 17, 1234, 7), (7, 48, 0.25, 65, 2**40 + 5, 2**33),
+                                                   (300, 33, 0.1, 1, 0, 0), (129, 160, 0.9, 200, 3, 1)])
+def test_dropout_mask_is_the_threefry_restatement_bit_for_bit(ops, R, C, p, site, seed, step):
+    """slnlp_dropout_mask == tests/threefry_ref.keep_mask (Threefry4x32-12 pinned to the published known-answer vectors by
+    tests/test_dropout_cpu.py): counter / key layout, 16-bit lots, the (c, c + 16) column pairing and the threshold."""
+    import threefry_ref as tf
+    rng = ops.make_rng(seed=seed, step=step)
+    m = ops.dropout_mask(R, C, p, site, rng).cpu().numpy()
+    assert np.array_equal(m, tf.keep_mask(R, C, p, site, seed, step))
+
+
 def _mha_ref(qkv, ids, pad, B, S, H, dh, causal, mask=None, p=0.0):
     E = H * dh
     x = qkv.view(S, B, 3, H, dh)

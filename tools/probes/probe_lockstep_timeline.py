@@ -67,6 +67,9 @@ for n in sorted(groups, key=lambda n: -n * len(groups[n])):
     ok = np.abs(ph[2]) < 1e6
     start = np.concatenate([us(L[:, 0] - L[:, 0].min()) for L in Ls])
     life_sum = np.mean([us((L[:, 4] - L[:, 0]).sum()) for L in Ls])
+    if os.environ.get("PROBE_EPI"):       # a -DSLNLP_PROBE_EPI build: words 6 / 7 are stamps behind (1b) and in front of (2)'s stores
+        e = [us(allw[:, 6] - allw[:, 3]), us(allw[:, 7] - allw[:, 6]), us(allw[:, 4] - allw[:, 7])]
+        print(f"        epilogue phases: image + element-wise (1a, 1b) {q(e[0])} | barrier {q(e[1])} | row-major stores (2) {q(e[2])}")
     print(f"  {n:5d} workgroups x {len(Ls):2d} launches: span {span:7.2f} us | first K-step {q(ph[0])} | K loop {q(ph[1])} | meeting {q(ph[2][ok])} | "
           f"epilogue {q(ph[3][ok])} | life {q(ph[4])} | start p50/p90 {np.percentile(start, 50):6.1f} {np.percentile(start, 90):6.1f} | "
           f"sum of lives / span = {life_sum / span:5.1f} workgroups alive on average")
