@@ -118,6 +118,18 @@ int slnlp_set_gemm_ks(int ks);
 int slnlp_set_fp8_tile(int tile);
 int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
                      int64_t scratch_bytes, void* stream);
+/* The decoder's products: the reference decodes ONE target position (transformer.py:82-87), so every nn.Linear of its
+ * decoder (and the generator, transformer.py:46-48,88) is y[B rows, N] = x[B rows, K] W[N, K]^T on a dependent chain.
+ * Both operands as k-major bf16 hi / lo planes (A_hi / A_lo / lda_p, B_hi / B_lo / ldb_p; rows zero-padded to multiples of
+ * 64, strides multiples of 64 covering K); each wave loads its MFMA fragments straight from the planes -- no conversion, no
+ * LDS staging, no barrier in the K loop.  Same epilogue fields as slnlp_gemm (bias, relu, gate, dropout incl. drop_head_dim,
+ * resid, C and / or C_hi / C_lo); the K sum is (first half of the 64-k tiles) + (second half), as slnlp_gemm defines it. */
+int slnlp_gemm_rows(const slnlp_gemm_args* args, void* stream);
+/* Output tile of slnlp_gemm_rows launches: -1 = automatic (16 x 16 for one fit's launch -- it is bound by what ONE compute unit can
+ * load, so the panels are spread over as many as possible -- 64 x 16 or 64 x 32 for the merged launches of fits in lockstep, which
+ * pay for total bytes instead); 0 / 1 / 2 force 16 x 16, 64 x 16, 64 x 32.  A tuning / test knob: the K sum is defined per 64-k
+ * tile (partial products added in tile order), so results do not depend on it. */
+int slnlp_set_rows_tile(int tile);
 /* fp32 [R,K] rows (row stride ld) -> OCP e4m3 rows with one fp32 scale per row: scale[r] = max|x[r,:]| / 448 (1 for an
  * all-zero row), q[r,k] = e4m3(x[r,k] / scale[r]); row stride of q = ldq bytes.  The weight operand of precision 8. */
 int slnlp_quant_rows_fp8(const float* x, int64_t ld, int R, int K, uint8_t* q, int64_t ldq, float* scale, void* stream);

@@ -485,6 +485,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid_x, int bi
             if (g.drop_p > 0.f) v = (lot[r] >= p.drop_thr) ? v * p.drop_scale : 0.f;
             if (g.resid) v += rs[r];
             g.C[(long)gm * g.ldc + gn] = v;
+            if (g.C_hi) {                        // also as planes: the operand of a B-row product (gemm_rows.hip)
+                unsigned short hh, ll;
+                split_bf16(v, hh, ll);
+                g.C_hi[(long)gm * g.ldc_p + gn] = hh;
+                if (g.C_lo) g.C_lo[(long)gm * g.ldc_p + gn] = ll;
+            }
         }
     }
 }
@@ -524,6 +530,8 @@ __global__ __launch_bounds__(256 * KS) void gemm_group_kernel(const GemmGroupPar
         p.a.B += (long)z * p.a.batch_stride_b;
         p.a.C += (long)z * p.a.batch_stride_c;
         if (p.a.resid) p.a.resid += (long)z * p.a.batch_stride_c;
+        if (p.a.C_hi) p.a.C_hi += (long)z * p.a.batch_stride_c;     // (plane outputs share C's column layout: ldc_p = ldc)
+        if (p.a.C_lo) p.a.C_lo += (long)z * p.a.batch_stride_c;
     }
     const int bx = lid % gx, by = lid / gx;
     probe_kernel_begin();
@@ -600,6 +608,7 @@ static int fill_params(const slnlp_gemm_args& a, GemmParams& p) {
     SLNLP_CHECK_ARG(!(a.a_kmajor == 0 && a.b_kmajor != 0), "gemm: layout (A m-major, B k-major) not built");
     SLNLP_CHECK_ARG(a.drop_head_dim >= 0 && (a.drop_head_dim == 0 || a.N % a.drop_head_dim == 0),
                     "gemm: drop_head_dim %d does not divide N %d", a.drop_head_dim, a.N);
+    SLNLP_CHECK_ARG(!a.C_hi || a.ldc_p >= a.N, "gemm: ldc_p < N");
     p.a = a;
     p.drop_thr = dropout_threshold(a.drop_p);
     p.drop_scale = 1.f / (1.f - a.drop_p);
@@ -666,6 +675,8 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
                 a.batch = 0;
                 a.A += (long)z * jobs[i].batch_stride_a; a.B += (long)z * jobs[i].batch_stride_b; a.C += (long)z * jobs[i].batch_stride_c;
                 if (a.resid) a.resid += (long)z * jobs[i].batch_stride_c;
+                if (a.C_hi) a.C_hi += (long)z * jobs[i].batch_stride_c;
+                if (a.C_lo) a.C_lo += (long)z * jobs[i].batch_stride_c;
                 SLNLP_TRY(gemm(a, s));
             }
         }

@@ -207,6 +207,15 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
                     m.block = dim3(threads);
                 }
             }
+            {   // the decoder's B-row products pick their tile for K fits' worth of workgroups (same bits whatever the tile: gemm_rows.hip)
+                dim3 gr;
+                size_t lds = 0;
+                if (const void* twin = gemm_rows_for_fits(o0.fn, o0.args.data(), K, &gr, &lds)) {
+                    m.fn = twin;
+                    m.grid = dim3(gr.x, gr.y, K);
+                    m.lds = lds;
+                }
+            }
         } else if (o0.kind == REC_PLANE_GROUP) {
             std::vector<PlaneJob> jobs;
             std::vector<int> map;

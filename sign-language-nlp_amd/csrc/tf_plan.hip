@@ -79,6 +79,11 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     p->w = carve(*cfg, buf->workspace);
     bool ok = attn_init() == 0 && gemm_planes_init() == 0;
     p->use_planes = (cfg->E % 64 == 0) && (cfg->F % 64 == 0);
+    {   // SLNLP_DEC_ROWS=0: the decoder's products on gemm.hip's fp32-operand kernel again (A / B measurements; another arithmetic:
+        // that kernel splits its operands itself, with a truncated head)
+        const char* e = getenv("SLNLP_DEC_ROWS");
+        p->use_rows = p->use_planes && cfg->E <= 1024 && cfg->F <= 1024 && !(e && atoi(e) == 0);
+    }
     if (ok && cfg->precision == 8) {     // rows the fp8 forward products read: one {offset, K} entry each, uploaded once
         std::vector<QuantRow> rows;
         auto block = [&](long off, int nrows, int K) {
@@ -145,13 +150,18 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
 // Decoder layer l up to its cross-attention query: self-attention over ONE key (softmax == 1 -> out_proj(v_proj(t));
 // the q/k rows of in_proj are dead; in train mode the weight-1 "attention" is still dropped per (row, head) -- fused into
 // the V projection), residual + norm1, then q = in_proj_q(t1) (transformer.py:82-87).
-int slnlp_tf_plan::dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const {
+int slnlp_tf_plan::dec_self_block(int l, const float* t, const PP* tp, int B, float p, hipStream_t st) const {
     const slnlp_tf_plan* pl = this;
     const int E = cfg.E, dh = E / cfg.H;
-    const unsigned long long* rng = buf.rng;
-    (void)rng;
     const DecP& q = L.dec[l];
     const DecA& a = w.dec[l];
+    if (use_rows) {        // B-row products on planes (gemm_rows.hip): every producer also emits its output as the next product's operand
+        SLNLP_TRY(pl->linear_r(*tp, B, E, q.sin_w + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, &a.vp, st, dh));
+        SLNLP_TRY(pl->linear_r(a.vp, B, E, q.sout_w, E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, nullptr, st));
+        SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st, a.t1p.out()));
+        SLNLP_TRY(pl->linear_r(a.t1p, B, E, q.cin_w, E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, nullptr, st));
+        return 0;
+    }
     SLNLP_TRY(pl->linear(t, B, E, pl->P(q.sin_w) + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, st, dh));
     SLNLP_TRY(pl->linear(a.v, B, E, pl->P(q.sout_w), E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, st));
     SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st));
@@ -170,14 +180,15 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     // The target side up to the first cross-attention (embedding, layer 0's single-key self-attention block and its
     // query projection: five B-row launches) depends on nothing the encoder computes; everything runs on the caller's
     // ONE stream in program order (round 1 forked it to a side stream: -3 % and a data race).
-    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st));
-    SLNLP_TRY(dec_self_block(0, w.t0, B, p, st));
     const bool up = use_planes;
     if (up) {   // weights as bf16 planes: current unless the arena changed outside the fused optimizer step
         SLNLP_TRY(prepare_planes(B, st));
         SLNLP_TRY(ensure_wplanes(st));
         SLNLP_TRY(ensure_wq(st));
     }
+    SLNLP_TRY(embed_fwd(y, 1, B, 1, E, c.Vt, pl->P(L.tgt_emb), pl->buf.pe, w.t0, sqrtf((float)E), p, SITE_TGT_EMB, rng, c.pad_tgt, st,
+                        use_rows ? w.t0p.out() : PlaneOut{}));
+    SLNLP_TRY(dec_self_block(0, w.t0, &w.t0p, B, p, st));
     SLNLP_TRY(embed_fwd(X, S, B, S, E, c.Vs, pl->P(L.src_emb), pl->buf.pe, w.x0, sqrtf((float)E), p, SITE_SRC_EMB, rng, -1, st,
                         up ? w.x0p.out() : PlaneOut{}, w.emb_keep));
 
@@ -211,10 +222,11 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     SLNLP_TRY(layernorm_fwd(x, pl->P(L.encn_w), pl->P(L.encn_b), M, E, 1e-5f, w.mem, w.st_mem, st, up ? w.memp.out() : PlaneOut{}));
 
     const float* t = w.t0;
+    const PP* tp = &w.t0p;
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
-        if (l > 0) SLNLP_TRY(dec_self_block(l, t, B, p, st));   // (layer 0's block ran ahead of the encoder, above)
+        if (l > 0) SLNLP_TRY(dec_self_block(l, t, tp, B, p, st));   // (layer 0's block ran ahead of the encoder, above)
         // cross-attention over the memory itself: with ONE query per sequence the K / V projections of the S memory rows
         // re-associate into B-row products (attention_mem.hip) -- no [S*B, 2E] projection, no K|V gradient GEMMs:
         // qk = Wk_h^T q_h (batched GEMM) -> scores / softmax / dropout / mbar (+ ctx0 = bv sum_s p_s) -> ctx = Wv_h mbar + ctx0
@@ -223,18 +235,33 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
             const slnlp_gemm_args j1 = pl->head_expand(a.q, Wk, a.qk, B, H, dh);
             SLNLP_TRY(gemm_group(&j1, 1, st));
             SLNLP_TRY(xmem_fwd(a.qk, w.mem, pl->P(q.cin_b) + 2 * E, B, S, H, dh, a.mbar, a.psum, a.xprobs, a.xctx, p, pl->dec_site(l, 2), rng, st));
-            const slnlp_gemm_args j2 = pl->head_reduce(a.mbar, Wv, a.xctx, a.xctx, B, H, dh);
+            slnlp_gemm_args j2 = pl->head_reduce(a.mbar, Wv, a.xctx, a.xctx, B, H, dh);
+            if (use_rows) { j2.C_hi = a.xctxp.hi; j2.C_lo = a.xctxp.lo; j2.ldc_p = E; }      // ... and as planes, for the out projection
             SLNLP_TRY(gemm_group(&j2, 1, st));
         }
-        SLNLP_TRY(pl->linear(a.xctx, B, E, pl->P(q.cout_w), E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, st));
-        SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st));
-        SLNLP_TRY(pl->linear(a.t2, B, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, st));
-        SLNLP_TRY(pl->linear(a.h, B, F, pl->P(q.l2_w), E, pl->P(q.l2_b), a.y3, E, 0, p, pl->dec_site(l, 5), a.t2, st));
-        SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st));
+        if (use_rows) {
+            SLNLP_TRY(pl->linear_r(a.xctxp, B, E, q.cout_w, E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, nullptr, st));
+            SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st, a.t2p.out()));
+            SLNLP_TRY(pl->linear_r(a.t2p, B, E, q.l1_w, F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, &a.hp, st));
+            SLNLP_TRY(pl->linear_r(a.hp, B, F, q.l2_w, E, pl->P(q.l2_b), a.y3, E, 0, p, pl->dec_site(l, 5), a.t2, nullptr, st));
+            SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st, a.t3p.out()));
+        } else {
+            SLNLP_TRY(pl->linear(a.xctx, B, E, pl->P(q.cout_w), E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, st));
+            SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st));
+            SLNLP_TRY(pl->linear(a.t2, B, E, pl->P(q.l1_w), F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, st));
+            SLNLP_TRY(pl->linear(a.h, B, F, pl->P(q.l2_w), E, pl->P(q.l2_b), a.y3, E, 0, p, pl->dec_site(l, 5), a.t2, st));
+            SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st));
+        }
         t = a.t3;
+        tp = &a.t3p;
     }
-    SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
-    SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
+    if (use_rows) {
+        SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st, w.tfinp.out()));
+        SLNLP_TRY(pl->linear_r(w.tfinp, B, E, L.lin_w, c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, nullptr, st));
+    } else {
+        SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
+        SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));
+    }
     // log_softmax (transformer.py:88-89) + the criterion skorch applies to it (helper.py:61-70)
     // the caller's copy of the log-probs is written by the same kernel (no device-to-device copy); in lockstep it lands
     // in the epoch buffer at the batch's row offset and the loss in the epoch's loss history

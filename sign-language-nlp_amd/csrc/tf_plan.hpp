@@ -155,6 +155,7 @@ struct DecA {
     float *qk, *mbar, *psum;                 // cross-attention without K / V projections (attention_mem.hip): kept for the backward
     float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gt1, *gA1, *gB1, *gv, *gt0;
     float *dmbar, *dsc, *dqk, *dcp;          // its gradients: d mbar, d scores, d qk [B*H, .], d ctx * sum_s p_s [B, E]
+    PP vp, t1p, xctxp, t2p, hp, t3p;         // operands of the layer's B-row products as planes (gemm_rows.hip); rows padded to 64
 };
 struct Ws {
     float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp, *row_nll;
@@ -164,6 +165,7 @@ struct Ws {
     void *emb_scratch_src, *emb_scratch_tgt;
     unsigned char* emb_keep;   // 4 keep bits per float4 of the source embedding's dropout (read by its backward)
     PP x0p, memp, wp;                   // wp: planes of the whole parameter arena (same offsets)
+    PP t0p, tfinp;                      // target embedding / final decoder LayerNorm as planes (operands of B-row products)
     unsigned char* wq;                  // precision 8: e4m3 plane of the arena (same offsets; only the GEMM weight rows are filled)
     float* wscale;                      // [qrows] per-row scales
     QuantRow* qrow_table;               // [qrows] device table for the quantiser
@@ -305,6 +307,21 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.ctxp = pp(E, true); a.x1p = pp(E, true); a.hp = pp(F, true); a.x2p = pp(E, true);
         a.d2p = pp(E); a.ghp = pp(F); a.d1p = pp(E); a.gqkvp = pp(3 * E);
     }
+    {   // the decoder's B-row operands (rows padded to 64: the padding stays zero from the region's memset)
+        const size_t Bp = (B + 63) / 64 * 64;
+        auto ppd = [&](size_t cols) {
+            PP q;
+            q.hi = b.take<unsigned short>(Bp * cols);
+            q.lo = b.take<unsigned short>(Bp * cols);
+            return q;
+        };
+        w.t0p = ppd(E);
+        w.tfinp = ppd(E);
+        for (int i = 0; i < c.N; ++i) {
+            DecA& a = w.dec[i];
+            a.vp = ppd(E); a.t1p = ppd(E); a.xctxp = ppd(E); a.t2p = ppd(E); a.hp = ppd(F); a.t3p = ppd(E);
+        }
+    }
     {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
         // (the weight gradients' partial tiles: [3E or F] x [E or F] outputs rounded up to the widest (256 x 256) tile, x MAX_SPLITK)
         const size_t nx = ((E > F ? E : F) + 255) / 256 * 256, ny = ((3 * E > F ? 3 * E : F) + 255) / 256 * 256;
@@ -367,16 +384,18 @@ struct slnlp_tf_plan {
         wplanes_gen = g;
         return 0;
     }
-    // the arena range whose planes have readers: the encoder layers' weights (everything else -- embeddings, the decoder's B-row
-    // GEMMs, the generator -- is read as fp32); the optimizer kernels write planes for this range only
+    // the arena range whose planes have readers: everything behind the embeddings -- the encoder layers' weights (plane GEMMs),
+    // the decoder layers' and the generator's (the B-row products, gemm_rows.hip); the embedding tables are gathered as fp32.
+    // The optimizer kernels write planes for this range only
     long wplane_begin() const { return L.enc.empty() ? 0 : L.enc[0].in_w; }
-    long wplane_end() const { return L.enc.empty() ? 0 : L.encn_w; }
+    long wplane_end() const { return L.enc.empty() ? 0 : L.total; }
     // the optimizer just rewrote the arena (and, with planes, the planes with it)
     void params_stepped() {
         const unsigned long long g = bump_params_generation(buf.params);
         if (use_planes) wplanes_gen = g;
     }
     bool use_planes = false;   // E, F multiples of 64: M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
+    bool use_rows = false;     // ... and the decoder's B-row products on planes, register-direct (gemm_rows.hip; K <= 1024)
     int planes_B = -1;         // batch size the activation planes' zero padding is valid for
 
     float* P(long off) const { return buf.params + off; }
@@ -384,7 +403,7 @@ struct slnlp_tf_plan {
     int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
     int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
 
-    int dec_self_block(int l, const float* t, int B, float p, hipStream_t st) const;
+    int dec_self_block(int l, const float* t, const PP* tp, int B, float p, hipStream_t st) const;
 
     // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
     int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
@@ -496,6 +515,22 @@ struct slnlp_tf_plan {
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
         a.precision = prec3();
         return gemm(a, st);
+    }
+    // the same product for the decoder's B rows: both operands as planes, register-direct (gemm_rows.hip)
+    int linear_r(const PP& x, int M, int K, long woff, int N, const float* bias, float* y, long ldy, int relu, float p, int site,
+                 const float* resid, const PP* outp, hipStream_t st, int drop_head_dim = 0) const {
+        slnlp_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
+        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; a.b_kmajor = 1;
+        a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+        a.bias = bias; a.relu = relu;
+        a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
+        a.resid = resid; a.ldr = ldy;
+        if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
+        a.precision = prec3();
+        a.drop_head_dim = drop_head_dim;
+        return gemm_rows(a, st);
     }
     slnlp_gemm_args dgrad_p_args(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
                                  float gate_scale, const float* resid, const PP* outp) const {

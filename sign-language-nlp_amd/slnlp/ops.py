@@ -133,6 +133,30 @@ def gemm_planes(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, prec
     return (out, cp) if want_planes else out
 
 
+def gemm_rows(Ap, Bp, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0,
+              drop_site=0, rng=None, drop_head_dim=0, resid=None, want_planes=False):
+    """C = A B^T for a few rows (the decoder's products) over k-major planes Ap = (hi, lo), Bp = (hi, lo): slnlp_gemm_rows."""
+    _lib.require_gpu()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=Ap[0].device)
+    a = GemmArgs()
+    a.C, a.ldc, a.M, a.N, a.K = ptr(out), out.stride(0), M, N, K
+    a.a_kmajor, a.b_kmajor, a.precision = 1, 1, precision
+    a.A_hi, a.A_lo, a.lda_p = ptr(Ap[0]), ptr(Ap[1]), Ap[0].stride(0)
+    a.B_hi, a.B_lo, a.ldb_p = ptr(Bp[0]), ptr(Bp[1]), Bp[0].stride(0)
+    a.bias, a.relu = ptr(bias), int(relu)
+    a.gate, a.ldg, a.gate_scale, a.gate_mode = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale, gate_mode
+    a.drop_p, a.drop_site, a.rng, a.drop_head_dim = drop_p, drop_site, ptr(rng), drop_head_dim
+    a.resid, a.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    cp = None
+    if want_planes:
+        cp = (torch.zeros(pad64(M), pad64(N), dtype=torch.int16, device=out.device),
+              torch.zeros(pad64(M), pad64(N), dtype=torch.int16, device=out.device))
+        a.C_hi, a.C_lo, a.ldc_p = ptr(cp[0]), ptr(cp[1]), cp[0].stride(0)
+    check(load().slnlp_gemm_rows(C.byref(a), stream_ptr()), "gemm_rows")
+    return (out, cp) if want_planes else out
+
+
 def embed_fwd(ids, table, pe, *, B, S, scale=None, drop_p=0.0, drop_site=0, rng=None, nan_idx=-1):
     _lib.require_gpu()
     V, E = table.shape

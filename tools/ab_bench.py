@@ -3,7 +3,8 @@ library under sign-language-nlp_amd/lib/ (libslnlp.so, or libslnlp_probe<name>.s
 workloads run in fresh child processes, variants interleaved, `--rounds` times.
 
     python tools/ab_bench.py --variants ,old --workloads cfg2,cfg5,ls15 [--rounds 2]
-        ""    = the product library;  old = lib/libslnlp_probeold.so  (build: see tools/gpu/steps.sh, step `ab`)
+        ""    = the product library;  old = lib/libslnlp_probeold.so (make VARIANT=old in a checkout of the old tree);
+        NAME=VALUE = the product library with that environment knob (e.g. SLNLP_DEC_ROWS=0); join with "+"
 workloads: cfg2 / cfg5 / cfg3 / cfg3gru (bench.py lines, ms per step), ls4 / ls15 (tools/bench_lockstep.py, ms per lockstep step),
            nodrop (cfg2 with dropout 0)
 """
@@ -20,7 +21,12 @@ a = ap.parse_args()
 def run(variant, wl):
     env = dict(os.environ)
     env.pop("SLNLP_PROBE_LIB", None)
-    if variant: env["SLNLP_PROBE_LIB"] = variant
+    for part in (variant.split("+") if variant else []):       # "old", "SLNLP_DEC_ROWS=0", "old+X=1": a library and / or environment knobs
+        if "=" in part:
+            k, v = part.split("=", 1)
+            env[k] = v
+        else:
+            env["SLNLP_PROBE_LIB"] = part
     if wl.startswith("ls"):
         cmd = [sys.executable, "tools/bench_lockstep.py", "--workload", "cfg2", "--ks", wl[2:], "--steps", "12"]
     elif wl == "nodrop":

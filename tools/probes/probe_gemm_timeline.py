@@ -17,8 +17,12 @@ lib.slnlp_probe_gemm_ts.restype = C.c_int
 lib.slnlp_probe_gemm_ts.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros((1 << 14, 6), dtype=np.uint64)
 
+lib.slnlp_probe_rows_ts.restype = C.c_int
+lib.slnlp_probe_rows_ts.argtypes = [C.c_void_p, C.c_int]
+READ = [lib.slnlp_probe_gemm_ts]        # which recorder report() reads: the fp32-operand kernel's or the B-row plane kernel's (gemm_rows.hip)
+
 def read():
-    n = lib.slnlp_probe_gemm_ts(buf.ctypes.data, buf.shape[0])
+    n = READ[0](buf.ctypes.data, buf.shape[0])
     assert n >= 0
     return buf[:n].astype(np.int64).copy()
 
@@ -58,3 +62,11 @@ Wt = W.T.contiguous()
 report("dgrad [50x512]x[512x512] (W m-major) +res", lambda: ops.gemm(x, Wt, M=B, N=E, K=E, b_kmajor=False, resid=R, out=out))
 W3 = rnd(3 * E, E); out3 = torch.empty(B, 3 * E, device="cuda")
 report("linear [50x512]x[512x1536]",                lambda: ops.gemm(x, W3, M=B, N=3 * E, K=E, out=out3))
+
+# the same products on plane operands, register-direct (gemm_rows.hip): entry -> first tile's operands landed -> partials stored ->
+# K sum done -> epilogue done
+READ[0] = lib.slnlp_probe_rows_ts
+xp, Wp, W3p = ops.split_planes(x), ops.split_planes(W), ops.split_planes(W3)
+report("rows linear [50x512]x[512x512] bias",       lambda: ops.gemm_rows(xp, Wp, M=B, N=E, K=E, bias=bias, out=out))
+report("rows linear ... + dropout + residual",      lambda: ops.gemm_rows(xp, Wp, M=B, N=E, K=E, bias=bias, drop_p=0.1, drop_site=3, rng=rng, resid=R, out=out))
+report("rows linear [50x512]x[512x1536]",           lambda: ops.gemm_rows(xp, W3p, M=B, N=3 * E, K=E, out=out3))
