@@ -125,6 +125,13 @@ int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int nj
  * LDS staging, no barrier in the K loop.  Same epilogue fields as slnlp_gemm (bias, relu, gate, dropout incl. drop_head_dim,
  * resid, C and / or C_hi / C_lo); the K sum is (first half of the 64-k tiles) + (second half), as slnlp_gemm defines it. */
 int slnlp_gemm_rows(const slnlp_gemm_args* args, void* stream);
+/* The backward pair of such a product in ONE launch (autograd's two mm calls for nn.Linear at batch rows):
+ *   dgrad: dX[B rows, Kin] = dY[B rows, Nout] W[Nout, Kin] (+ the slnlp_gemm epilogue: gate, dropout, residual, planes out) --
+ *          A = dY planes k-major, B = W planes NOT k-major (m-major: k = W's row);
+ *   wgrad: dW[Nout, Kin] = dY^T x, rowsum_a = db[Nout] = column sums of dY (optional) -- A = the same dY planes, B = x planes, both
+ *          NOT k-major, K = the batch rows (plane rows beyond them must be zero), C = dW fp32, no epilogue.
+ * Same precision for both; K sums per 64-k tile in tile order, as slnlp_gemm_rows. */
+int slnlp_gemm_rows_bwd(const slnlp_gemm_args* dgrad, const slnlp_gemm_args* wgrad, void* stream);
 /* Output tile of slnlp_gemm_rows launches: -1 = automatic (16 x 16 for one fit's launch -- it is bound by what ONE compute unit can
  * load, so the panels are spread over as many as possible -- 64 x 16 or 64 x 32 for the merged launches of fits in lockstep, which
  * pay for total bytes instead); 0 / 1 / 2 force 16 x 16, 64 x 16, 64 x 32.  A tuning / test knob: the K sum is defined per 64-k

@@ -20,6 +20,7 @@
 //  * the epilogue (bias -> activation -> gate -> dropout -> residual; fp32 and / or planes out) runs in the accumulator layout;
 //    its bias / gate / residual values and the dropout key are requested behind the operand loads, before the first MFMA.
 // A SLNLP_ZKERNEL: K fits in lockstep share one launch through grid.z (launch.hpp).
+#include <algorithm>
 #include <atomic>
 
 #include "common.hpp"
@@ -65,10 +66,40 @@ constexpr int RT_MAX_KTILES = 16;             // K <= 1024
 // fragments, hi and lo, every byte of the workgroup's panels loaded by exactly one wave.  The partials meet in LDS and are added
 // in TILE ORDER -- C = ((P_0 + P_1) + P_2) + ... -- which is the DEFINITION of this kernel's K sum: one value per product however
 // many waves, workgroups or fits share the launch, whatever the tile.
-template <int NSPLIT, int MT, int NT>
-__device__ __forceinline__ void gemm_rows_body(RowsParams p) {
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef __attribute__((address_space(1))) const void* glb_vp;
+
+// ---- m-major operands (the data gradient's W [k][n], both operands of a weight gradient): a wave stages ITS 64-k x 16-row
+// image [64 k][16 rows] of a plane (2 KiB, 32-byte rows) by LDS-DMA and reads MFMA fragments with the transposing LDS read.  The
+// image is private to the wave, so the only ordering needed is the wave's own s_waitcnt vmcnt (no barrier).
+constexpr int RT_IMG = 64 * 16;               // elements of one image
+__device__ __forceinline__ void rows_dma_image(const unsigned short* __restrict__ plane, long ld, int k0, int r0, unsigned short* img, int lane) {
+    // two instructions of 64 lanes x 16 B: lane -> k-row 32 q + lane / 2, half lane % 2; the destination is wave-uniform base + lane x 16
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned short* src = plane + (long)(k0 + 32 * q + (lane >> 1)) * ld + r0 + 8 * (lane & 1);
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(img + q * 512), 16, 0, 0);
+    }
+}
+// fragment of rows 0 .. 15 of the image, k in [32 kk, 32 kk + 32): lane (i = l & 15) addresses k-row kb + i / 4, rows 4 (i % 4) .. + 3
+// of a 4 (k) x 16 (row) block and receives the 4 k-values of row i (ds_read_b64_tr_b16)
+__device__ __forceinline__ bf16x8 rows_tr_frag(const unsigned short* img, int kk, int lane) {
+    const int i = lane & 15, kb = kk * 32 + ((lane >> 4) << 3) + (i >> 2);
+    const unsigned short* p0 = img + kb * 16 + ((i & 3) << 2);
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + 4 * 16));
+    const s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// One product unit: output tile (bx, by) of 16 MT rows x 16 NT columns.  BK: the B operand is k-major (forward products: fragments
+// straight from the plane) or m-major (data gradients: the wave's image through LDS, above).  smem: [partials][wave images].
+template <int NSPLIT, int MT, int NT, bool BK>
+__device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, float* part) {
     static_assert(MT * NT <= RT_WAVES, "one epilogue tile per wave");
-    extern __shared__ __attribute__((aligned(16))) float part[];      // [ktiles][MT x NT tiles][64 lanes][4]
     const slnlp_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #if SLNLP_PROBE_FENCES == 256
@@ -86,7 +117,7 @@ __device__ __forceinline__ void gemm_rows_body(RowsParams p) {
     } rts_flush{rts};
     RTS_MARK(0);
 #endif
-    const int bn0 = blockIdx.x * 16 * NT, bm0 = blockIdx.y * 16 * MT;
+    const int bn0 = bx * 16 * NT, bm0 = by * 16 * MT;
     const int M = g.M, N = g.N;
     const int ktiles = (g.K + 63) >> 6;
     // this lane's fragment rows and its k-octet inside a 32-k step.  The planes are zero-padded to multiples of 64 rows and weight
@@ -95,6 +126,7 @@ __device__ __forceinline__ void gemm_rows_body(RowsParams p) {
     const int am_last = ((M + 15) / 16 - 1) * 16, bn_last = ((N + 15) / 16 - 1) * 16;
     const long koct = 8 * (lane >> 4);
     const unsigned short *ah[MT], *al[MT], *bh[NT], *bl[NT];
+    int bcol[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const long off = (long)(min(bm0 + 16 * i, am_last) + (lane & 15)) * g.lda_p + koct;
@@ -102,9 +134,12 @@ __device__ __forceinline__ void gemm_rows_body(RowsParams p) {
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const long off = (long)(min(bn0 + 16 * j, bn_last) + (lane & 15)) * g.ldb_p + koct;
+        bcol[j] = min(bn0 + 16 * j, bn_last);
+        const long off = (long)(bcol[j] + (lane & 15)) * g.ldb_p + koct;
         bh[j] = g.B_hi + off; bl[j] = g.B_lo + off;
     }
+    // (m-major B: this wave's images, behind the partial tiles: [NT column tiles][hi, lo][64 k][16 n])
+    unsigned short* bimg = reinterpret_cast<unsigned short*>(part + (size_t)ktiles * MT * NT * 256) + wave * NT * 2 * RT_IMG;
 
     // what the epilogue will want: wave w < MT * NT runs it for MFMA tile (w / NT, w % NT); the lane holds rows gm0 .. gm0 + 3 of column gn
     const int ei = wave / NT, ej = wave % NT;
@@ -126,13 +161,23 @@ __device__ __forceinline__ void gemm_rows_body(RowsParams p) {
 
     for (int t = wave; t < ktiles; t += RT_WAVES) {
         bf16x8 fa[2][MT], la[2][MT], fb[2][NT], lb[2][NT];
+        if (!BK) {
+            if (t != wave) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the images' last fragment reads: LDS operations of a wave retire in order)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                rows_dma_image(g.B_hi, g.ldb_p, t * 64, bcol[j], bimg + (2 * j) * RT_IMG, lane);
+                if (NSPLIT == 3) rows_dma_image(g.B_lo, g.ldb_p, t * 64, bcol[j], bimg + (2 * j + 1) * RT_IMG, lane);
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int k = t * 64 + kk * 32;
+            if (BK) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                fb[kk][j] = *reinterpret_cast<const bf16x8*>(bh[j] + k);
-                if (NSPLIT == 3) lb[kk][j] = *reinterpret_cast<const bf16x8*>(bl[j] + k);
+                for (int j = 0; j < NT; ++j) {
+                    fb[kk][j] = *reinterpret_cast<const bf16x8*>(bh[j] + k);
+                    if (NSPLIT == 3) lb[kk][j] = *reinterpret_cast<const bf16x8*>(bl[j] + k);
+                }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -143,6 +188,16 @@ __device__ __forceinline__ void gemm_rows_body(RowsParams p) {
         // (requested behind the first tile's operands, in front of its MFMAs: vector-memory operations retire in order, so a slow
         //  residual line in FRONT of the operands would hold the first MFMA's counted wait -- 0.4 us on gemm.hip's 16-wide tile)
         if (t == wave) epilogue_loads();
+        if (!BK) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's images have landed
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    fb[kk][j] = rows_tr_frag(bimg + (2 * j) * RT_IMG, kk, lane);
+                    if (NSPLIT == 3) lb[kk][j] = rows_tr_frag(bimg + (2 * j + 1) * RT_IMG, kk, lane);
+                }
+        }
 #if SLNLP_PROBE_FENCES == 256
         if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RTS_MARK(1); }
 #endif
@@ -214,13 +269,124 @@ __device__ __forceinline__ void gemm_rows_body(RowsParams p) {
     }
 }
 
+// One weight-gradient unit: dW[16 WM m x 128 n] = dY^T x over the batch rows -- A = dY planes [k = row][m], B = x planes [k = row][n],
+// both m-major; WAVE w computes the WM 16 x 16 tiles of columns n0 + 16 w.  The WM dY images are staged ONCE per workgroup (the waves
+// share the DMA instructions; one barrier), each wave stages its own x image.  K = the batch rows (one 64-k tile at the headline
+// batch of 50; more tiles: partials added in tile order, as everywhere in this file).  rowsum_a (the bias gradient: sum over the rows
+// of dY[., m]) is written by the first column unit's wave 0, k ascending, hi + lo per row.  WM = 1 for a solo fit's launch (128 units of
+// 36 KB for a 512 x 512 gradient), 4 for merged lockstep launches (a quarter of the x-image reads).
+template <int NSPLIT, int WM>
+__device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int unit, unsigned short* smem) {
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = g.M, N = g.N, ktiles = (g.K + 63) >> 6;
+    const int units_n = (N + 127) / 128, um = unit / units_n, un = unit - um * units_n;
+    const int m0 = um * 16 * WM, n0 = un * 128 + wave * 16, m_last = ((M + 15) / 16 - 1) * 16;
+    const bool active = n0 < N;                          // (a wave past the last column tile only keeps the barriers company)
+    unsigned short* aimg = smem;                          // [WM][hi, lo][64 k][16 m]: the workgroup's
+    unsigned short* bimg = smem + WM * 2 * RT_IMG + wave * 2 * RT_IMG;   // [hi, lo][64 k][16 n]: this wave's
+    f32x4 total[WM];
+    float rsum[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) { total[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rsum[i] = 0.f; }
+    const bool do_rs = g.rowsum_a != nullptr && un == 0 && wave == 0;
+    for (int t = 0; t < ktiles; ++t) {
+        if (t) {                                          // every wave is done with the previous tile's images
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        for (int im = wave; im < WM * NP; im += RT_WAVES) {
+            const int i = im / NP, pl = im - i * NP;
+            rows_dma_image(pl ? g.A_lo : g.A_hi, g.lda_p, t * 64, min(m0 + 16 * i, m_last), aimg + (2 * i + pl) * RT_IMG, lane);
+        }
+        if (active) {
+            rows_dma_image(g.B_hi, g.ldb_p, t * 64, n0, bimg, lane);
+            if (NSPLIT == 3) rows_dma_image(g.B_lo, g.ldb_p, t * 64, n0, bimg + RT_IMG, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active) {
+            bf16x8 fb[2], lb[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                fb[kk] = rows_tr_frag(bimg, kk, lane);
+                if (NSPLIT == 3) lb[kk] = rows_tr_frag(bimg + RT_IMG, kk, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 fa = rows_tr_frag(aimg + (2 * i) * RT_IMG, kk, lane);
+                    if (NSPLIT == 3) {
+                        const bf16x8 la = rows_tr_frag(aimg + (2 * i + 1) * RT_IMG, kk, lane);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(la, fb[kk], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, lb[kk], acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[kk], acc, 0, 0, 0);
+                }
+                total[i] = t == 0 ? acc : total[i] + acc;
+            }
+        }
+        if (do_rs && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                for (int k = 0; k < 64; ++k) {
+                    float v = __uint_as_float((unsigned)aimg[(2 * i) * RT_IMG + k * 16 + lane] << 16);
+                    if (NSPLIT == 3) v += __uint_as_float((unsigned)aimg[(2 * i + 1) * RT_IMG + k * 16 + lane] << 16);
+                    rsum[i] += v;
+                }
+        }
+    }
+    if (!active) return;
+    const int gn = n0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int gm0 = m0 + 16 * i + ((lane >> 4) << 2);
+        if (gn < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gm0 + r < M) g.C[(long)(gm0 + r) * g.ldc + gn] = total[i][r];
+        }
+        if (do_rs && lane < 16 && m0 + 16 * i + lane < M) g.rowsum_a[m0 + 16 * i + lane] = rsum[i];
+    }
+}
+
+template <int NSPLIT, int MT, int NT>
+__device__ __forceinline__ void gemm_rows_body(RowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float part[];      // [ktiles][MT x NT tiles][64 lanes][4]
+    rows_tile<NSPLIT, MT, NT, true>(p, blockIdx.x, blockIdx.y, part);
+}
+
+// The backward pair of one dY in ONE launch: blocks [0, nd) are the data gradient's tiles (dX = dY W, W m-major), the rest the weight
+// gradient's units (dW = dY^T x, db = column sums of dY).  Both read the same dY planes.
+struct RowsBwdParams {
+    RowsParams d;
+    slnlp_gemm_args w;
+};
+__device__ __forceinline__ RowsBwdParams as_global(RowsBwdParams p) {
+    launder(p.d.a);
+    launder(p.w);
+    return p;
+}
+template <int NSPLIT, int MT, int NT>
+__device__ __forceinline__ void gemm_rows_bwd_body(RowsBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float part[];
+    const int gx = (p.d.a.N + 16 * NT - 1) / (16 * NT), gy = (p.d.a.M + 16 * MT - 1) / (16 * MT), nd = gx * gy;
+    const int id = blockIdx.x;
+    if (id < nd) rows_tile<NSPLIT, MT, NT, false>(p.d, id % gx, id / gx, part);
+    else rows_wgrad_unit<NSPLIT, MT>(p.w, id - nd, reinterpret_cast<unsigned short*>(part));      // (16 MT gradient rows per unit)
+}
+
 // geometries: MFMA tiles per workgroup
 struct RowsGeo { int mt, nt; };
 constexpr int RT_NGEO = 3;
 constexpr RowsGeo RT_GEO[RT_NGEO] = {{1, 1}, {4, 1}, {4, 2}};
 #define SLNLP_ROWS_KERNEL(NS, G)                                                                                          \
     __device__ __forceinline__ void gemm_rows_body_##NS##_##G(RowsParams p) { gemm_rows_body<NS, RT_GEO[G].mt, RT_GEO[G].nt>(p); } \
-    SLNLP_ZKERNEL(gemm_rows_kernel_##NS##_##G, RT_THREADS, gemm_rows_body_##NS##_##G)
+    SLNLP_ZKERNEL(gemm_rows_kernel_##NS##_##G, RT_THREADS, gemm_rows_body_##NS##_##G)                                     \
+    __device__ __forceinline__ void gemm_rows_bwd_body_##NS##_##G(RowsBwdParams p) { gemm_rows_bwd_body<NS, RT_GEO[G].mt, RT_GEO[G].nt>(p); } \
+    SLNLP_ZKERNEL(gemm_rows_bwd_kernel_##NS##_##G, RT_THREADS, gemm_rows_bwd_body_##NS##_##G)
 SLNLP_ROWS_KERNEL(3, 0)
 SLNLP_ROWS_KERNEL(3, 1)
 SLNLP_ROWS_KERNEL(3, 2)
@@ -229,24 +395,39 @@ SLNLP_ROWS_KERNEL(1, 1)
 SLNLP_ROWS_KERNEL(1, 2)
 
 using RowsKernel = void (*)(Pack<RowsParams>, const Pack<RowsParams>*);
+using RowsBwdKernel = void (*)(Pack<RowsBwdParams>, const Pack<RowsBwdParams>*);
 static RowsKernel rows_kernel(int precision, int geo) {
     if (precision == 3) return geo == 0 ? gemm_rows_kernel_3_0 : geo == 1 ? gemm_rows_kernel_3_1 : gemm_rows_kernel_3_2;
     return geo == 0 ? gemm_rows_kernel_1_0 : geo == 1 ? gemm_rows_kernel_1_1 : gemm_rows_kernel_1_2;
 }
+static RowsBwdKernel rows_bwd_kernel(int precision, int geo) {
+    if (precision == 3) return geo == 0 ? gemm_rows_bwd_kernel_3_0 : geo == 1 ? gemm_rows_bwd_kernel_3_1 : gemm_rows_bwd_kernel_3_2;
+    return geo == 0 ? gemm_rows_bwd_kernel_1_0 : geo == 1 ? gemm_rows_bwd_kernel_1_1 : gemm_rows_bwd_kernel_1_2;
+}
 static size_t rows_lds(int geo, int K) { return (size_t)ceil_div(K, 64) * RT_GEO[geo].mt * RT_GEO[geo].nt * 64 * 4 * sizeof(float); }
+// backward launches: the data gradient's partial tiles + its waves' W images, or the weight gradient's four images per wave
+static size_t rows_bwd_lds(int geo, int K) {
+    const size_t d = rows_lds(geo, K) + (size_t)RT_WAVES * RT_GEO[geo].nt * 2 * RT_IMG * sizeof(unsigned short);
+    const size_t w = (size_t)(RT_GEO[geo].mt + RT_WAVES) * 2 * RT_IMG * sizeof(unsigned short);      // the workgroup's dY images + the waves' x images
+    return d > w ? d : w;
+}
 static dim3 rows_grid(int geo, int M, int N) { return dim3(ceil_div(N, 16 * RT_GEO[geo].nt), ceil_div(M, 16 * RT_GEO[geo].mt)); }
+static int rows_wgrad_units(const slnlp_gemm_args& w, int geo) { return ceil_div(w.M, 16 * RT_GEO[geo].mt) * ceil_div(w.N, 128); }
 
 // -1 = automatic; 0 .. RT_NGEO-1 forced (slnlp_set_rows_tile: tests, tuning)
 static std::atomic<int> g_rows_geo{[] { const char* e = getenv("SLNLP_ROWS_TILE"); const int v = e ? atoi(e) : -1; return v >= 0 && v < RT_NGEO ? v : -1; }()};
 // Which tile a launch of `fits` products [M x N x K] takes: rounds of workgroups over the 256 compute units x the panel bytes one
 // workgroup loads (a compute unit's load rate is the limit, see gemm_rows_body) -- the small tile while the launch fits the chip
 // about once (one fit: 128 workgroups of 64 KB), the wide ones when K fits in lockstep fill it many times over.
-static int rows_geo(int M, int N, int K, int fits) {
+constexpr size_t RT_LDS_MAX = 160 * 1024;    // per workgroup (MI355X: 160 KiB per compute unit)
+static int rows_geo(int M, int N, int K, int fits, bool bwd) {
     const int forced = g_rows_geo.load(std::memory_order_relaxed);
-    if (forced >= 0) return forced;
+    auto fits_lds = [&](int geo) { return (bwd ? rows_bwd_lds(geo, K) : rows_lds(geo, K)) <= RT_LDS_MAX; };
+    if (forced >= 0 && fits_lds(forced)) return forced;
     int best = 0;
     long best_cost = -1;
     for (int geo = 0; geo < RT_NGEO; ++geo) {
+        if (!fits_lds(geo)) continue;
         const dim3 gr = rows_grid(geo, M, N);
         const long units = (long)gr.x * gr.y * fits, rounds = (units + 255) / 256;
         const long cost = rounds * (16L * (RT_GEO[geo].mt + RT_GEO[geo].nt) * K * 4 + 16384);     // (+ a fixed cost per round)
@@ -262,7 +443,9 @@ static int rows_init() {
         for (int prec = 1; prec <= 3; prec += 2)
             for (int geo = 0; geo < RT_NGEO; ++geo)
                 ok = ok && hipFuncSetAttribute((const void*)rows_kernel(prec, geo), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)rows_lds(geo, 64 * RT_MAX_KTILES)) == hipSuccess;
+                                               (int)std::min(rows_lds(geo, 64 * RT_MAX_KTILES), RT_LDS_MAX)) == hipSuccess &&
+                     hipFuncSetAttribute((const void*)rows_bwd_kernel(prec, geo), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)std::min(rows_bwd_lds(geo, 64 * RT_MAX_KTILES), RT_LDS_MAX)) == hipSuccess;
         if (!ok) {
             set_error("gemm_rows: cannot raise dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
             return SLNLP_ERR_LAUNCH;
@@ -275,44 +458,81 @@ static int rows_init() {
 // kernel to launch and its grid / LDS, or nullptr when `fn` is not a gemm_rows kernel.  Results do not depend on the tile.
 const void* gemm_rows_for_fits(const void* fn, const void* recorded_args, int fits, dim3* grid, size_t* lds) {
     int prec = 0;
+    bool bwd = false;
     for (int geo = 0; geo < RT_NGEO; ++geo) {
         if (fn == (const void*)rows_kernel(3, geo)) prec = 3;
         if (fn == (const void*)rows_kernel(1, geo)) prec = 1;
+        if (fn == (const void*)rows_bwd_kernel(3, geo)) { prec = 3; bwd = true; }
+        if (fn == (const void*)rows_bwd_kernel(1, geo)) { prec = 1; bwd = true; }
     }
     if (!prec) return nullptr;
+    if (bwd) {
+        const RowsBwdParams& P = *reinterpret_cast<const RowsBwdParams*>(recorded_args);
+        const int geo = rows_geo(P.d.a.M, P.d.a.N, P.d.a.K, fits, true);
+        const dim3 gr = rows_grid(geo, P.d.a.M, P.d.a.N);
+        *grid = dim3(gr.x * gr.y + rows_wgrad_units(P.w, geo));
+        *lds = rows_bwd_lds(geo, P.d.a.K);
+        return (const void*)rows_bwd_kernel(prec, geo);
+    }
     const slnlp_gemm_args& a = reinterpret_cast<const RowsParams*>(recorded_args)->a;
-    const int geo = rows_geo(a.M, a.N, a.K, fits);
+    const int geo = rows_geo(a.M, a.N, a.K, fits, false);
     *grid = rows_grid(geo, a.M, a.N);
     *lds = rows_lds(geo, a.K);
     return (const void*)rows_kernel(prec, geo);
 }
 
+static int check_rows_job(const slnlp_gemm_args& a, bool b_kmajor, const char* who) {
+    SLNLP_CHECK_ARG(a.A_hi && a.B_hi, "%s: operand planes required", who);
+    SLNLP_CHECK_ARG(a.a_kmajor && (a.b_kmajor != 0) == b_kmajor, "%s: operand layouts (A k-major; B k-major for a forward product, m-major for a data gradient)", who);
+    SLNLP_CHECK_ARG(a.C || a.C_hi, "%s: no output", who);
+    SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "%s: bad shape M=%d N=%d K=%d", who, a.M, a.N, a.K);
+    SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo && a.B_lo), "%s: precision 1, or 3 with both lo planes", who);
+    SLNLP_CHECK_ARG(a.lda_p % 64 == 0 && a.ldb_p % 64 == 0 && a.lda_p >= a.K && a.ldb_p >= (b_kmajor ? a.K : a.N),
+                    "%s: plane row strides must be multiples of 64 and cover the row (zero-padded)", who);
+    SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.B_hi | (uintptr_t)a.A_lo | (uintptr_t)a.B_lo) & 15) == 0, "%s: planes must be 16-byte aligned", who);
+    SLNLP_CHECK_ARG(!a.C || a.ldc >= a.N, "%s: ldc < N", who);
+    SLNLP_CHECK_ARG(!a.C_hi || a.ldc_p >= a.N, "%s: ldc_p < N", who);
+    SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "%s: bad dropout args", who);
+    SLNLP_CHECK_ARG(!a.gate || a.ldg >= a.N, "%s: ldg too small", who);
+    SLNLP_CHECK_ARG(!a.resid || a.ldr >= a.N, "%s: ldr too small", who);
+    SLNLP_CHECK_ARG(!a.rowsum_a && a.batch <= 1, "%s: no row sums, no batched jobs", who);
+    SLNLP_CHECK_ARG(a.drop_head_dim >= 0 && (a.drop_head_dim == 0 || a.N % a.drop_head_dim == 0), "%s: drop_head_dim %d does not divide N %d", who,
+                    a.drop_head_dim, a.N);
+    SLNLP_CHECK_ARG(ceil_div(a.K, 64) <= RT_MAX_KTILES, "%s: K = %d > %d (the workgroup's partial tiles live in LDS)", who, a.K, 64 * RT_MAX_KTILES);
+    return 0;
+}
+
+// dX = dY W (+ epilogue) and dW = dY^T x, db = colsum(dY) in one launch (gemm_rows_bwd_body).  dgrad: A = dY planes k-major, B = W planes
+// m-major; wgrad: A = dY planes, B = x planes, both m-major, K = the batch rows (planes zero beyond them), C = dW fp32, rowsum_a = db or null.
+int gemm_rows_bwd(const slnlp_gemm_args& dgrad, const slnlp_gemm_args& wgrad, hipStream_t st) {
+    SLNLP_TRY(check_rows_job(dgrad, false, "gemm_rows_bwd (dgrad)"));
+    const slnlp_gemm_args& w = wgrad;
+    SLNLP_CHECK_ARG(w.A_hi && w.B_hi && w.C && !w.a_kmajor && !w.b_kmajor, "gemm_rows_bwd (wgrad): m-major operand planes and an fp32 output required");
+    SLNLP_CHECK_ARG(w.precision == dgrad.precision && (w.precision == 1 || (w.A_lo && w.B_lo)), "gemm_rows_bwd (wgrad): same precision as the dgrad, lo planes for 3");
+    SLNLP_CHECK_ARG(w.M > 0 && w.N > 0 && w.K > 0 && w.lda_p % 64 == 0 && w.ldb_p % 64 == 0 && w.lda_p >= w.M && w.ldb_p >= w.N && w.ldc >= w.N,
+                    "gemm_rows_bwd (wgrad): bad shape / strides");
+    SLNLP_CHECK_ARG((((uintptr_t)w.A_hi | (uintptr_t)w.B_hi | (uintptr_t)w.A_lo | (uintptr_t)w.B_lo) & 15) == 0, "gemm_rows_bwd (wgrad): planes must be 16-byte aligned");
+    SLNLP_CHECK_ARG(!w.bias && !w.gate && !w.resid && w.drop_p == 0.f && !w.C_hi && w.relu == 0 && w.batch <= 1, "gemm_rows_bwd (wgrad): no epilogue");
+    RowsBwdParams p;
+    p.d.a = dgrad;
+    p.d.drop_thr = dropout_threshold(dgrad.drop_p);
+    p.d.drop_scale = 1.f / (1.f - dgrad.drop_p);
+    p.w = wgrad;
+    SLNLP_TRY(rows_init());
+    const int geo = rows_geo(dgrad.M, dgrad.N, dgrad.K, 1, true);
+    const dim3 gr = rows_grid(geo, dgrad.M, dgrad.N);
+    return zlaunch(rows_bwd_kernel(dgrad.precision, geo), dim3(gr.x * gr.y + rows_wgrad_units(wgrad, geo)), RT_THREADS, rows_bwd_lds(geo, dgrad.K), st,
+                   "gemm_rows_bwd", p);
+}
+
 int gemm_rows(const slnlp_gemm_args& a, hipStream_t st) {
-    SLNLP_CHECK_ARG(a.A_hi && a.B_hi, "gemm_rows: operand planes required");
-    SLNLP_CHECK_ARG(a.a_kmajor && a.b_kmajor, "gemm_rows: both operands k-major (the forward products y = x W^T)");
-    SLNLP_CHECK_ARG(a.C || a.C_hi, "gemm_rows: no output");
-    SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_rows: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
-    SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo && a.B_lo), "gemm_rows: precision 1, or 3 with both lo planes");
-    SLNLP_CHECK_ARG(a.lda_p % 64 == 0 && a.ldb_p % 64 == 0 && a.lda_p >= a.K && a.ldb_p >= a.K,
-                    "gemm_rows: plane row strides must be multiples of 64 and cover K (zero-padded)");
-    SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.B_hi | (uintptr_t)a.A_lo | (uintptr_t)a.B_lo) & 15) == 0,
-                    "gemm_rows: planes must be 16-byte aligned");
-    SLNLP_CHECK_ARG(!a.C || a.ldc >= a.N, "gemm_rows: ldc < N");
-    SLNLP_CHECK_ARG(!a.C_hi || a.ldc_p >= a.N, "gemm_rows: ldc_p < N");
-    SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "gemm_rows: bad dropout args");
-    SLNLP_CHECK_ARG(!a.gate || a.ldg >= a.N, "gemm_rows: ldg too small");
-    SLNLP_CHECK_ARG(!a.resid || a.ldr >= a.N, "gemm_rows: ldr too small");
-    SLNLP_CHECK_ARG(!a.rowsum_a && a.batch <= 1, "gemm_rows: no row sums, no batched jobs");
-    SLNLP_CHECK_ARG(a.drop_head_dim >= 0 && (a.drop_head_dim == 0 || a.N % a.drop_head_dim == 0),
-                    "gemm_rows: drop_head_dim %d does not divide N %d", a.drop_head_dim, a.N);
+    SLNLP_TRY(check_rows_job(a, true, "gemm_rows"));
     RowsParams p;
     p.a = a;
     p.drop_thr = dropout_threshold(a.drop_p);
     p.drop_scale = 1.f / (1.f - a.drop_p);
-    const int ktiles = ceil_div(a.K, 64);
-    SLNLP_CHECK_ARG(ktiles <= RT_MAX_KTILES, "gemm_rows: K = %d > %d (the workgroup's partial tiles live in LDS)", a.K, 64 * RT_MAX_KTILES);
     SLNLP_TRY(rows_init());
-    const int geo = rows_geo(a.M, a.N, a.K, 1);
+    const int geo = rows_geo(a.M, a.N, a.K, 1, false);
     return zlaunch(rows_kernel(a.precision, geo), rows_grid(geo, a.M, a.N), RT_THREADS, rows_lds(geo, a.K), st, "gemm_rows", p);
 }
 
@@ -332,6 +552,14 @@ extern "C" int slnlp_probe_rows_ts(unsigned long long* dst, int max_entries) {
     return (int)n;
 }
 #endif
+
+extern "C" int slnlp_gemm_rows_bwd(const slnlp_gemm_args* dgrad, const slnlp_gemm_args* wgrad, void* stream) {
+    if (!dgrad || !wgrad) {
+        slnlp::set_error("gemm_rows_bwd: null args");
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    return slnlp::gemm_rows_bwd(*dgrad, *wgrad, (hipStream_t)stream);
+}
 
 extern "C" int slnlp_set_rows_tile(int tile) {
     if (tile < -1 || tile >= slnlp::RT_NGEO) {

@@ -312,6 +312,40 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
         const float* t_in = l > 0 ? w.dec[l - 1].t3 : w.t0;
+        if (pl->use_rows) {
+            // the same chain on plane operands: LayerNorm backward emits the sub-layer's dY as planes (the dropout-masked copy when
+            // dropout is on), every Linear's backward pair is ONE gemm_rows_bwd launch, whose data gradient emits the next dY
+            const PlaneOut none{};
+            const PP& t_inp = l > 0 ? w.dec[l - 1].t3p : w.t0p;
+            SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, a.gA3, nullptr, p, pl->dec_site(l, 5), rng, nullptr, nullptr, 0, st,
+                                    p == 0.f ? a.d3p.out() : none, p > 0.f ? a.d3p.out() : none));
+            SLNLP_TRY(pl->wd_rows(a.d3p, B, E, q.l2_w, F, nullptr, &a.ghp, a.h, ik, nullptr, a.hp, q.l2_w, q.l2_b, st));
+            SLNLP_TRY(pl->wd_rows(a.ghp, B, F, q.l1_w, E, a.gt2, nullptr, nullptr, 0.f, a.gA3, a.t2p, q.l1_w, q.l1_b, st));
+            SLNLP_TRY(layernorm_bwd(a.gt2, a.y2, pl->P(q.n2_w), a.st2, B, E, nullptr, a.gA2, nullptr, p, pl->dec_site(l, 3), rng, nullptr, nullptr, 0, st,
+                                    p == 0.f ? a.d2p.out() : none, p > 0.f ? a.d2p.out() : none));
+            SLNLP_TRY(pl->wd_rows(a.d2p, B, E, q.cout_w, E, a.gxctx, nullptr, nullptr, 0.f, nullptr, a.xctxp, q.cout_w, q.cout_b, st));
+            {
+                const float *Wk = pl->P(q.cin_w) + (long)E * E, *Wv = pl->P(q.cin_w) + 2L * E * E;
+                const slnlp_gemm_args j1 = pl->head_expand(a.gxctx, Wv, a.dmbar, B, H, dh);
+                SLNLP_TRY(gemm_group(&j1, 1, st));
+                SLNLP_TRY(xmem_bwd(w.mem, pl->P(q.cin_b) + 2 * E, a.xprobs, a.psum, a.qk, a.dmbar, a.gxctx, B, S, H, dh, a.dsc, a.dqk, a.dcp,
+                                   pl->G(q.cin_b) + 2 * E, w.gmem, l == c.N - 1 ? 0 : 1, p, pl->dec_site(l, 2), rng, st));
+                slnlp_gemm_args jobs[3] = {pl->head_reduce(a.dqk, Wk, a.gq, nullptr, B, H, dh),
+                                           pl->head_wgrad(a.q, a.dqk, pl->G(q.cin_w) + (long)E * E, B, H, dh),
+                                           pl->head_wgrad(a.gxctx, a.mbar, pl->G(q.cin_w) + 2L * E * E, B, H, dh)};
+                jobs[0].C_hi = a.gqp.hi; jobs[0].C_lo = a.gqp.lo; jobs[0].ldc_p = E;
+                SLNLP_TRY(gemm_group(jobs, 3, st));
+            }
+            SLNLP_TRY(pl->wd_rows(a.gqp, B, E, q.cin_w, E, a.gt1, nullptr, nullptr, 0.f, a.gA2, a.t1p, q.cin_w, q.cin_b, st));
+            SLNLP_TRY(layernorm_bwd(a.gt1, a.y1, pl->P(q.n1_w), a.st1, B, E, nullptr, a.gA1, nullptr, p, pl->dec_site(l, 1), rng, nullptr, nullptr, 0, st,
+                                    p == 0.f ? a.d1p.out() : none, p > 0.f ? a.d1p.out() : none));
+            // (the single-key self-attention's per-(row, head) dropout: the same mask as the forward V projection)
+            SLNLP_TRY(pl->wd_rows(a.d1p, B, E, q.sout_w, E, nullptr, &a.gvp, nullptr, 0.f, nullptr, a.vp, q.sout_w, q.sout_b, st, p, pl->dec_site(l, 0), p > 0.f ? dh : 0));
+            // softmax over one element has zero gradient: the q/k rows of in_proj (weight and bias) get exactly 0 -- nothing writes them
+            SLNLP_TRY(pl->wd_rows(a.gvp, B, E, q.sin_w + 2L * E * E, E, a.gt0, nullptr, nullptr, 0.f, a.gA1, t_inp, q.sin_w + 2L * E * E, q.sin_b + 2 * E, st));
+            dt = a.gt0;
+            continue;
+        }
         // norm3 / FFN
         SLNLP_TRY(layernorm_bwd(dt, a.y3, pl->P(q.n3_w), a.st3, B, E, nullptr, a.gA3, p > 0.f ? a.gB3 : nullptr, p,
                                 pl->dec_site(l, 5), rng, nullptr, nullptr, 0, st));

@@ -156,6 +156,7 @@ struct DecA {
     float *gA3, *gB3, *gh, *gt2, *gA2, *gB2, *gxctx, *gq, *gt1, *gA1, *gB1, *gv, *gt0;
     float *dmbar, *dsc, *dqk, *dcp;          // its gradients: d mbar, d scores, d qk [B*H, .], d ctx * sum_s p_s [B, E]
     PP vp, t1p, xctxp, t2p, hp, t3p;         // operands of the layer's B-row products as planes (gemm_rows.hip); rows padded to 64
+    PP d3p, ghp, d2p, gqp, d1p, gvp;         // ... and the gradients its backward pairs contract (dY of linear2, linear1, cross out / q, self out / v)
 };
 struct Ws {
     float *x0, *t0, *mem, *st_mem, *lnp_mem, *tfin, *st_fin, *lnp_fin, *logits, *dlogits, *logp, *row_nll;
@@ -320,6 +321,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         for (int i = 0; i < c.N; ++i) {
             DecA& a = w.dec[i];
             a.vp = ppd(E); a.t1p = ppd(E); a.xctxp = ppd(E); a.t2p = ppd(E); a.hp = ppd(F); a.t3p = ppd(E);
+            a.d3p = ppd(E); a.ghp = ppd(F); a.d2p = ppd(E); a.gqp = ppd(E); a.d1p = ppd(E); a.gvp = ppd(E);
         }
     }
     {   // grouped-launch scratch lives in the zero-on-demand region: its arrival counters must start at zero
@@ -531,6 +533,28 @@ struct slnlp_tf_plan {
         a.precision = prec3();
         a.drop_head_dim = drop_head_dim;
         return gemm_rows(a, st);
+    }
+    // the backward pair of a decoder Linear y[B, Nout] = x[B, Kin] W^T + b in ONE launch (gemm_rows.hip: gemm_rows_bwd): dX = dY W with
+    // its epilogue (gate, per-head dropout, residual; fp32 and / or planes out) and dW = dY^T x, db = colsum(dY)
+    int wd_rows(const PP& dy, int B, int Nout, long woff, int Kin, float* dx, const PP* dxp, const float* gate, float gate_scale,
+                const float* resid, const PP& x, long gw, long gb, hipStream_t st, float drop_p = 0.f, int drop_site = 0, int drop_head_dim = 0) const {
+        slnlp_gemm_args d, g;
+        memset(&d, 0, sizeof(d));
+        memset(&g, 0, sizeof(g));
+        d.A_hi = dy.hi; d.A_lo = dy.lo; d.lda_p = Nout; d.a_kmajor = 1;
+        d.B_hi = w.wp.hi + woff; d.B_lo = w.wp.lo + woff; d.ldb_p = Kin; d.b_kmajor = 0;
+        d.C = dx; d.ldc = Kin; d.M = B; d.N = Kin; d.K = Nout;
+        d.gate = gate; d.ldg = Kin; d.gate_scale = gate_scale;
+        d.resid = resid; d.ldr = Kin;
+        if (dxp) { d.C_hi = dxp->hi; d.C_lo = dxp->lo; d.ldc_p = Kin; }
+        d.drop_p = drop_p; d.drop_site = drop_site; d.rng = buf.rng; d.drop_head_dim = drop_head_dim;
+        d.precision = prec3();
+        g.A_hi = dy.hi; g.A_lo = dy.lo; g.lda_p = Nout; g.a_kmajor = 0;
+        g.B_hi = x.hi; g.B_lo = x.lo; g.ldb_p = Kin; g.b_kmajor = 0;
+        g.C = G(gw); g.ldc = Kin; g.M = Nout; g.N = Kin; g.K = B;
+        g.rowsum_a = G(gb);
+        g.precision = prec3();
+        return gemm_rows_bwd(d, g, st);
     }
     slnlp_gemm_args dgrad_p_args(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
                                  float gate_scale, const float* resid, const PP* outp) const {

@@ -91,6 +91,7 @@ SIGNATURES = {
     "slnlp_gemm_group_scratch_bytes": (i64, [C.POINTER(GemmArgs), C.POINTER(i32), i32]),
     "slnlp_gemm_group": (i32, [C.POINTER(GemmArgs), C.POINTER(i32), i32, vp, i64, vp]),
     "slnlp_gemm_rows": (i32, [C.POINTER(GemmArgs), vp]),
+    "slnlp_gemm_rows_bwd": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
     "slnlp_set_rows_tile": (i32, [i32]),
     "slnlp_quant_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
     "slnlp_split_planes": (i32, [vp, i64, i32, i32, vp, vp, i64, vp]),

@@ -157,6 +157,36 @@ def gemm_rows(Ap, Bp, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate
     return (out, cp) if want_planes else out
 
 
+def gemm_rows_bwd(dYp, Wp, Xp, *, B, Nout, Kin, precision=3, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0, drop_site=0, rng=None,
+                  drop_head_dim=0, resid=None, want_planes=False, want_db=True):
+    """dX = dY W (+ epilogue), dW = dY^T x, db = colsum(dY) in one launch (slnlp_gemm_rows_bwd): dYp [B, Nout], Wp [Nout, Kin],
+    Xp [B, Kin] as (hi, lo) planes."""
+    _lib.require_gpu()
+    dev = dYp[0].device
+    dX = torch.empty(B, Kin, dtype=torch.float32, device=dev)
+    dW = torch.empty(Nout, Kin, dtype=torch.float32, device=dev)
+    db = torch.empty(Nout, dtype=torch.float32, device=dev) if want_db else None
+    d, w = GemmArgs(), GemmArgs()
+    d.C, d.ldc, d.M, d.N, d.K = ptr(dX), dX.stride(0), B, Kin, Nout
+    d.a_kmajor, d.b_kmajor, d.precision = 1, 0, precision
+    d.A_hi, d.A_lo, d.lda_p = ptr(dYp[0]), ptr(dYp[1]), dYp[0].stride(0)
+    d.B_hi, d.B_lo, d.ldb_p = ptr(Wp[0]), ptr(Wp[1]), Wp[0].stride(0)
+    d.gate, d.ldg, d.gate_scale, d.gate_mode = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale, gate_mode
+    d.drop_p, d.drop_site, d.rng, d.drop_head_dim = drop_p, drop_site, ptr(rng), drop_head_dim
+    d.resid, d.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)
+    cp = None
+    if want_planes:
+        cp = (torch.zeros(pad64(B), pad64(Kin), dtype=torch.int16, device=dev), torch.zeros(pad64(B), pad64(Kin), dtype=torch.int16, device=dev))
+        d.C_hi, d.C_lo, d.ldc_p = ptr(cp[0]), ptr(cp[1]), cp[0].stride(0)
+    w.C, w.ldc, w.M, w.N, w.K = ptr(dW), dW.stride(0), Nout, Kin, B
+    w.a_kmajor, w.b_kmajor, w.precision = 0, 0, precision
+    w.A_hi, w.A_lo, w.lda_p = ptr(dYp[0]), ptr(dYp[1]), dYp[0].stride(0)
+    w.B_hi, w.B_lo, w.ldb_p = ptr(Xp[0]), ptr(Xp[1]), Xp[0].stride(0)
+    w.rowsum_a = ptr(db)
+    check(load().slnlp_gemm_rows_bwd(C.byref(d), C.byref(w), stream_ptr()), "gemm_rows_bwd")
+    return (dX, dW, db, cp) if want_planes else (dX, dW, db)
+
+
 def embed_fwd(ids, table, pe, *, B, S, scale=None, drop_p=0.0, drop_site=0, rng=None, nan_idx=-1):
     _lib.require_gpu()
     V, E = table.shape

@@ -469,6 +469,50 @@ def test_gemm_rows_tiles_return_the_same_bits(ops):
             assert torch.equal(a, b), f"output {i} differs between workgroup tiles"
 
 
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("B,Nout,Kin", [(50, 512, 512), (50, 512, 256), (7, 64, 64), (130, 192, 96), (64, 1024, 512), (50, 128, 200)])
+def test_gemm_rows_bwd_vs_fp64(ops, B, Nout, Kin, prec):
+    """dX = dY W, dW = dY^T x, db = column sums of dY in ONE launch (slnlp_gemm_rows_bwd): W and both wgrad operands m-major through
+    the waves' LDS images, at every workgroup tile (same bits), batches over 64 rows (several K tiles in the weight gradient)."""
+    from slnlp._lib import load, check
+    dY, W, X = rnd(B, Nout, seed=1), rnd(Nout, Kin, seed=2), rnd(B, Kin, seed=3)
+    pad = lambda x: torch.nn.functional.pad(x, (0, (-x.shape[1]) % 4))
+    dYp, Wp, Xp = ops.split_planes(pad(dY).cuda()), ops.split_planes(pad(W).cuda()), ops.split_planes(pad(X).cuda())
+    res = []
+    try:
+        for tile in (0, 1, 2):
+            check(load().slnlp_set_rows_tile(tile), "set_rows_tile")
+            res.append([t.clone() for t in ops.gemm_rows_bwd(dYp, Wp, Xp, B=B, Nout=Nout, Kin=Kin, precision=prec)])
+    finally:
+        load().slnlp_set_rows_tile(-1)
+    dX, dW, db = res[0]
+    tol = TOL[prec] * max(1.0, math.sqrt(max(Nout, B) / 64))
+    assert rel(dX, dY.double() @ W.double()) < tol
+    assert rel(dW, dY.double().T @ X.double()) < tol
+    assert rel(db, dY.double().sum(0)) < (1e-4 if prec == 3 else 2e-2)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
+def test_gemm_rows_bwd_epilogue(ops):
+    """The data gradient's epilogue: ReLU-with-scale gate (the FFN's backward), residual, per-(row, head) dropout, planes out."""
+    B, Nout, Kin, dh = 50, 512, 512, 64
+    dY, W, X, G, R = rnd(B, Nout, seed=1), rnd(Nout, Kin, seed=2), rnd(B, Kin, seed=3), rnd(B, Kin, seed=4), rnd(B, Kin, seed=5)
+    dYp, Wp, Xp = ops.split_planes(dY.cuda()), ops.split_planes(W.cuda()), ops.split_planes(X.cuda())
+    base = dY.double() @ W.double()
+    dX, dW, db, (hi, lo) = ops.gemm_rows_bwd(dYp, Wp, Xp, B=B, Nout=Nout, Kin=Kin, gate=G.cuda(), gate_scale=1.25, resid=R.cuda(), want_planes=True)
+    assert rel(dX, base * (G.double() > 0) * 1.25 + R.double()) < 1e-4
+    h2, l2 = ops.split_planes(dX)
+    assert torch.equal(hi[:B, :Kin], h2[:B, :Kin]) and torch.equal(lo[:B, :Kin], l2[:B, :Kin])
+    rng = ops.make_rng(seed=1234, step=7)
+    p = 0.3
+    mh = ops.dropout_mask(B * (Kin // dh), 1, p, 9, rng).cpu().double().view(B, Kin // dh).repeat_interleave(dh, dim=1)
+    dX, dW, db = ops.gemm_rows_bwd(dYp, Wp, Xp, B=B, Nout=Nout, Kin=Kin, drop_p=p, drop_site=9, rng=rng, drop_head_dim=dh, want_db=False)
+    assert rel(dX, base * mh / (1 - p)) < 1e-4 and db is None
+    assert rel(dW, dY.double().T @ X.double()) < 1e-4
+
+
 def test_gemm_rows_epilogue_dropout_and_output_planes(ops):
     """bias -> ReLU -> dropout -> residual with the masks slnlp_dropout_mask reports (per element and per (row, head)), the
     tanh / ReLU gates, an in-place residual, and the emitted planes equal to the split of the fp32 result."""
