@@ -129,32 +129,32 @@ def dominant_kernel_roofline(c, precision, dev, workload, in_step=None):
     jw, _ = ops.plane_job(dYp, Xp, M=E, N=F, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=wp)
     jd, _ = ops.plane_job(dYp, Wp, M=M, N=F, K=E, a_kmajor=True, b_kmajor=False, precision=dp)
     cd = lambda a, b: (a + b - 1) // b
-    tw, td, kw, kd = cd(E, 64) * cd(F, 64), cd(M, 64) * cd(F, 64), cd(M, 64), cd(E, 64)
-    split = min(range(1, min(8, kw) + 1), key=lambda n: cd(tw * n + td, 512) * max(cd(kw, n) + (n > 1), kd))   # tf_plan.hip wd_group
-    scr = ops.gemm_group([jw, jd], [split, 1])
+    # what the library does with this pair (csrc/gemm_planes.hip: gemm_planes_wd_plan, plane_geo_auto): the weight gradient's K-split,
+    # one grouped launch or two, and the tile geometry of the launch
+    split, separate, geo_w, geo_d = ops.gemm_wd_plan(jw, jd)
+    scr = ops.gemm_wd(jw, jd)
     for _ in range(20):
-        ops.gemm_group([jw, jd], [split, 1], scr)
+        ops.gemm_wd(jw, jd, scr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 200
     e0.record()
     for _ in range(n):
-        ops.gemm_group([jw, jd], [split, 1], scr)
+        ops.gemm_wd(jw, jd, scr)
     e1.record()
     e1.synchronize()
     us_b2b = e0.elapsed_time(e1) / n * 1e3
     flops = 2.0 * 2 * M * E * F                       # two GEMMs, 2 m n k each (the split-bf16 MFMA passes are not counted)
-    blocks = tw * split + td
-    # the launch geometry the library picks for this group (csrc/gemm_planes.hip plane_geo_auto): 64 x 64 tiles under 200 tiles of
-    # 128 x 128, else 128 x 128 on the 32-k ring (two workgroups per CU) from 300 tiles or K loops >= 1024, else on the 64-k ring
-    u128 = cd(E, 128) * cd(F, 128) * split + cd(M, 128) * cd(F, 128)
-    geo, wgs = ("64x64", blocks) if u128 < 200 else ("128x128 32-k ring" if (min(M // split, E) >= 1024 or u128 >= 300) else "128x128 64-k ring", u128)
+    GEO_DIMS = [(64, 64, "64x64"), (128, 128, "128x128 64-k ring"), (128, 128, "128x128 32-k ring"), (256, 256, "256x256 32-k ring")]
+    bm, bn, geo = GEO_DIMS[geo_d]
+    wgs = cd(E, bm) * cd(F, bn) * split + cd(M, bm) * cd(F, bn)           # workgroups of the (grouped) launch
+    blocks = wgs
     # this launch inside train steps: the timer's records with this workgroup count and two jobs
-    mine = [us for (b, nj, _, us) in (in_step or []) if b == wgs and nj == 2]
+    mine = [us for (b, nj, g_, us) in (in_step or []) if b == wgs and nj == 2 and g_ == geo_d] if not separate else []
     us_step = sum(mine) / len(mine) if mine else None
     us = us_step if us_step else us_b2b
     tf = flops / (us * 1e-6) / 1e12
     prof = rocprof_kernel_times(workload)
-    traffic, traffic_src = pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}, 0> x{blocks}")
+    traffic, traffic_src = pmc_kernel_traffic(workload, f"gemm_planes_kernel<{precision}, {geo_d}> x{blocks}")
     return {"kernel": f"gemm_planes_kernel<{precision}, {geo}> dgrad+wgrad group [{M}x{E}]x[{E}x{F}], wgrad split-K {split}, {wgs} workgroups, "
                       f"split-bf16 passes wgrad {wp} / dgrad {dp}",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -162,6 +162,10 @@ def dominant_kernel_roofline(c, precision, dev, workload, in_step=None):
             "population": (f"in-step: {len(mine)} launches inside {len(mine) // 18 if len(mine) >= 18 else '?'}+ eager train steps, HIP events around each launch on the launch stream (live)"
                            if us_step else "back-to-back launches (live; no in-step records)"),
             "us_per_launch": round(us, 2),
+            # the two populations under keys of their own (never a silent stand-in for each other): None = not measured in this run
+            "us_per_launch_in_step": round(us_step, 2) if us_step else None,
+            "achieved_in_step": round(flops / (us_step * 1e-6) / 1e12, 1) if us_step else None,
+            "achieved_is": "in_step" if us_step else "back_to_back",
             "us_per_launch_back_to_back": round(us_b2b, 2), "achieved_back_to_back": round(flops / (us_b2b * 1e-6) / 1e12, 1),
             "frac_back_to_back": round(flops / (us_b2b * 1e-6) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
             "us_per_launch_rocprof": prof,
@@ -204,7 +208,7 @@ def large_launch_roofline(precision, dev):
     configs[4]'s in_proj ([16384 x 3072] dY, W [3072 x 1024]; 2176 workgroups at the 128 x 128 tile the launch takes by itself).
     What a merged lockstep launch of many fits looks like to the kernel; reported beside the cfg2 launch, never instead of it."""
     from slnlp import ops
-    M, Nout, Kin, split = 16384, 3072, 1024, 6
+    M, Nout, Kin = 16384, 3072, 1024
     wp, dp = backward_passes() if precision == 3 else (precision, precision)
     g = torch.Generator().manual_seed(0)
     dY, X, W = [torch.randn(*sh, generator=g).to(dev) for sh in ((M, Nout), (M, Kin), (Nout, Kin))]
@@ -212,24 +216,28 @@ def large_launch_roofline(precision, dev):
     rs = torch.empty(Nout, device=dev)
     jw, _ = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=wp)
     jd, _ = ops.plane_job(dYp, Wp, M=M, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=dp)
-    scr = ops.gemm_group([jw, jd], [split, 1])
+    split, separate, geo_w, geo_d = ops.gemm_wd_plan(jw, jd)          # the library's own choice for this pair (slnlp_gemm_wd)
+    scr = ops.gemm_wd(jw, jd)
     for _ in range(10):
-        ops.gemm_group([jw, jd], [split, 1], scr)
+        ops.gemm_wd(jw, jd, scr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 40
     e0.record()
     for _ in range(n):
-        ops.gemm_group([jw, jd], [split, 1], scr)
+        ops.gemm_wd(jw, jd, scr)
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     flops = 2.0 * 2 * M * Nout * Kin
     tf = flops / (us * 1e-6) / 1e12
+    GEO_NAMES = ["64x64", "128x128 64-k ring", "128x128 32-k ring", "256x256 32-k ring"]
+    how = (f"TWO launches (both large: a launch each): wgrad {GEO_NAMES[geo_w]} split-K {split}, dgrad {GEO_NAMES[geo_d]}" if separate
+           else f"ONE grouped launch, {GEO_NAMES[geo_d]}, wgrad split-K {split}")
     traffic, traffic_src = pmc_large_launch_traffic()
-    return {"kernel": f"gemm_planes_kernel<{precision}, 128x128> dgrad+wgrad group [{M}x{Nout}]x[{Nout}x{Kin}], wgrad split-K {split} (configs[4] in_proj), "
+    return {"kernel": f"gemm_planes_kernel<{precision}> dgrad + wgrad of one dY [{M}x{Nout}]x[{Nout}x{Kin}] (configs[4] in_proj) as the plans launch it: {how}; "
                       f"split-bf16 passes wgrad {wp} / dgrad {dp}",
             "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
-            "population": "back-to-back launches, HIP events (live)",
+            "population": "back-to-back pairs, HIP events around the loop (live)",
             "traffic": traffic, "traffic_source": traffic_src, "us_per_launch_hip_events": round(us, 1), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * (M * Nout + M * Kin + Nout * Kin) + 4.0 * (M * Kin + Nout * Kin) + 4.0 * M * Kin,
             "mfma_pipe_frac": round((wp + dp) / 2.0 * tf / BF16_DENSE_PEAK_TFLOPS, 3),

@@ -118,6 +118,14 @@ int slnlp_set_gemm_ks(int ks);
 int slnlp_set_fp8_tile(int tile);
 int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,
                      int64_t scratch_bytes, void* stream);
+/* The gradient pair of one dY over plane operands -- wgrad: dW = dY^T x (A, B not k-major, rowsum_a = db), dgrad: dX = dY W (A k-major,
+ * B not) -- launched the way the training plans launch it: the library picks the weight gradient's K-split and whether the two
+ * share ONE grouped launch (the weight gradient's workgroups fill the CUs the data gradient leaves idle) or, when both are large,
+ * take a launch each with the tile that suits each.  scratch as for slnlp_gemm_group with split factors up to 8.
+ * slnlp_gemm_wd_plan reports the choice (geometry codes: 0 = 64 x 64, 1 = 128 x 128 / 64-k, 2 = 128 x 128 / 32-k, 3 = 256 x 256). */
+int slnlp_gemm_wd(const slnlp_gemm_args* wgrad, const slnlp_gemm_args* dgrad, void* scratch, int64_t scratch_bytes, void* stream);
+int slnlp_gemm_wd_plan(const slnlp_gemm_args* wgrad, const slnlp_gemm_args* dgrad, int32_t* split, int32_t* separate, int32_t* geo_wgrad,
+                       int32_t* geo_dgrad);
 /* The decoder's products: the reference decodes ONE target position (transformer.py:82-87), so every nn.Linear of its
  * decoder (and the generator, transformer.py:46-48,88) is y[B rows, N] = x[B rows, K] W[N, K]^T on a dependent chain.
  * Both operands as k-major bf16 hi / lo planes (A_hi / A_lo / lda_p, B_hi / B_lo / ldb_p; rows zero-padded to multiples of

@@ -274,6 +274,12 @@ int gemm_planes_init();
 int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs, void* scratch, size_t scratch_bytes,
                       hipStream_t s);
 size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs);
+// the gradient pair of one dY over plane operands: dW = dY^T x (split-K) and dX = dY W -- one grouped launch, or a launch each when
+// both are large (gemm_planes.hip: gemm_planes_wd_plan holds the rule; split <= WD_MAX_SPLITK)
+constexpr int WD_MAX_SPLITK = 8;
+struct WdPlan { int split, separate; };
+WdPlan gemm_planes_wd_plan(const slnlp_gemm_args& wgrad, const slnlp_gemm_args& dgrad);
+int gemm_planes_wd(const slnlp_gemm_args& wgrad, const slnlp_gemm_args& dgrad, void* scratch, size_t scratch_bytes, hipStream_t s);
 struct QuantRow { long off; int K, pad; };   // one weight row of a precision-8 plan: offset into the arena (floats), length
 int quant_rows_fp8(const float* x, int64_t ld, int R, int K, unsigned char* q, int64_t ldq, float* scale, const void* row_table,
                    hipStream_t st);   // row_table: device array of {long offset (floats); int K; int pad} or null

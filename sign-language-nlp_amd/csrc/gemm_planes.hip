@@ -950,6 +950,7 @@ struct LaunchShape {
     long units128 = 0, units256 = 0;     // workgroups the launch would have at 128 x 128 / 256 x 256 tiles
     int min_k = 1 << 30;                 // shortest K loop (per split)
     bool forward = true;                 // every job: both operands k-major, no split-K
+    int njobs = 0;
 };
 static void shape_add(LaunchShape& s, const slnlp_gemm_args& a, int nks) {
     if (nks < 1) nks = 1;
@@ -957,12 +958,17 @@ static void shape_add(LaunchShape& s, const slnlp_gemm_args& a, int nks) {
     s.units256 += (long)ceil_div(a.M, 256) * ceil_div(a.N, 256) * nks;
     s.min_k = std::min(s.min_k, a.K / nks);
     s.forward = s.forward && a.a_kmajor && a.b_kmajor && nks == 1 && a.precision != 2;
+    ++s.njobs;
 }
 static int plane_geo_auto(const LaunchShape& s) {
     const int forced = g_plane_geo.load(std::memory_order_relaxed);
     if (forced >= 0) return forced;
     if (s.units128 < BIG_TILE_MIN_UNITS) return 0;
     if (s.forward && s.min_k >= 1024 && (s.units256 >= 512 || s.min_k >= 2048) && s.units256 * 100 >= (s.units256 + 255) / 256 * 256 * 85) return 3;
+    // ... and for a gradient product launched ALONE (gemm_planes_wd below: the data and the weight gradient of a large dY take a
+    // launch each) with long K loops and a filled round of 256-wide tiles: configs[4] in_proj, data gradient 256 tiles x K 3072 --
+    // 212 -> 192 us; weight gradient 48 tiles x 5 K slices -- 253 -> 236 us (profiles/r05_plane_pair_sweep.txt)
+    if (s.njobs == 1 && !s.forward && s.min_k >= 2048 && s.units256 >= 192 && s.units256 * 100 >= (s.units256 + 255) / 256 * 256 * 85) return 3;
     return (s.min_k >= 1024 || s.units128 >= TWO_PER_CU_UNITS) ? 2 : 1;
 }
 int plane_geo_for(const slnlp_gemm_args* jobs, const int* split_k, int njobs) {
@@ -1114,6 +1120,53 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
     }
     if (timed >= 0) launch_timer_end(timed, s, blocks, njobs, geo);
     return 0;
+}
+
+// ---- the gradient pair of one dY: dW = dY^T x (split-K over the tokens) and dX = dY W.
+// Split factor of the weight gradient (K loop = tokens): the plane GEMM keeps 2 workgroups per CU resident (512 slots) and a K-step
+// costs about the same in every workgroup, so estimate   time ~ rounds(total workgroups / 512) x longest K loop   (+1 step for the
+// split-K meeting) and take the best split; more workgroups than slots only adds a second, mostly empty round.
+static int wd_split_grouped(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg) {
+    auto cd = [](int a, int b) { return (a + b - 1) / b; };
+    const int tw = cd(wg.M, 64) * cd(wg.N, 64), td = cd(dg.M, 64) * cd(dg.N, 64), kw = cd(wg.K, 64), kd = cd(dg.K, 64);
+    int best = 1, best_cost = 1 << 30;
+    for (int n = 1; n <= WD_MAX_SPLITK && n <= kw; ++n) {
+        const int len = cd(kw, n) + (n > 1 ? 1 : 0);
+        const int cost = cd(tw * n + td, 512) * (len > kd ? len : kd);
+        if (cost < best_cost) { best_cost = cost; best = n; }
+    }
+    return best;
+}
+// ONE launch for both -- the weight gradient's workgroups fill the CUs the data gradient leaves idle, and there is no second
+// dispatch to pay for -- unless both are large: then neither has idle CUs to offer, sharing a launch only mixes their working
+// sets in the L2s (1.70 GB fetched per launch together against 0.48 + 0.70 GB alone at configs[4]'s in_proj,
+// profiles/r05_pmc_plane_pair.txt), and alone each takes the tile and the split that suit it: the data gradient one full round of
+// 256-wide tiles, the weight gradient as many K slices as fill one round of them (48 tiles x 5).  Measured on one box
+// (profiles/r05_plane_pair_sweep.txt): 480 us grouped (128-wide tiles, 6 slices) -> 192 + 236 us.
+WdPlan gemm_planes_wd_plan(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg) {
+    WdPlan p;
+    p.separate = 0;
+    p.split = wd_split_grouped(wg, dg);
+    const long d128 = (long)ceil_div(dg.M, 128) * ceil_div(dg.N, 128), w256 = (long)ceil_div(wg.M, 256) * ceil_div(wg.N, 256);
+    static const bool allow_separate = [] { const char* e = getenv("SLNLP_WD_SEPARATE"); return !(e && atoi(e) == 0); }();   // (A / B measurements)
+    if (allow_separate && g_plane_geo.load(std::memory_order_relaxed) < 0 && wg.precision != 8 && d128 >= 1024 && dg.K >= 1024 && w256 >= 24 && w256 <= 256 && wg.K >= 4096) {
+        p.separate = 1;
+        int n = (int)(256 / w256);                          // K slices that fill one round of 256-wide tiles
+        n = std::min(n, std::min(WD_MAX_SPLITK, ceil_div(wg.K, 2048)));
+        p.split = std::max(n, 1);
+    }
+    return p;
+}
+int gemm_planes_wd(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    const WdPlan p = gemm_planes_wd_plan(wg, dg);
+    if (p.separate) {
+        const int one = 1;
+        SLNLP_TRY(gemm_planes_group(&wg, &p.split, 1, scratch, scratch_bytes, st));
+        return gemm_planes_group(&dg, &one, 1, scratch, scratch_bytes, st);
+    }
+    const slnlp_gemm_args jobs[2] = {wg, dg};
+    const int split[2] = {p.split, 1};
+    return gemm_planes_group(jobs, split, 2, scratch, scratch_bytes, st);
 }
 
 // A recorded job re-tiled for a merged launch (lockstep.hip): only the tile grid changes -- the K partition (nks) and the
@@ -1323,6 +1376,30 @@ extern "C" int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* spli
     if (jobs && njobs >= 1 && !jobs[0].A_hi && !jobs[0].B_hi) return slnlp::gemm_group(jobs, njobs, (hipStream_t)stream);
     return slnlp::gemm_planes_group(jobs, split_k, njobs, scratch, (size_t)(scratch_bytes < 0 ? 0 : scratch_bytes),
                                     (hipStream_t)stream);
+}
+
+extern "C" int slnlp_gemm_wd(const slnlp_gemm_args* wgrad, const slnlp_gemm_args* dgrad, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (!wgrad || !dgrad) {
+        slnlp::set_error("gemm_wd: null args");
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    return slnlp::gemm_planes_wd(*wgrad, *dgrad, scratch, (size_t)(scratch_bytes < 0 ? 0 : scratch_bytes), (hipStream_t)stream);
+}
+extern "C" int slnlp_gemm_wd_plan(const slnlp_gemm_args* wgrad, const slnlp_gemm_args* dgrad, int32_t* split, int32_t* separate, int32_t* geo_wgrad,
+                                  int32_t* geo_dgrad) {
+    if (!wgrad || !dgrad) {
+        slnlp::set_error("gemm_wd_plan: null args");
+        return SLNLP_ERR_INVALID_ARG;
+    }
+    const slnlp::WdPlan p = slnlp::gemm_planes_wd_plan(*wgrad, *dgrad);
+    if (split) *split = p.split;
+    if (separate) *separate = p.separate;
+    const slnlp_gemm_args jobs[2] = {*wgrad, *dgrad};
+    const int sk[2] = {p.split, 1}, one = 1;
+    const int g = p.separate ? -1 : slnlp::plane_geo_for(jobs, sk, 2);
+    if (geo_wgrad) *geo_wgrad = p.separate ? slnlp::plane_geo_for(wgrad, &p.split, 1) : g;
+    if (geo_dgrad) *geo_dgrad = p.separate ? slnlp::plane_geo_for(dgrad, &one, 1) : g;
+    return 0;
 }
 
 extern "C" int slnlp_split_planes(const float* x, int64_t ld, int R, int C, uint16_t* hi, uint16_t* lo, int64_t ldp,

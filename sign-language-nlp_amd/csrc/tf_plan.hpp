@@ -181,7 +181,7 @@ struct Ws {
     size_t bytes;
 };
 
-constexpr int MAX_SPLITK = 8;
+constexpr int MAX_SPLITK = WD_MAX_SPLITK;
 // weight-gradient GEMMs contract over the T tokens: aim at ~10 K-tiles (of 64) per workgroup
 static int splitk_for(int T) {
     const int n = ((T + 63) / 64 + 5) / 10;
@@ -589,21 +589,7 @@ struct slnlp_tf_plan {
     // weight gradient (split-K over the tokens) and data gradient of one dY in ONE launch: the wgrad's workgroups
     // fill the CUs the dgrad leaves idle, and there is no cross-queue edge to pay for (measured 4-10 us each)
     int wd_group(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, int which_scratch, hipStream_t st) const {
-        const slnlp_gemm_args jobs[2] = {wg, dg};
-        // Split factor of the weight gradient (K loop = tokens): the plane GEMM keeps 2 workgroups per CU resident
-        // (512 slots) and a K-step costs about the same in every workgroup, so estimate
-        //   time ~ rounds(total workgroups / 512) x longest K loop   (+1 step for the split-K meeting)
-        // and take the best split; more workgroups than slots only adds a second, mostly empty round.
-        auto cd = [](int a, int b) { return (a + b - 1) / b; };
-        const int tw = cd(wg.M, 64) * cd(wg.N, 64), td = cd(dg.M, 64) * cd(dg.N, 64), kw = cd(wg.K, 64), kd = cd(dg.K, 64);
-        int best = 1, best_cost = 1 << 30;
-        for (int n = 1; n <= MAX_SPLITK && n <= kw; ++n) {
-            const int len = cd(kw, n) + (n > 1 ? 1 : 0);
-            const int cost = cd(tw * n + td, 512) * (len > kd ? len : kd);
-            if (cost < best_cost) { best_cost = cost; best = n; }
-        }
-        const int split[2] = {best, 1};
-        return gemm_planes_group(jobs, split, 2, w.gscr[which_scratch], w.gscr_bytes, st);
+        return gemm_planes_wd(wg, dg, w.gscr[which_scratch], w.gscr_bytes, st);      // (split factor, one launch or two: gemm_planes.hip)
     }
     // zero padding of the activation planes is per batch size: re-zero when it changes (outside any capture)
     int prepare_planes(int B, hipStream_t st) {

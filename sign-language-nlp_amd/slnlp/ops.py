@@ -111,6 +111,24 @@ def gemm_group(jobs, split_k=None, scratch=None):
     return scratch
 
 
+def gemm_wd_plan(jw, jd):
+    """(split, separate, geometry of the wgrad launch, of the dgrad launch) the library picks for this gradient pair."""
+    v = [C.c_int32(0) for _ in range(4)]
+    check(load().slnlp_gemm_wd_plan(C.byref(jw), C.byref(jd), *[C.byref(x) for x in v]), "gemm_wd_plan")
+    return tuple(int(x.value) for x in v)
+
+
+def gemm_wd(jw, jd, scratch=None):
+    """The gradient pair of one dY (plane_job wgrad + dgrad) launched as the training plans launch it (slnlp_gemm_wd)."""
+    _lib.require_gpu()
+    if scratch is None:
+        arr = (GemmArgs * 2)(jw, jd)
+        sk = (C.c_int32 * 2)(8, 1)
+        scratch = torch.zeros(int(load().slnlp_gemm_group_scratch_bytes(arr, sk, 2)), dtype=torch.uint8, device="cuda")
+    check(load().slnlp_gemm_wd(C.byref(jw), C.byref(jd), ptr(scratch), scratch.numel(), stream_ptr()), "gemm_wd")
+    return scratch
+
+
 def gemm_planes(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, precision=3, rowsum_a=None, bias=None,
                 relu=False, resid=None, want_planes=False):
     """C = A B^T over pre-split operands Ap = (hi, lo), Bp = (hi, lo) (see split_planes)."""

@@ -16,6 +16,19 @@ load().slnlp_get_backward_passes(_C.byref(_w), _C.byref(_d))   # the passes the 
 jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=_w.value)
 jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=_d.value)
 check(load().slnlp_set_plane_tile(tile), "set_plane_tile")
+import os
+only = os.environ.get("ONLY", "")                      # ONLY=dgrad / wgrad: one of the two jobs alone (which one misses the L2?)
+if only:
+    jobs, splits = ([jd], [1]) if only == "dgrad" else ([jw], [split])
+    scr = ops.gemm_group(jobs, splits)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): ops.gemm_group(jobs, splits, scr)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / n * 1e3
+    print(f"{only} alone: tokens {Mtok} n_out {Nout} k_in {Kin} split {split} tile {tile}: {t:.1f} us/launch, {2.0 * Mtok * Nout * Kin / t / 1e6:.1f} TFLOP/s")
+    sys.exit(0)
 scr = ops.gemm_group([jw, jd], [split, 1])
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
