@@ -84,7 +84,16 @@ def build_sd(c, seed):
     return cfg, {k: torch.from_numpy(v) for k, v in w.items()}
 
 
-PROFILE_ROUND = "r04"           # which round's committed profiles the provenance-labelled fields are read from
+PROFILE_ROUNDS = ("r05", "r04")  # committed profiles the provenance-labelled fields are read from: the newest round that holds the file
+
+
+def profile_file(name):
+    """profiles/<round>_<name> of the newest round that has it (every value read from it is labelled with the path)."""
+    for r in PROFILE_ROUNDS:
+        f = os.path.join(ROOT, "profiles", f"{r}_{name}")
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", f"{PROFILE_ROUNDS[0]}_{name}")
 
 
 def backward_passes():
@@ -185,7 +194,7 @@ def dominant_kernel_roofline(c, precision, dev, workload, in_step=None):
 def held_clock():
     """Shader clock the chip holds under the plane GEMM (probe build: s_memtime / s_memrealtime over the K loop after 2 s of
     back-to-back launches on random data), from the committed probe output -- not measurable in the product build."""
-    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_plane_gemm_clock.txt")
+    f = profile_file("plane_gemm_clock.txt")
     try:
         vals = {}
         for line in open(f):
@@ -392,7 +401,7 @@ def _fit_local(gs, ds):
 def rocprof_kernel_times(workload):
     """The committed rocprofv3 --kernel-trace view of the same kernel (tools/roofline_kernel_stats.py): its back-to-back
     launches and its launches inside train steps, with the file it was read from, or None."""
-    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_bench_{workload}_roofline_kernel.json")
+    f = profile_file(f"bench_{workload}_roofline_kernel.json")
     try:
         e = json.load(open(f))
         return {"back_to_back_avg_us": e["back_to_back"]["avg_us"], "in_step_avg_us": e["in_step"]["avg_us"], "min_us": e["min_us"],
@@ -403,7 +412,7 @@ def rocprof_kernel_times(workload):
 
 def pmc_kernel_traffic(workload, shape):
     """(HBM bytes of one launch of `shape` ("kernel xWORKGROUPS") from the committed PMC passes, the file) or (None, None)."""
-    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{workload}_step_traffic.json")
+    f = profile_file(f"pmc_{workload}_step_traffic.json")
     try:
         e = json.load(open(f))["per_launch"][shape]
         return float(e["fetch_bytes"] + e["write_bytes"]), os.path.relpath(f, ROOT)
@@ -413,7 +422,7 @@ def pmc_kernel_traffic(workload, shape):
 
 def pmc_large_launch_traffic():
     """(HBM bytes of one launch of the configs[4] in_proj gradient group from the committed PMC passes, the file) or (None, None)."""
-    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_large_launch_traffic.json")
+    f = profile_file("pmc_large_launch_traffic.json")
     try:
         return float(json.load(open(f))["hbm_bytes"]), os.path.relpath(f, ROOT)
     except Exception:
@@ -422,7 +431,7 @@ def pmc_large_launch_traffic():
 
 def pmc_traffic(workload):
     """(HBM bytes per train step from the committed rocprofv3 --pmc passes (tools/pmc_step_traffic.py), the file) or (None, None)."""
-    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{workload}_step_traffic.json")
+    f = profile_file(f"pmc_{workload}_step_traffic.json")
     try:
         return float(json.load(open(f))["hbm_bytes_per_step"]), os.path.relpath(f, ROOT)
     except Exception:
@@ -572,8 +581,10 @@ def main():
 
     launch = {"auto": "auto", "graph": True, "eager": False}["eager" if args.eager else args.launch]
     from slnlp.launch import PROBE
-    if launch == "auto" and args.warmup < 2 + 2 * PROBE:
-        launch = False                       # not enough warmup steps to time both modes: plain launches
+    # "auto" times a few steps of hipGraph replay and of plain launches and keeps the faster (slnlp/launch.py: 2 + 2 * PROBE steps).
+    # With a short --warmup (the driver's 5) those steps run as a fixed PRE-warmup in front of it -- untimed like the warmup itself,
+    # so the W warmup steps and the K timed steps all run in the chosen mode
+    pre_warmup = max(0, 2 + 2 * PROBE - args.warmup) if launch == "auto" else 0
 
     def run(k0, k):
         for i in range(k0, k0 + k):
@@ -587,6 +598,8 @@ def main():
             torch.cuda.synchronize(dev)
 
     with torch.cuda.stream(stream):
+        if pre_warmup:
+            run(n_batches - pre_warmup, pre_warmup)
         run(0, args.warmup)
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -631,7 +644,8 @@ def main():
     if rank == 0:
         seqs = world * B * args.steps
         if launch == "auto":
-            launch_used = f"{'hipGraph replay' if chosen == 'graph' else 'eager stream launches'} (auto: timed both in warmup)"
+            launch_used = (f"{'hipGraph replay' if chosen == 'graph' else 'eager stream launches'} (auto: timed both in "
+                           f"{'warmup' if not pre_warmup else str(pre_warmup) + ' untimed pre-warmup steps + warmup'})")
         else:
             launch_used = "hipGraph replay" if launch else "eager stream launches"
         step_flops = 3.0 * fwd_flops_per_seq(c) * B

@@ -466,8 +466,9 @@ int slnlp_set_thread_stream_policy(int serialise);
 int slnlp_set_stream_policy(int serialise);
 
 /* Split-bf16 passes of the gradient products that run on the plane GEMM (the [S*B]-row dgrad / wgrad of every encoder-side
- * Linear; what autograd computes for nn.Linear behind /root/reference/model/transformer.py:40-45,82-87), process-wide,
- * read when a plan issues or records its launches.  3: the full split, A_lo B_hi + A_hi B_lo + A_hi B_hi (fp32-grade
+ * Linear; what autograd computes for nn.Linear behind /root/reference/model/transformer.py:40-45,82-87): the DEFAULT FOR PLANS
+ * CREATED AFTERWARDS -- a plan copies both counts at creation and keeps them for its life, so its eager steps, its captured
+ * graph, its lockstep program and every host thread that steps it issue the same products; other plans are not touched.  3: the full split, A_lo B_hi + A_hi B_lo + A_hi B_hi (fp32-grade
  * products).  2: dY enters with its bf16 head only (rounded to nearest: unbiased), A_hi (B_hi + B_lo) -- a third less MFMA work,
  * a quarter less operand staging, a three-stage ring in the same LDS.  Default since round 4: wgrad 2, dgrad 2.  Measured against
  * the reference's golden training trajectories (tools/backward_pass_errors.py, profiles/r04_backward_pass_errors.jsonl; cfg2, five

@@ -197,7 +197,7 @@ int launch_timer_begin(hipStream_t st);            // -> record index, or -1 whe
 void launch_timer_end(int rec, hipStream_t st, int blocks, int njobs, int geo);
 
 // split-bf16 passes of the plane GEMM's gradient products (2: the dY operand enters with its bf16 head only; 3: full split) --
-// process-wide, read when a plan builds (or records) its launches: slnlp_set_backward_passes, launch.hip
+// the process-wide DEFAULT FOR NEW PLANS: a plan copies it at creation and never looks again (slnlp_set_backward_passes, launch.hip)
 int wgrad_passes();
 int dgrad_passes();
 

@@ -255,6 +255,7 @@ struct slnlp_rnn_plan {
     bool use_planes = false;  // E, Hd multiples of 64: the M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
     int planes_B = -1;        // batch size the activation planes' zero padding is valid for
     int destroy_sync = 1;     // slnlp_rnn_set_destroy_sync: wait for the device before the plan goes away (launch.hpp)
+    int wgrad_p = 2, dgrad_p = 2;   // split-bf16 passes of the plane gradient products: the process default AT CREATION, fixed for the plan's life
     bool persistent = false;  // opt-in: all timesteps of an encoder layer in one launch (not yet faster; needs one fit per GPU)
     // backward through time: the cell kernel + K-sliced grouped GEMM pair per timestep (default), or ONE launch per timestep
     // (gemm.hip rnn_step_bwd_kernel; slnlp_rnn_set_fused_backward(plan, 1), env SLNLP_RNN_FUSED_BWD=1).  Round 4 built the
@@ -329,7 +330,7 @@ struct slnlp_rnn_plan {
         a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dx; a.ldc = Kin; a.M = M; a.N = Kin; a.K = Nout;
         a.resid = resid; a.ldr = Kin;
-        a.precision = cfg.precision == 3 ? dgrad_passes() : cfg.precision;     // (slnlp_set_backward_passes: dY's bf16 head only)
+        a.precision = cfg.precision == 3 ? dgrad_p : cfg.precision;     // (slnlp_set_backward_passes: dY's bf16 head only)
         return a;
     }
     slnlp_gemm_args wgr_p(const RPP& dy, int T, int Nout, const RPP& x, int Kin, float* dW, float* db) const {
@@ -339,7 +340,7 @@ struct slnlp_rnn_plan {
         a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
-        a.precision = cfg.precision == 3 ? wgrad_passes() : cfg.precision;
+        a.precision = cfg.precision == 3 ? wgrad_p : cfg.precision;
         return a;
     }
     // the recurrent dgrad dh(t-1) = dgh W_hh + carry contracts over the G*Hd gate columns: one K-slice per gate
@@ -404,6 +405,8 @@ int slnlp_rnn_create(const slnlp_rnn_config* cfg, const slnlp_tf_buffers* buf, s
                     "rnn_create: arenas / workspace must be 256-byte aligned");
     slnlp_rnn_plan* p = new slnlp_rnn_plan();
     p->cfg = *cfg;
+    p->wgrad_p = wgrad_passes();
+    p->dgrad_p = dgrad_passes();
     p->buf = *buf;
     p->L = build_rlayout(*cfg);
     p->w = rcarve(*cfg, buf->workspace);

@@ -79,6 +79,8 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
     p->w = carve(*cfg, buf->workspace);
     bool ok = attn_init() == 0 && gemm_planes_init() == 0;
     p->use_planes = (cfg->E % 64 == 0) && (cfg->F % 64 == 0);
+    p->wgrad_np = wgrad_passes();
+    p->dgrad_np = dgrad_passes();
     {   // SLNLP_DEC_ROWS=0: the decoder's products on gemm.hip's fp32-operand kernel again (A / B measurements; another arithmetic:
         // that kernel splits its operands itself, with a truncated head)
         const char* e = getenv("SLNLP_DEC_ROWS");
@@ -561,7 +563,12 @@ int slnlp_tf_debug_layout(const slnlp_tf_config* cfg, char* out, int64_t out_byt
     SLNLP_CHECK_ARG(out && out_bytes > 0, "tf_debug_layout: no output buffer");
     const Ws w = carve(*cfg, nullptr);
     std::string s;
-    auto add = [&](const std::string& n, const void* p) { s += n + " " + std::to_string((size_t)(const char*)p) + "\n"; };
+    bool first = true;          // (only the very first buffer may sit at offset 0: any other null pointer is a buffer this configuration does not carve)
+    auto add = [&](const std::string& n, const void* p) {
+        if (p == nullptr && !first) return;
+        first = false;
+        s += n + " " + std::to_string((size_t)(const char*)p) + "\n";
+    };
 #define F(pre, st, f) add(pre + std::string(#f), st.f)
     add("x0", w.x0); add("t0", w.t0);
     for (int i = 0; i < cfg->N; ++i) {

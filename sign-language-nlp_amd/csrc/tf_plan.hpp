@@ -193,13 +193,18 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     Bump b(base);
     const size_t B = c.B, S = c.S, E = c.E, F = c.F, H = c.H, M = B * S, Vp = align_up(c.Vt, 4);
     const size_t lnp = (size_t)SLNLP_LN_MAX_PARTIALS * 2 * E;
+    // plane path with single-tile attention (E, F multiples of 64, S <= 64): the attention context, d qkv, the gated FFN gradient and the
+    // dropout-masked LayerNorm gradients exist as bf16 planes only -- their fp32 twins have no writer and no reader and are not carved
+    // (34 MB per layer at cfg2; the debug layout omits them)
+    const bool lean = (E % 64 == 0) && (F % 64 == 0) && S <= 64;
+    auto opt = [&](size_t n) -> float* { return lean ? nullptr : b.take<float>(n); };
     w.x0 = b.take<float>(M * E);
     w.t0 = b.take<float>(B * E);
     for (int i = 0; i < c.N; ++i) {
         EncA a;
         a.qkv = b.take<float>(M * 3 * E);
         a.probs = b.take<float>(B * H * S * S);
-        a.ctx = b.take<float>(M * E);
+        a.ctx = opt(M * E);
         a.y1 = b.take<float>(M * E);
         a.st1 = b.take<float>(M * 2);
         a.x1 = b.take<float>(M * E);
@@ -210,13 +215,13 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.lnp1 = b.take<float>(lnp);
         a.lnp2 = b.take<float>(lnp);
         a.gA2 = b.take<float>(M * E);
-        a.gB2 = b.take<float>(M * E);
-        a.gh = b.take<float>(M * F);
+        a.gB2 = opt(M * E);
+        a.gh = opt(M * F);
         a.gx1 = b.take<float>(M * E);
         a.gA1 = b.take<float>(M * E);
-        a.gB1 = b.take<float>(M * E);
+        a.gB1 = opt(M * E);
         a.gctx = b.take<float>(M * E);
-        a.gqkv = b.take<float>(M * 3 * E);
+        a.gqkv = opt(M * 3 * E);
         a.gx0 = b.take<float>(M * E);
         w.enc.push_back(a);
     }
@@ -398,6 +403,9 @@ struct slnlp_tf_plan {
     }
     bool use_planes = false;   // E, F multiples of 64: M = S*B GEMMs run on pre-split bf16 planes (gemm_planes.hip)
     bool use_rows = false;     // ... and the decoder's B-row products on planes, register-direct (gemm_rows.hip; K <= 1024)
+    // split-bf16 passes of the plane GEMM's gradient products: the process default AT CREATION (slnlp_set_backward_passes), fixed for the
+    // plan's life -- a captured graph, a recorded lockstep program and every host thread that steps this plan issue the same products
+    int wgrad_np = 2, dgrad_np = 2;
     int planes_B = -1;         // batch size the activation planes' zero padding is valid for
 
     float* P(long off) const { return buf.params + off; }
@@ -566,7 +574,7 @@ struct slnlp_tf_plan {
         a.gate = gate; a.ldg = Kin; a.gate_scale = gate_scale;
         a.resid = resid; a.ldr = Kin;
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = Kin; }
-        a.precision = prec3() == 3 ? dgrad_passes() : prec3();
+        a.precision = prec3() == 3 ? dgrad_np : prec3();
         return a;
     }
     int dgrad_p(const PP& dy, long ldy, int M, int Nout, long woff, int Kin, float* dx, const float* gate,
@@ -580,7 +588,7 @@ struct slnlp_tf_plan {
         a.B_hi = x.hi; a.B_lo = x.lo; a.ldb_p = Kin; a.b_kmajor = 0;
         a.C = dW; a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = T;
         a.rowsum_a = db;
-        a.precision = prec3() == 3 ? wgrad_passes() : prec3();
+        a.precision = prec3() == 3 ? wgrad_np : prec3();
         return a;
     }
     int wgrad_p(const PP& dy, long ldy, int T, int Nout, const PP& x, int Kin, float* dW, float* db, hipStream_t st) const {

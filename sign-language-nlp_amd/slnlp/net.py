@@ -73,6 +73,12 @@ class _DeviceGate:
             if not exclusive and depth:                      # nested shared call
                 self._tl.shared = depth + 1
                 return
+            if exclusive and depth:
+                # this thread already holds the gate SHARED (it is inside a fused fit): waiting for "no shared holders" would wait for
+                # itself, for ever.  A torch-stepped fit / predict nested in a fused fit of the same thread has no legal order.
+                raise RuntimeError("slnlp device gate: a fit or predict that steps through torch kernels (exclusive use of the GPU) was "
+                                   "started from inside a fused fit of the same thread (shared use): finish the fused fit first, or run "
+                                   "the other estimator from a thread of its own")
             if exclusive:
                 self._excl_waiting += 1
                 while self._excl_owner is not None or self._shared:

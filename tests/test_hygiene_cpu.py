@@ -277,3 +277,49 @@ def test_the_built_library_contains_no_packed_fp32_instructions():
     lines, hits = chk.packed_fp32_hits(lib)          # (the Makefile runs the same check after linking)
     assert lines > 100000, "disassembly looks empty"
     assert not hits, f"{len(hits)} packed fp32 instructions in the built library (first: {hits[0]})"
+
+
+def test_device_gate_orders_shared_and_exclusive_holders_and_refuses_the_self_deadlock():
+    """slnlp.net._DeviceGate: fused fits hold the GPU shared, a fit that steps through torch kernels exclusively -- shared holders
+    overlap, an exclusive holder is alone, both nest per thread, and the one request that can never be granted (exclusive from a
+    thread that already holds the gate shared) raises instead of waiting for itself."""
+    import threading, time
+    import pytest
+    from slnlp.net import _DeviceGate
+    g = _DeviceGate()
+    inside, peak, excl_alone = [0], [0], [True]
+    lock = threading.Lock()
+
+    def shared():
+        g.enter(False)
+        g.enter(False)                                   # nested shared call
+        with lock:
+            inside[0] += 1
+            peak[0] = max(peak[0], inside[0])
+        time.sleep(0.05)
+        with lock:
+            inside[0] -= 1
+        g.leave(False)
+        g.leave(False)
+
+    def exclusive():
+        g.enter(True)
+        g.enter(False)                                   # the exclusive holder's nested (predict) call
+        with lock:
+            excl_alone[0] = excl_alone[0] and inside[0] == 0
+        time.sleep(0.02)
+        with lock:
+            excl_alone[0] = excl_alone[0] and inside[0] == 0
+        g.leave(False)
+        g.leave(True)
+
+    ts = [threading.Thread(target=shared) for _ in range(3)] + [threading.Thread(target=exclusive)] + [threading.Thread(target=shared) for _ in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join(10)
+    assert not any(t.is_alive() for t in ts)
+    assert peak[0] >= 2 and excl_alone[0]
+    g.enter(False)
+    with pytest.raises(RuntimeError, match="device gate"):
+        g.enter(True)
+    g.leave(False)
+    g.enter(True); g.leave(True)                         # ... and the gate is still usable

@@ -156,6 +156,34 @@ def test_train_steps_vs_golden(name):
     gold.check_summary(g, "wfinal", {k: v.cpu() for k, v in eng.views().items()}, TOL)
 
 
+def test_a_plan_keeps_the_backward_passes_it_was_created_with():
+    """slnlp_set_backward_passes is the default for plans created AFTERWARDS: a plan copies the counts at creation, so changing the
+    default between (or during) its steps does not change its products -- eager steps, a captured graph and other threads' plans
+    cannot end up with different arithmetic inside one fit."""
+    import ctypes as C
+    from slnlp._lib import load, check
+    g, c, sd, X, L, y = gold.tf_case("cfg1")
+    Xc, yc = X.cuda(), y.cuda()
+    w, d = C.c_int32(0), C.c_int32(0)
+    load().slnlp_get_backward_passes(C.byref(w), C.byref(d))
+    saved = (int(w.value), int(d.value))
+    try:
+        check(load().slnlp_set_backward_passes(2, 2), "set_backward_passes")
+        e1, e2 = make_engine(c, sd), make_engine(c, sd)
+        e1.set_lr(0.01); e2.set_lr(0.01)
+        e2.train_step(Xc, yc); e2.train_step(Xc, yc)
+        check(load().slnlp_set_backward_passes(3, 3), "set_backward_passes")      # ... while e1 is between / inside its steps
+        e3 = make_engine(c, sd)
+        e3.set_lr(0.01)
+        e1.train_step(Xc, yc); e1.train_step(Xc, yc)
+        e3.train_step(Xc, yc); e3.train_step(Xc, yc)
+        torch.cuda.synchronize()
+        assert torch.equal(e1.params, e2.params)                   # e1 kept (2, 2)
+        assert not torch.equal(e1.params, e3.params)               # a plan created under (3, 3) is another arithmetic
+    finally:
+        load().slnlp_set_backward_passes(*saved)
+
+
 def test_graph_replay_equals_eager():
     g, c, sd, X, L, y = gold.tf_case("cfg1")
     Xc, yc = X.cuda(), y.cuda()

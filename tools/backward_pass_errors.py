@@ -29,6 +29,10 @@ def summary_err(g, prefix, named):
     return worst_norm, worst_head
 
 
+import ctypes as _C
+_w, _d = _C.c_int32(0), _C.c_int32(0)
+load().slnlp_get_backward_passes(_C.byref(_w), _C.byref(_d))
+_SAVED = (int(_w.value), int(_d.value))          # the default this process started with: restored at the end (new plans copy it)
 out = []
 for name in (sys.argv[1:] or ["cfg1", "cfg2", "cfg5"]):
     g, c, sd, X, L, y = gold.tf_case(name)
@@ -54,4 +58,4 @@ for name in (sys.argv[1:] or ["cfg1", "cfg2", "cfg5"]):
                "grad_norm_rel_err_step0": norm_e[0], "grad_norm_rel_err_max": max(norm_e), "wfinal_worst_norm_err": wn, "wfinal_worst_head_err": wh}
         out.append(rec)
         print(json.dumps({k: (float("%.3g" % v) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
-check(load().slnlp_set_backward_passes(2, 3), "set_backward_passes")
+check(load().slnlp_set_backward_passes(*_SAVED), "set_backward_passes")        # leave the process default as it was found

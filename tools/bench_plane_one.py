@@ -1,5 +1,6 @@
 """ONE plane-GEMM launch shape at ONE tile geometry, a few launches -- the thing to run under rocprofv3 --pmc.
-    python tools/bench_plane_one.py <tokens> <n_out> <k_in> <split> <tile knob> [launches]"""
+    python tools/bench_plane_one.py <tokens> <n_out> <k_in> <split> <tile knob> [launches]
+split 0 = the gradient pair as the training plans launch it (slnlp_gemm_wd); ONLY=dgrad / wgrad in the environment = one job alone."""
 import sys, torch
 sys.path.insert(0, "sign-language-nlp_amd")
 from slnlp import ops
@@ -29,11 +30,16 @@ if only:
     t = e0.elapsed_time(e1) / n * 1e3
     print(f"{only} alone: tokens {Mtok} n_out {Nout} k_in {Kin} split {split} tile {tile}: {t:.1f} us/launch, {2.0 * Mtok * Nout * Kin / t / 1e6:.1f} TFLOP/s")
     sys.exit(0)
-scr = ops.gemm_group([jw, jd], [split, 1])
+if split == 0:      # split 0: the pair as the training plans launch it (slnlp_gemm_wd: the library picks split, tile, one launch or two)
+    print("library plan (split, separate, geometry wgrad, geometry dgrad):", ops.gemm_wd_plan(jw, jd))
+    launch = lambda scr=None: ops.gemm_wd(jw, jd, scr)
+else:
+    launch = lambda scr=None: ops.gemm_group([jw, jd], [split, 1], scr)
+scr = launch()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(n): ops.gemm_group([jw, jd], [split, 1], scr)
+for _ in range(n): launch(scr)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / n * 1e3
 print(f"tokens {Mtok} n_out {Nout} k_in {Kin} split {split} tile {tile}: {t:.1f} us/launch, {2 * 2.0 * Mtok * Nout * Kin / t / 1e6:.1f} TFLOP/s")

@@ -9,7 +9,25 @@ import os, re, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kernel_registers as kr
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+def find_objdump():
+    """llvm-objdump of the ROCm toolchain in use: next to $HIPCC's clang, under $ROCM_PATH / $HIP_PATH / /opt/rocm, or on PATH."""
+    import shutil
+    cands = []
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if hipcc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(root, "llvm", "bin", "llvm-objdump")]
+    for var in ("ROCM_PATH", "HIP_PATH"):
+        if os.environ.get(var):
+            cands.append(os.path.join(os.environ[var], "lib", "llvm", "bin", "llvm-objdump"))
+    cands.append("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    return shutil.which("llvm-objdump")
+
+
+OBJDUMP = find_objdump()
 
 
 def packed_fp32_hits(lib):
@@ -27,9 +45,10 @@ def packed_fp32_hits(lib):
 
 if __name__ == "__main__":
     lib = sys.argv[1]
-    if not os.path.exists(OBJDUMP):
-        print(f"check_no_packed_fp32: {OBJDUMP} not found -- cannot verify {lib}", file=sys.stderr)
-        sys.exit(1)
+    if not OBJDUMP:
+        # exit code 2 = "cannot verify" (the Makefile keeps the library and says so), 1 = packed fp32 found (the Makefile deletes it)
+        print(f"check_no_packed_fp32: no llvm-objdump (looked beside hipcc, under ROCM_PATH / HIP_PATH, /opt/rocm, on PATH) -- cannot verify {lib}", file=sys.stderr)
+        sys.exit(2)
     n, hits = packed_fp32_hits(lib)
     if n < 1000:
         print(f"check_no_packed_fp32: disassembly of {lib} looks empty ({n} lines)", file=sys.stderr)

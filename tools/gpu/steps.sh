@@ -15,6 +15,7 @@
 #   suite        the whole -m gpu suite
 #   bench        default bench line (cfg2) without grid / cpu baseline
 #   bench_full   the default bench.py run, exactly as the driver runs it
+#   records      every other workload's bench line with its cpu_baseline (cfg1, cfg3, cfg3gru, e1024, cfg5, cfg5 precision 8)
 #   bench_cfg5   cfg5 (configs[4] shape) line, precision 3
 #   bench_cfg5p8 ... precision 8
 #   bench_rnn    cfg3 LSTM + GRU lines
@@ -72,6 +73,9 @@ for spec in "$@"; do
     bench_cfg5)  timeout -k 10 400 python bench.py --workload cfg5 --steps 20 --warmup 5 --no-grid --no-cpu-baseline > $O/bench_cfg5.json 2> $O/bench_cfg5.err || { tail -5 $O/bench_cfg5.err; exit 1; }; line $O/bench_cfg5.json ;;
     bench_cfg5p8) timeout -k 10 400 python bench.py --workload cfg5 --precision 8 --steps 20 --warmup 5 --no-grid --no-cpu-baseline > $O/bench_cfg5_p8.json 2> $O/bench_cfg5_p8.err || { tail -5 $O/bench_cfg5_p8.err; exit 1; }; line $O/bench_cfg5_p8.json ;;
     bench_rnn)   for w in cfg3 cfg3gru; do timeout -k 10 400 python bench.py --workload $w --steps 40 --warmup 10 --no-grid --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err || { tail -5 $O/bench_$w.err; exit 1; }; line $O/bench_$w.json; done ;;
+    records)     # every workload's bench line WITH its cpu_baseline (the round's record-keeping runs -> profiles/<round>_bench_<workload>.json)
+                 for w in cfg1 cfg3 cfg3gru e1024 cfg5; do timeout -k 10 500 python bench.py --workload $w --steps 40 --warmup 10 --no-grid > $O/bench_$w.json 2> $O/bench_$w.err || { tail -5 $O/bench_$w.err; exit 1; }; line $O/bench_$w.json; done
+                 timeout -k 10 500 python bench.py --workload cfg5 --precision 8 --steps 40 --warmup 10 --no-grid > $O/bench_cfg5_p8.json 2> $O/bench_cfg5_p8.err || { tail -5 $O/bench_cfg5_p8.err; exit 1; }; line $O/bench_cfg5_p8.json ;;
     lockstep)    timeout -k 10 400 python tools/bench_lockstep.py --workload cfg2 --ks 1,4,15 --steps 12 > $O/lockstep.json 2> $O/lockstep.err || { tail -5 $O/lockstep.err; exit 1; }
                  tail -1 $O/lockstep.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], [(r['K'], r['seq_per_s'], r['ms_per_lockstep_step']) for r in d['results']])" ;;
     lockstep_rnn) for w in cfg3 cfg3gru; do timeout -k 10 400 python tools/bench_lockstep.py --workload $w --ks 1,4,16 --steps 12 > $O/lockstep_$w.json 2> $O/lockstep_$w.err || { tail -5 $O/lockstep_$w.err; exit 1; }
@@ -86,7 +90,7 @@ for spec in "$@"; do
 import json,sys
 for l in open('$O/gridcal.jsonl'):
     d=json.loads(l); print(d['lockstep'], d['fits_per_gpu'], d['units_per_thread'], d['folds_per_hr'], d['seconds'], d['work_units'], d['scores_crc32'])" ;;
-    profile)     bash tools/gpu/profile.sh r04 $O/prof ${PROFILE_SECTIONS:-} || exit 1 ;;
+    profile)     bash tools/gpu/profile.sh ${PROFILE_TAG:-r05} $O/prof ${PROFILE_SECTIONS:-} || exit 1 ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
