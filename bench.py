@@ -558,6 +558,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(hours=2))
         backend = dist.get_backend()
     dev = torch.device("cuda", dev_index)
+    rccl_ranks = 0
+    if backend == "nccl":
+        # count the ranks THROUGH RCCL (an all-reduce of ones on the GPUs), do not assume them: the bench line's ranks.rccl_ranks is
+        # this sum, and a communicator that does not span the world stops the run here instead of producing a line
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(round(float(ones.item())))
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: RCCL all-reduce counted {rccl_ranks} ranks, WORLD_SIZE is {world}")
 
     from slnlp import synth, tf_engine as te
     c = dict(WORKLOADS[args.workload], precision=args.precision)
@@ -675,7 +684,7 @@ def main():
                                    f"batch {B} len {S} |src| {c['Vs']} |tgt| {c['Vt']} dropout {c['dropout']}, "
                                    "fwd+CE+bwd+clip(0.5)+SGD(m=.9)",
                        "launch": launch_used, "per_gpu": "independent fit (grid shard)" + (f"; REHEARSAL: {world} ranks share {ndev} GPU(s)" if shared else "")},
-            "ranks": {"world": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+            "ranks": {"world": world, "backend": backend, "rccl_ranks": rccl_ranks,
                       "devices_visible": ndev, "rank_wall_s": [round(v, 4) for v in rank_walls]},
             "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 5),

@@ -411,3 +411,94 @@ def test_estimate_fit_bytes_asks_the_library_and_orders_candidates():
     assert 0 < small < mid < big and big > 2 * 2**30
     assert size(512, 512, 4, module="model.EncoderDecoderLSTMAttn") > 0
     assert size(128, 128, 2, module="torch.nn.Linear") is None
+
+
+# ---- 8 ranks x 5 host threads against rank 0's store (what `bench.py --gpus 8` starts on an 8-GPU node), rehearsed on the CPU:
+# the bench's own grid sample, lockstep units of up to 15 fits cut by the cost ceiling, a fake group fit whose duration follows
+# the estimated cost (with a deterministic +-30 % the estimate cannot see).  40 threads poll / add on ONE TCP store.
+def _sample_grid():
+    import bench
+    return bench.GRID_SAMPLE, bench.GRID_CV
+
+
+def rehearsal_group(factory, params_list, trains, tests, scoring="neg_log_loss", seeds=None):
+    """Stands in for slnlp.lockstep.fit_and_score_group: sleeps for the unit's estimated cost, scores = a pure function of the task."""
+    import time, zlib
+    cost = sum(grid.estimate_cost(p, trains[0].ids.shape[1], len(tr)) for p, tr in zip(params_list, trains))
+    jitter = 0.7 + 0.6 * (zlib.crc32(repr(sorted(params_list[0].items())).encode()) % 1000) / 1000.0
+    dt = min(0.5, REHEARSAL_S_PER_COST * cost * jitter)
+    with _SLEPT_LOCK:
+        _SLEPT[0] += dt
+    time.sleep(dt)
+    return [-float(p["lr"]) * p["module__embedding_size"] - 0.001 * len(te) - 0.01 * p["module__num_layers"] for p, te in zip(params_list, tests)]
+
+
+REHEARSAL_S_PER_COST = 2.5e-12
+_SLEPT, _SLEPT_LOCK = [0.0], __import__("threading").Lock()       # what this process' units slept in total
+
+
+def _run_rehearsal(rank, world, port, out, threads):
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G, cv = _sample_grid()
+    ds = synthetic_dataset(400, seq_len=48, src_vocab=300, n_labels=20, seed=1, min_len=8) if rank == 0 else None
+    gs = grid.ShardedGridSearchCV(lambda: None, G, cv=cv, refit=False, fits_per_gpu=threads, lockstep=15, fit_and_score_group=rehearsal_group,
+                                  recipe_init=False)
+    t0 = time.perf_counter()
+    gs.fit(ds)
+    out[rank] = (gs.cv_results_["mean_test_score"].tolist(), gs.rank_seconds_, gs.rank_tasks_, gs.n_units_, time.perf_counter() - t0, gs.best_index_, _SLEPT[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_times_five_host_threads_on_one_store_neither_deadlock_nor_dominate():
+    """the N = 8 leg of bench.py has never run -- 8 ranks x 5 host threads pulling work units from rank 0's
+    rendezvous store.  Here on the CPU (gloo; the fits are sleeps that follow the cost estimate): every rank ends with the one-rank
+    results, every unit is run exactly once, the ranks finish within 25 % of each other, and the whole search -- dataset
+    broadcast, 40 threads' store traffic, all_gather -- stays within 1.6 x the ideal makespan of its sleeps (sum / 40 threads)."""
+    G, cv = _sample_grid()
+    ds = synthetic_dataset(400, seq_len=48, src_vocab=300, n_labels=20, seed=1, min_len=8)
+    single = grid.ShardedGridSearchCV(lambda: None, G, cv=cv, refit=False, fits_per_gpu=2, lockstep=15, fit_and_score_group=rehearsal_group,
+                                      recipe_init=False).fit(ds)
+    world, threads = 8, 5
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_rehearsal, args=(world, _free_port(), out, threads), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        mean, secs, ntasks, n_units, wall, best, slept = out[r]
+        assert np.allclose(mean, single.cv_results_["mean_test_score"], rtol=0, atol=1e-12) and best == single.best_index_
+    mean, secs, ntasks, n_units, wall, best, _ = out[0]
+    assert sum(ntasks) == single.n_tasks_ == 480 and n_units >= world * threads          # cut finer than one unit per thread
+    assert max(secs) / (sum(secs) / len(secs)) <= 1.25, secs
+    ideal = sum(out[r][6] for r in range(world)) / (world * threads)                      # every thread asleep all the time
+    print(f"[rehearsal] {n_units} units, rank seconds {[round(v, 2) for v in secs]}, ideal makespan {ideal:.2f} s, wall (rank 0, with broadcast + gather) {wall:.2f} s")
+    assert max(secs) <= 1.6 * ideal + 0.3, (secs, ideal)                                   # (a dead-locked or serialised store shows here)
+
+
+def _run_world1_group(rank, world, port, out):
+    import zlib
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    gs = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=oracle_fit_and_score, refit=False, force_collectives=True).fit(ds)
+    out[rank] = "%08x" % zlib.crc32(np.asarray(gs.cv_results_["mean_test_score"], dtype=np.float64).tobytes())
+    dist.destroy_process_group()
+
+
+def test_one_rank_under_a_launcher_scores_like_one_rank_alone():
+    """`python bench.py --gpus 1` (BENCH) and the same command under torch.distributed.run with one process (SCALE, N = 1) take
+    different routes through the grid leg -- no process group against a world-1 group with its broadcast, store counter and
+    all_gather -- and must report the same scores_crc32 (bench.py's checksum of every candidate's mean test score)."""
+    import zlib
+    ds = synthetic_dataset(48, seq_len=8, src_vocab=40, n_labels=4, seed=3, min_len=3)
+    alone = grid.ShardedGridSearchCV(lambda: None, GRID, cv=CV, fit_and_score=oracle_fit_and_score, refit=False).fit(ds)
+    crc = "%08x" % zlib.crc32(np.asarray(alone.cv_results_["mean_test_score"], dtype=np.float64).tobytes())
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_world1_group, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out[0] == crc
