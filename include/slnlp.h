@@ -114,6 +114,11 @@ int slnlp_set_plane_tile(int tile);
  * tiles; one for everything larger, merged lockstep launches included), 1 or 2 forced.  A tuning / test knob: the K sum is
  * defined as (first half of the tiles) + (second half) whichever way it is scheduled, so results do not depend on it. */
 int slnlp_set_gemm_ks(int ks);
+/* Tile of the fused recurrent forward timestep (slnlp_rnn_step_fwd) when ONE fit launches it: 1 (default) = 16 batch rows x 16
+ * hidden units x all gates per workgroup -- 256 workgroups at B = 50, Hd = 512, two directions, 160 KB of operands each -- 0 = the
+ * 64-row tile (64 workgroups of 256 KB) that merged lockstep launches keep.  A tuning / test knob: same K order, same cell
+ * arithmetic per element, same bits.  Env: SLNLP_RNN_STEP_RT. */
+int slnlp_set_rnn_step_tile(int rows16);
 /* the same knob for precision-8 launches: 0 = automatic (128 x 128 once the launch holds >= 512 of them), 64 or 128 */
 int slnlp_set_fp8_tile(int tile);
 int slnlp_gemm_group(const slnlp_gemm_args* jobs, const int32_t* split_k, int njobs, void* scratch,

@@ -1124,25 +1124,218 @@ __global__ __launch_bounds__(256 * KS) void rnn_step_fwd_kernel(const RnnStepPar
     }
 }
 
+// The same timestep RE-TILED for a solo fit's launch: a workgroup owns 16 batch rows x 16 hidden units x all G gates (grid Hd / 16 x
+// ndir x row tiles of 16: 256 workgroups at B = 50, Hd = 512, two directions -- every CU -- instead of 64), WAVE g computes gate g's
+// 16 x 16 tile, and wave 0 applies the cell once the gates have met in LDS.  Why: such a launch lasts as long as one workgroup takes
+// to LOAD its operands (gemm_rows.hip measured the same for the decoder's products: ~33 GB/s per compute unit), and the 64-row
+// tile above pulls 128 KB of h beside its 128 KB of W_hh per workgroup where this one pulls 32 + 128.  Same K order, same halves,
+// same cell arithmetic per element: bit-identical to rnn_step_fwd_kernel (tests/test_rnn_gpu.py), so a merged lockstep launch --
+// which pays for total bytes, not for one workgroup's -- keeps the 64-row kernel (rnn_step_fwd_for_blocks).
+template <int NSPLIT, bool LSTM, bool EDGE, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void rnn_step_fwd_rt_kernel(const RnnStepParams P0, const RnnStepParams* __restrict__ tab) {
+    RnnStepParams P;
+    if (tab) P = tab[blockIdx.z];
+    else P = P0;
+    P.lengths = as_global(P.lengths);
+    P.rng = as_global(P.rng);
+    constexpr int G = LSTM ? 4 : 3;
+    constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    using TA = TileIO<true, 16>;
+    using TB = TileIO<true, 16>;
+    __shared__ __attribute__((aligned(16))) unsigned short As_all[KS * NP * TA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs_all[KS * G * NP * TB::PLANE];
+    __shared__ f32x4 red[(KS == 2 ? 4 : 0) * 64 + 4 * 64];     // group 1's half of the K sum; then the gates on their way to wave 0
+    const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
+    unsigned short* As = As_all + grp * NP * TA::PLANE;
+    unsigned short* Bs = Bs_all + grp * G * NP * TB::PLANE;
+    const int dir = blockIdx.y % P.ndir;
+    const slnlp_rnn_step_dir d = as_global(dir == 0 ? P.d[0] : P.d[1]);
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // wave = gate
+    const int B = P.B, Hd = P.Hd, j0 = blockIdx.x * 16, bm0 = (blockIdx.y / P.ndir) * 16;
+    const int K = Hd, ktiles = (K + BKT - 1) / BKT;
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra0[TA::NV], ra1[TA::NV], rb0[G][TB::NV], rb1[G][TB::NV];
+    auto fetch = [&](int kt, float4 (&ra)[TA::NV], float4 (&rb)[G][TB::NV]) {
+        TA::template fetch<true>(d.h_in, Hd, bm0, B, kt * BKT, K, tid, ra);
+#pragma unroll
+        for (int g = 0; g < G; ++g) TB::template fetch<true>(d.w_hh + (long)g * Hd * Hd, Hd, j0, Hd, kt * BKT, K, tid, rb[g]);
+    };
+    auto stash = [&](int kt, const float4 (&ra)[TA::NV], const float4 (&rb)[G][TB::NV]) {
+        TA::template stash<NSPLIT, EDGE>(As, tid, ra, bm0, B, kt * BKT, K);
+#pragma unroll
+        for (int g = 0; g < G; ++g) TB::template stash<NSPLIT, EDGE>(Bs + g * NP * TB::PLANE, tid, rb[g], j0, Hd, kt * BKT, K);
+    };
+    auto consume = [&]() {
+        if (wave >= G) return;                                     // (GRU: three gates, the fourth wave only stages)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 ah = TA::frag(As, 0, kk, lane);
+            bf16x8 al = ah;
+            if (NSPLIT == 3) al = TA::frag(As + TA::PLANE, 0, kk, lane);
+            const unsigned short* bt = Bs + wave * NP * TB::PLANE;
+            const bf16x8 bh = TB::frag(bt, 0, kk, lane);
+            if (NSPLIT == 3) {
+                const bf16x8 bl = TB::frag(bt + TB::PLANE, 0, kk, lane);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+        }
+    };
+    // the cell's own operands are requested first (by the wave that will apply it), so their latency hides behind the K loop
+    const int j = j0 + (lane & 15), jj = j < Hd ? j : 0;
+    float bh[G], xpv[4][G], hpv[4], cpv[4];
+    if (grp == 0 && wave == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) bh[g] = d.b_hh ? d.b_hh[g * Hd + jj] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = bm0 + ((lane >> 4) << 2) + r, bb = b < B ? b : 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) xpv[r][g] = d.xproj[(long)bb * G * Hd + g * Hd + jj];
+            hpv[r] = d.h_in[(long)bb * Hd + jj];
+            cpv[r] = LSTM ? d.c[(long)bb * Hd + jj] : 0.f;
+        }
+    }
+    // the K sum in two halves, tiles [0, T) and [T, ktiles), first + second: gemm_tile's definition
+    const int half = (ktiles + 1) / 2;
+    if constexpr (KS == 1) {
+        f32x4 acc_first = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto park = [&]() { acc_first = acc; acc = f32x4{0.f, 0.f, 0.f, 0.f}; };
+        fetch(0, ra0, rb0);
+        fetch(1, ra1, rb1);
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            if (kt == half) park();
+            lds_barrier();
+            stash(kt, ra0, rb0);
+            lds_barrier();
+            fetch(kt + 2, ra0, rb0);
+            consume();
+            if (kt + 1 >= ktiles) break;
+            if (kt + 1 == half) park();
+            lds_barrier();
+            stash(kt + 1, ra1, rb1);
+            lds_barrier();
+            fetch(kt + 3, ra1, rb1);
+            consume();
+        }
+        if (ktiles <= half) park();
+        acc = acc_first + acc;
+    } else {
+        const int k0 = grp * half, k1 = grp == 0 ? half : ktiles;
+        fetch(k0, ra0, rb0);
+        fetch(k0 + 1, ra1, rb1);
+        for (int it = 0; it < half; it += 2) {
+            const int kt = k0 + it;
+            lds_barrier();
+            if (kt < k1) stash(kt, ra0, rb0);
+            lds_barrier();
+            fetch(kt + 2, ra0, rb0);
+            if (kt < k1) consume();
+            if (it + 1 >= half) break;
+            lds_barrier();
+            if (kt + 1 < k1) stash(kt + 1, ra1, rb1);
+            lds_barrier();
+            fetch(kt + 3, ra1, rb1);
+            if (kt + 1 < k1) consume();
+        }
+        if (grp == 1) red[4 * 64 + wave * 64 + lane] = acc;
+        __syncthreads();
+        if (grp == 1) return;
+        acc = acc + red[4 * 64 + wave * 64 + lane];
+    }
+    // the gates meet: wave g -> LDS -> wave 0
+    red[wave * 64 + lane] = acc;
+    lds_barrier();                                 // (KS = 2: group 1 has left; the barrier counts the waves that remain)
+    if (wave != 0) return;
+    f32x4 ga[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) ga[g] = red[g * 64 + lane];
+
+    // ---- cell (same arithmetic and order as rnn_cell_fwd_kernel)
+    if (j >= Hd) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = bm0 + ((lane >> 4) << 2) + r;
+        if (b >= B) break;
+        const long idx = (long)b * Hd + j;
+        const bool valid = P.lengths ? (d.t < P.lengths[b]) : true;
+        float* a = d.acts + (long)b * G * Hd;
+        const float hprev = hpv[r];
+        float hnew;
+        if constexpr (LSTM) {
+            const float cprev = cpv[r];
+            const float gi = sigm(xpv[r][0] + (ga[0][r] + bh[0]));
+            const float gf = sigm(xpv[r][1] + (ga[1][r] + bh[1]));
+            const float gg = tanhf(xpv[r][2] + (ga[2][r] + bh[2]));
+            const float go = sigm(xpv[r][3] + (ga[3][r] + bh[3]));
+            const float cnew = gf * cprev + gi * gg;
+            hnew = go * tanhf(cnew);
+            a[j] = gi; a[Hd + j] = gf; a[2 * Hd + j] = gg; a[3 * Hd + j] = go;
+            d.cprev_save[idx] = cprev;
+            d.c[idx] = valid ? cnew : cprev;
+        } else {
+            const float hn = ga[2][r] + bh[2];
+            const float rr = sigm(xpv[r][0] + (ga[0][r] + bh[0]));
+            const float z = sigm(xpv[r][1] + (ga[1][r] + bh[1]));
+            const float nn = tanhf(xpv[r][2] + rr * hn);
+            hnew = (1.f - z) * nn + z * hprev;
+            a[j] = rr; a[Hd + j] = z; a[2 * Hd + j] = nn;
+            d.hn_save[idx] = hn;
+        }
+        d.h_out[idx] = valid ? hnew : hprev;
+        if (d.out) {
+            float o = valid ? hnew : P.fill;
+            if (P.drop_p > 0.f && valid)
+                o = dropout_keep(P.rng, P.drop_site, (unsigned)(d.out_row0 + b), (unsigned)(d.out_col0 + j), P.drop_thr)
+                        ? o / (1.f - P.drop_p) : 0.f;
+            d.out[(long)b * P.ld_out + j] = o;
+        }
+    }
+}
+
 // The kernel a MERGED launch of `blocks` workgroups runs in place of the recorded forward-step kernel `fn` (nullptr: `fn` is not one
 // of them, or is the right one already): same results, the thread-group count of the merged size.
-const void* rnn_step_fwd_for_blocks(const void* fn, const void* recorded_args, int blocks, int* threads) {
-    const void* pairs[8][2] = {
-        {(const void*)rnn_step_fwd_kernel<3, true, true, 1>, (const void*)rnn_step_fwd_kernel<3, true, true, 2>},
-        {(const void*)rnn_step_fwd_kernel<3, true, false, 1>, (const void*)rnn_step_fwd_kernel<3, true, false, 2>},
-        {(const void*)rnn_step_fwd_kernel<3, false, true, 1>, (const void*)rnn_step_fwd_kernel<3, false, true, 2>},
-        {(const void*)rnn_step_fwd_kernel<3, false, false, 1>, (const void*)rnn_step_fwd_kernel<3, false, false, 2>},
-        {(const void*)rnn_step_fwd_kernel<1, true, true, 1>, (const void*)rnn_step_fwd_kernel<1, true, true, 2>},
-        {(const void*)rnn_step_fwd_kernel<1, true, false, 1>, (const void*)rnn_step_fwd_kernel<1, true, false, 2>},
-        {(const void*)rnn_step_fwd_kernel<1, false, true, 1>, (const void*)rnn_step_fwd_kernel<1, false, true, 2>},
-        {(const void*)rnn_step_fwd_kernel<1, false, false, 1>, (const void*)rnn_step_fwd_kernel<1, false, false, 2>}};
-    for (auto& pr : pairs)
-        for (int k = 0; k < 2; ++k)
-            if (fn == pr[k]) {
-                const int ks = gemm_group_ks(blocks, ceil_div(static_cast<const RnnStepParams*>(recorded_args)->Hd, BKT));
-                *threads = 256 * ks;
-                return pr[ks - 1] == fn ? nullptr : pr[ks - 1];
-            }
+// kernel table: [precision 3 / 1][LSTM / GRU][EDGE][16-row re-tiled?][KS - 1]
+static const void* rnn_step_kernel(int ns, bool lstm, bool edge, bool rt, int ks) {
+#define SLNLP_RS(NS, L, E) (rt ? (ks == 2 ? (const void*)rnn_step_fwd_rt_kernel<NS, L, E, 2> : (const void*)rnn_step_fwd_rt_kernel<NS, L, E, 1>) \
+                               : (ks == 2 ? (const void*)rnn_step_fwd_kernel<NS, L, E, 2> : (const void*)rnn_step_fwd_kernel<NS, L, E, 1>))
+    if (ns == 3) {
+        if (lstm) return edge ? SLNLP_RS(3, true, true) : SLNLP_RS(3, true, false);
+        return edge ? SLNLP_RS(3, false, true) : SLNLP_RS(3, false, false);
+    }
+    if (lstm) return edge ? SLNLP_RS(1, true, true) : SLNLP_RS(1, true, false);
+    return edge ? SLNLP_RS(1, false, true) : SLNLP_RS(1, false, false);
+#undef SLNLP_RS
+}
+// slnlp_set_rnn_step_tile / SLNLP_RNN_STEP_RT=0: the 64-row tile for solo launches too (tests, A / B measurements; same bits)
+static std::atomic<int> g_rnn_step_rt{[] { const char* e = getenv("SLNLP_RNN_STEP_RT"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+static bool rnn_step_rt_enabled() { return g_rnn_step_rt.load(std::memory_order_relaxed) != 0; }
+// which tiling / thread groups a launch of `fits` timesteps [B x Hd, ndir directions] takes: the 16-row tile while it still fits the
+// chip about twice over (a launch-latency chain: one fit), the 64-row tile (a third of the operand bytes in total) beyond
+static void rnn_step_shape(int B, int Hd, int ndir, int fits, bool* rt, int* ks, dim3* grid) {
+    const int gx = ceil_div(Hd, 16), rt_blocks = gx * ndir * ceil_div(B, 16) * fits;
+    *rt = rnn_step_rt_enabled() && B > 16 && rt_blocks <= 512;
+    *grid = dim3(gx, ndir * ceil_div(B, *rt ? 16 : BM));
+    *ks = gemm_group_ks((int)(grid->x * grid->y) * fits, ceil_div(Hd, BKT));
+}
+// The kernel a MERGED launch of `fits` fits runs in place of the recorded forward-step kernel `fn` (nullptr: `fn` is not one of them):
+// same results, the tiling and thread-group count of the merged size.  `grid`: in = the recorded (x, y), out = the merged one.
+const void* rnn_step_fwd_for_blocks(const void* fn, const void* recorded_args, int fits, int* threads, dim3* grid) {
+    for (int ns = 1; ns <= 3; ns += 2)
+        for (int l = 0; l < 2; ++l)
+            for (int e = 0; e < 2; ++e)
+                for (int rt = 0; rt < 2; ++rt)
+                    for (int ks = 1; ks <= 2; ++ks)
+                        if (fn == rnn_step_kernel(ns, l != 0, e != 0, rt != 0, ks)) {
+                            const RnnStepParams& P = *static_cast<const RnnStepParams*>(recorded_args);
+                            bool mrt;
+                            int mks;
+                            rnn_step_shape(P.B, P.Hd, P.ndir, fits, &mrt, &mks, grid);
+                            *threads = 256 * mks;
+                            return rnn_step_kernel(ns, l != 0, e != 0, mrt, mks);
+                        }
     return nullptr;
 }
 
@@ -1163,33 +1356,20 @@ int rnn_step_fwd(int lstm, const slnlp_rnn_step_dir* dirs, int ndir, int B, int 
     if (ndir == 1) P.d[1] = P.d[0];
     P.B = B; P.Hd = Hd; P.ndir = ndir; P.lengths = (const long*)lengths; P.fill = fill; P.ld_out = ld_out;
     P.drop_p = drop_p; P.drop_thr = dropout_threshold(drop_p); P.drop_site = drop_site; P.rng = rng;
-    const dim3 grid(ceil_div(Hd, 16), ndir * ceil_div(B, BM));
     const bool edge = (Hd % BKT) != 0;
-    const bool rec = recording();
-    int rrc = 0;
-    // two thread groups per workgroup while the launch is a latency chain (gemm_group_ks: the rule of the 50-row GEMMs); a merged
-    // lockstep launch swaps the kernel for its one-group twin when it is past that size (rnn_step_fwd_for_blocks, lockstep.hip)
-    const bool two = gemm_group_ks((int)(grid.x * grid.y), ceil_div(Hd, BKT)) == 2;
-#define SLNLP_STEP(NS, L, E)                                                                                                    \
-    do {                                                                                                                        \
-        if (two) {                                                                                                              \
-            if (rec) rrc = record_op((const void*)rnn_step_fwd_kernel<NS, L, E, 2>, grid, dim3(512), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd"); \
-            else hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E, 2>), grid, dim3(512), 0, st, P, (const RnnStepParams*)nullptr); \
-        } else {                                                                                                                \
-            if (rec) rrc = record_op((const void*)rnn_step_fwd_kernel<NS, L, E, 1>, grid, dim3(256), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd"); \
-            else hipLaunchKernelGGL((rnn_step_fwd_kernel<NS, L, E, 1>), grid, dim3(256), 0, st, P, (const RnnStepParams*)nullptr); \
-        }                                                                                                                       \
-    } while (0)
-    if (precision == 3) {
-        if (lstm) { if (edge) SLNLP_STEP(3, true, true); else SLNLP_STEP(3, true, false); }
-        else { if (edge) SLNLP_STEP(3, false, true); else SLNLP_STEP(3, false, false); }
-    } else {
-        if (lstm) { if (edge) SLNLP_STEP(1, true, true); else SLNLP_STEP(1, true, false); }
-        else { if (edge) SLNLP_STEP(1, false, true); else SLNLP_STEP(1, false, false); }
+    // tile and thread groups for ONE fit's launch (a merged lockstep launch picks again for its size: rnn_step_fwd_for_blocks)
+    bool rt;
+    int ks;
+    dim3 grid;
+    rnn_step_shape(B, Hd, ndir, 1, &rt, &ks, &grid);
+    const void* fn = rnn_step_kernel(precision, lstm != 0, edge, rt, ks);
+    if (recording()) return record_op(fn, grid, dim3(256 * ks), 0, REC_Z, &P, sizeof(P), "rnn_step_fwd");
+    const RnnStepParams* no_tab = nullptr;
+    void* args[2] = {&P, &no_tab};
+    if (hipLaunchKernel(fn, grid, dim3(256 * ks), args, 0, st) != hipSuccess) {
+        set_error("rnn_step_fwd: %s", hipGetErrorString(hipGetLastError()));
+        return SLNLP_ERR_LAUNCH;
     }
-#undef SLNLP_STEP
-    if (rec) return rrc;
-    SLNLP_CHECK_LAUNCH("rnn_step_fwd");
     return SLNLP_OK;
 }
 
@@ -1491,5 +1671,10 @@ extern "C" int slnlp_set_gemm_ks(int ks) {
         return SLNLP_ERR_INVALID_ARG;
     }
     slnlp::g_gemm_ks.store(ks == 0 ? -1 : ks, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int slnlp_set_rnn_step_tile(int rows16) {
+    slnlp::g_rnn_step_rt.store(rows16 ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }

@@ -62,7 +62,7 @@ __device__ __forceinline__ void launder(slnlp_gemm_args& a) {
 
 // kernels a merged launch replays (type-erased by the recorder; declared here so lockstep.hip can name them)
 const void* gemm_group_kernel_ptr(int precision, int ks = 1);
-const void* rnn_step_fwd_for_blocks(const void* fn, const void* recorded_args, int blocks, int* threads);   // the forward-step kernel of a merged launch (gemm.hip)
+const void* rnn_step_fwd_for_blocks(const void* fn, const void* recorded_args, int fits, int* threads, dim3* grid);   // the forward-step kernel (tile, thread groups, grid) of a merged launch (gemm.hip)
 const void* gemm_rows_for_fits(const void* fn, const void* recorded_args, int fits, dim3* grid, size_t* lds);   // the B-row plane kernel of a merged launch (gemm_rows.hip)
 int gemm_group_ks(int blocks, int longest_ktiles);   // thread groups per workgroup a launch of this size takes (results do not depend on it)
 // tile geometries of the plane GEMM (gemm_planes.hip, GEO[]): 0 = 64 x 64, 1 = 128 x 128 (64-k stages), 2 = 128 x 128 (32-k stages), 3 = 256 x 256 (32-k stages)

@@ -202,9 +202,11 @@ static int merge(LockstepGroup* ls, std::vector<Recorder>& recs, Program& prog, 
             {   // the recurrent forward step splits its K loop over two thread groups while a launch is a latency chain; K fits side
                 // by side fill the chip and take the one-group twin (same bits: gemm.hip)
                 int threads = 0;
-                if (const void* twin = rnn_step_fwd_for_blocks(o0.fn, o0.args.data(), (int)(o0.grid.x * o0.grid.y) * K, &threads)) {
+                dim3 gr = o0.grid;
+                if (const void* twin = rnn_step_fwd_for_blocks(o0.fn, o0.args.data(), K, &threads, &gr)) {
                     m.fn = twin;
                     m.block = dim3(threads);
+                    m.grid = dim3(gr.x, gr.y, K);
                 }
             }
             {   // the decoder's B-row products pick their tile for K fits' worth of workgroups (same bits whatever the tile: gemm_rows.hip)

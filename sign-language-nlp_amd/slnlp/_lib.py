@@ -89,6 +89,7 @@ SIGNATURES = {
     "slnlp_abi_version": (i32, []),
     "slnlp_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "slnlp_gemm_group_scratch_bytes": (i64, [C.POINTER(GemmArgs), C.POINTER(i32), i32]),
+    "slnlp_set_rnn_step_tile": (i32, [i32]),
     "slnlp_gemm_group": (i32, [C.POINTER(GemmArgs), C.POINTER(i32), i32, vp, i64, vp]),
     "slnlp_gemm_wd": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp, i64, vp]),
     "slnlp_gemm_wd_plan": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

@@ -175,6 +175,40 @@ def test_fused_backward_step_equals_cell_plus_ksliced_gemm(rnn_type, name):
 
 
 @pytest.mark.parametrize("lstm", [1, 0])
+@pytest.mark.parametrize("B,Hd,ndir", [(50, 512, 2), (50, 512, 1), (33, 256, 2), (70, 64, 2), (20, 40, 1)])
+def test_recurrent_step_tiles_return_the_same_bits(lstm, B, Hd, ndir):
+    """The fused forward timestep on its two tiles -- 16 batch rows per workgroup with the gates on four waves (one fit's launch:
+    every CU gets a workgroup) and 64 rows with the gates in one wave's accumulators (merged lockstep launches) -- must agree bit
+    for bit (slnlp_set_rnn_step_tile): same K order, same halves, same cell arithmetic per element."""
+    import ctypes as C
+    from slnlp import ops
+    from slnlp._lib import RnnStepDir, check, load, ptr, stream_ptr
+    G = 4 if lstm else 3
+    g = torch.Generator().manual_seed(B + Hd + lstm)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+    h, c, W, bh, xp = rnd(ndir, B, Hd) * 0.5, rnd(ndir, B, Hd) * 0.5, rnd(ndir, G * Hd, Hd) * 0.05, rnd(ndir, G * Hd) * 0.1, rnd(ndir, B, G * Hd)
+    lengths = torch.randint(1, 6, (B,), generator=g).cuda()
+    rng = ops.make_rng(seed=3, step=1)
+    t, p, site, fill, ld_out = 2, 0.2, 40, 1.0, 2 * Hd
+    res = []
+    try:
+        for tile in (1, 0):
+            load().slnlp_set_rnn_step_tile(tile)
+            bufs = dict(acts=torch.zeros(ndir, B, G * Hd).cuda(), cprev=torch.zeros(ndir, B, Hd).cuda(), hn=torch.zeros(ndir, B, Hd).cuda(),
+                        out=torch.zeros(B, ld_out).cuda(), c=c.clone(), h_out=torch.zeros(ndir, B, Hd).cuda())
+            dirs = (RnnStepDir * ndir)(*[RnnStepDir(ptr(h[k]), ptr(bufs["h_out"][k]), ptr(W[k]), ptr(bh[k]), ptr(xp[k]), ptr(bufs["c"][k]), ptr(bufs["cprev"][k]),
+                                                    ptr(bufs["acts"][k]), ptr(bufs["hn"][k]), bufs["out"].data_ptr() + 4 * k * Hd, t, t * B, k * Hd) for k in range(ndir)])
+            check(load().slnlp_rnn_step_fwd(lstm, dirs, ndir, B, Hd, ptr(lengths), fill, ld_out, p, site, ptr(rng), 3, stream_ptr()), "step")
+            torch.cuda.synchronize()
+            res.append(bufs)
+    finally:
+        load().slnlp_set_rnn_step_tile(1)
+    for k in ("h_out", "acts", "out", "c", "cprev", "hn"):
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert float(res[0]["h_out"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("lstm", [1, 0])
 @pytest.mark.parametrize("B,Hd", [(50, 512), (7, 40), (70, 64)])
 def test_fused_step_equals_gemm_plus_cell(lstm, B, Hd):
     """slnlp_rnn_step_fwd (recurrent GEMM + cell in one launch) against slnlp_gemm + slnlp_rnn_cell_fwd on the same
