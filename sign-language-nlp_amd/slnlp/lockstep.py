@@ -148,9 +148,17 @@ def fit_lockstep(nets, datasets):
         nets[0]._gate.leave(False)
 
 
+# tools/bench_grid_long.py sets EPOCH_LOG = [] to get one record per lockstep unit: how many fits were still training in each
+# epoch and how long the epoch took (fits that stop early -- EarlyStopping, helper.py:240-250 -- leave the group, which is
+# rebuilt from the fits that are left: `regroups`)
+EPOCH_LOG = None
+
+
 def _fit_lockstep_gated(nets, datasets):
     from .net import _FitRun, stream_sync
+    import time
     K = len(nets)
+    log = {"fits": K, "epochs": [], "regroups": 0} if EPOCH_LOG is not None else None
     stream = nets[0]._stream
     assert all(n._stream is stream for n in nets), "lockstep: the fits of a group share the device's stream"
     nets[0]._enter_stream()                             # the stream waits for whatever this thread queued elsewhere so far
@@ -175,6 +183,8 @@ def _fit_lockstep_gated(nets, datasets):
                 if group is not None:
                     stream_sync(stream)
                     group.close()
+                    if log is not None:
+                        log["regroups"] += 1
                 group = LockstepGroup([engines[i] for i in active])
                 if adam is not None:
                     group.set_adam([nets[i].module_.adam_second_moment() for i in active], adam[1], adam[2], adam[3])
@@ -188,6 +198,7 @@ def _fit_lockstep_gated(nets, datasets):
                 engines[i].set_lr(nets[i].lr_)
                 nets[i].module_.train()
                 runs[i].begin_epoch()
+            t_epoch = time.perf_counter()
             group.epoch(TRAIN, r0.bs, True, r0.momentum, r0.max_norm)
             if r0.va is not None:
                 group.epoch(VALID, r0.bs, False, r0.momentum, r0.max_norm)
@@ -198,10 +209,15 @@ def _fit_lockstep_gated(nets, datasets):
                 va = group.results(VALID, j, r0.bs) if r0.va is not None else None
                 if not runs[i].end_epoch(tr, va):
                     nxt.append(i)
+            if log is not None:
+                log["epochs"].append([len(active), time.perf_counter() - t_epoch])
             active = nxt
     stream_sync(stream)
     if group is not None:
         group.close()
+    if log is not None:
+        log["epochs_run"] = [len(n.history) for n in nets]
+        EPOCH_LOG.append(log)
     return nets
 
 

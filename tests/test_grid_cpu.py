@@ -502,3 +502,50 @@ def test_one_rank_under_a_launcher_scores_like_one_rank_alone():
     out = mgr.dict()
     mp.spawn(_run_world1_group, args=(1, _free_port(), out), nprocs=1, join=True)
     assert out[0] == crc
+
+
+def test_simulated_schedule_with_the_unit_duration_spread_measured_to_early_stopping():
+    """a grid run to EarlyStopping (profiles/r05_grid_long.json: 120 fits, max_epochs 80, patience 30; a third of the
+    fits stop early, 26 regroupings) says how far a unit's duration strays from its estimated cost: 0.70 ... 2.57 of the median
+    ratio.  The simulated 8-GPU schedule of the bench sample is re-run with every unit's work scaled by those measured ratios
+    (dealt out cyclically, several phases): the dynamic counter absorbs the spread -- strong-scaling efficiency stays >= 0.90 at
+    8 GPUs and >= 0.93 at 2 / 4 -- while a static deal of the same units loses much more."""
+    import json, os, bench
+    from slnlp import grid_sim as gs
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r04_grid_calibration.json")))
+    long_run = json.load(open(os.path.join(ROOT, "profiles", "r05_grid_long.json")))
+    ratios = long_run["unit_seconds_over_estimated_cost_normalised"]["values"]
+    assert len(ratios) >= 20 and min(ratios) < 0.8 and max(ratios) > 1.5
+    per_fit = {}
+    for u in cal["solo_units_lockstep15_one_thread"]:
+        sh = u["shape"]
+        per_fit.setdefault((sh["embedding_size"], sh["hidden_size"], sh["num_heads"], sh["num_layers"]), []).append(u["seconds"] / u["fits"])
+    per_fit = {k: float(np.mean(v)) for k, v in per_fit.items()}
+    gain = gs.gain_from_throughputs({int(k): v for k, v in cal["throughput_by_threads_lockstep15_kfolds_per_hr"].items() if k.isdigit()})
+    ds = synthetic_dataset(bench.GRID_SAMPLES, seq_len=48, src_vocab=300, n_labels=200, seed=1, min_len=8)
+    defaults = {"max_epochs": bench.GRID_EPOCHS}
+    cands, folds, tasks, order = grid.build_tasks(bench.GRID_SAMPLE, ds.y, bench.GRID_CV, 48, defaults)
+    tc = lambda t: grid.estimate_cost(cands[tasks[t][0]], 48, len(folds[tasks[t][1]][0]), defaults)
+    total = sum(tc(t) for t in range(len(tasks)))
+    shape = lambda u: tuple(cands[tasks[u[0]][0]][k] for k in ("module__embedding_size", "module__hidden_size", "module__num_heads", "module__num_layers"))
+
+    def units_at(world, phase):
+        units = grid.build_units(cands, folds, tasks, order, 15, None, tc, grid.unit_cost_ceiling(total, world, 4, grid.UNITS_PER_THREAD), 4)
+        costs = [sum(tc(t) for t in u) for u in units]
+        work = [per_fit[shape(u)] * len(u) * ratios[(i * 7 + phase) % len(ratios)] for i, u in enumerate(units)]
+        return work, costs
+
+    eff, eff_static = {}, {}
+    for world in (2, 4, 8):
+        worst, worst_static = 1.0, 1.0
+        for phase in range(4):
+            w1, c1 = units_at(1, phase)
+            wn, cn = units_at(world, phase)
+            t1 = max(gs.simulate(w1, c1, 1, 4, gain, seed=s)["makespan"] for s in range(4))
+            tn = max(gs.simulate(wn, cn, world, 4, gain, seed=s)["makespan"] for s in range(4))
+            ts = gs.simulate(wn, cn, world, 4, gain, seed=0, static=True)["makespan"]
+            worst, worst_static = min(worst, t1 / (world * tn)), min(worst_static, t1 / (world * ts))
+        eff[world], eff_static[world] = worst, worst_static
+    print(f"[grid_sim with the measured spread] dynamic {eff}, static {eff_static}")
+    assert eff[2] >= 0.93 and eff[4] >= 0.93 and eff[8] >= 0.90, eff
+    assert eff_static[8] < eff[8]
