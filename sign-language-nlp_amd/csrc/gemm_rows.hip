@@ -95,6 +95,42 @@ __device__ __forceinline__ bf16x8 rows_tr_frag(const unsigned short* img, int kk
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- the WEIGHT operand of a product arrives as fp32 (row stride ldb) and is split in registers: hi = bf16(x) rounded to nearest,
+// lo = bf16(x - hi) -- exactly split_bf16, i.e. the bits a plane of the weight would hold -- so the optimizer kernels need not keep
+// bf16 planes of the decoder's weights (20 instead of 24 B per parameter and step for 58 % of the cfg2 parameters: a 15-fit lockstep
+// step's sgd_kernel 1.87 -> 1.57 ms).  Same bytes per fragment as hi + lo planes (8 x 4 B).
+template <int NSPLIT>
+__device__ __forceinline__ void rows_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        if (NSPLIT == 3) lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
+// k-major weight rows ([n][k], the forward products): the lane's 8 consecutive k of its row, two 16-byte loads
+__device__ __forceinline__ void rows_load8(const float* __restrict__ p, float (&x)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+// m-major weight ([k][n], the data gradients): a wave-private fp32 image [64 k][16 n] (4 KiB) filled by four LDS-DMA instructions
+// (lane -> k-row 16 q + lane / 4, 16-byte piece lane % 4; a piece never starts past column N - 4) ...
+constexpr int RT_FIMG = 64 * 16;              // floats of one fp32 image
+__device__ __forceinline__ void rows_dma_image_f32(const float* __restrict__ W, long ld, int k0, int c0, int N, float* img, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = min(c0 + 4 * (lane & 3), N - 4);
+        const float* src = W + (long)(k0 + 16 * q + (lane >> 2)) * ld + c;
+        __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(img + q * 256), 16, 0, 0);
+    }
+}
+// ... and read back transposed: lane (column l & 15, k-octet l >> 4) takes its 8 k-values with 8 ds_read_b32
+__device__ __forceinline__ void rows_img_col8(const float* img, int kk, int lane, float (&x)[8]) {
+    const float* p = img + (kk * 32 + ((lane >> 4) << 3)) * 16 + (lane & 15);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = p[e * 16];
+}
+
 // One product unit: output tile (bx, by) of 16 MT rows x 16 NT columns.  BK: the B operand is k-major (forward products: fragments
 // straight from the plane) or m-major (data gradients: the wave's image through LDS, above).  smem: [partials][wave images].
 template <int NSPLIT, int MT, int NT, bool BK>
@@ -125,7 +161,8 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
     // (its products belong to rows >= M / columns >= N, which nothing stores)
     const int am_last = ((M + 15) / 16 - 1) * 16, bn_last = ((N + 15) / 16 - 1) * 16;
     const long koct = 8 * (lane >> 4);
-    const unsigned short *ah[MT], *al[MT], *bh[NT], *bl[NT];
+    const unsigned short *ah[MT], *al[MT];
+    const float* bw[NT];                                   // k-major weight: this lane's row of column tile j, at its k-octet
     int bcol[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -135,11 +172,10 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         bcol[j] = min(bn0 + 16 * j, bn_last);
-        const long off = (long)(bcol[j] + (lane & 15)) * g.ldb_p + koct;
-        bh[j] = g.B_hi + off; bl[j] = g.B_lo + off;
+        bw[j] = g.B + (long)min(bcol[j] + (lane & 15), N - 1) * g.ldb + koct;      // (a row past N is a repeat of row N - 1: never stored)
     }
-    // (m-major B: this wave's images, behind the partial tiles: [NT column tiles][hi, lo][64 k][16 n])
-    unsigned short* bimg = reinterpret_cast<unsigned short*>(part + (size_t)ktiles * MT * NT * 256) + wave * NT * 2 * RT_IMG;
+    // (m-major B: this wave's fp32 images, behind the partial tiles: [NT column tiles][64 k][16 n])
+    float* bimg = part + (size_t)ktiles * MT * NT * 256 + wave * NT * RT_FIMG;
 
     // what the epilogue will want: wave w < MT * NT runs it for MFMA tile (w / NT, w % NT); the lane holds rows gm0 .. gm0 + 3 of column gn
     const int ei = wave / NT, ej = wave % NT;
@@ -164,10 +200,7 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
         if (!BK) {
             if (t != wave) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the images' last fragment reads: LDS operations of a wave retire in order)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                rows_dma_image(g.B_hi, g.ldb_p, t * 64, bcol[j], bimg + (2 * j) * RT_IMG, lane);
-                if (NSPLIT == 3) rows_dma_image(g.B_lo, g.ldb_p, t * 64, bcol[j], bimg + (2 * j + 1) * RT_IMG, lane);
-            }
+            for (int j = 0; j < NT; ++j) rows_dma_image_f32(g.B, g.ldb, t * 64, bcol[j], N, bimg + j * RT_FIMG, lane);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -175,8 +208,9 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
             if (BK) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    fb[kk][j] = *reinterpret_cast<const bf16x8*>(bh[j] + k);
-                    if (NSPLIT == 3) lb[kk][j] = *reinterpret_cast<const bf16x8*>(bl[j] + k);
+                    float x[8];
+                    rows_load8(bw[j] + k, x);
+                    rows_split8<NSPLIT>(x, fb[kk][j], lb[kk][j]);
                 }
             }
 #pragma unroll
@@ -194,8 +228,9 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    fb[kk][j] = rows_tr_frag(bimg + (2 * j) * RT_IMG, kk, lane);
-                    if (NSPLIT == 3) lb[kk][j] = rows_tr_frag(bimg + (2 * j + 1) * RT_IMG, kk, lane);
+                    float x[8];
+                    rows_img_col8(bimg + j * RT_FIMG, kk, lane, x);
+                    rows_split8<NSPLIT>(x, fb[kk][j], lb[kk][j]);
                 }
         }
 #if SLNLP_PROBE_FENCES == 256
@@ -407,7 +442,7 @@ static RowsBwdKernel rows_bwd_kernel(int precision, int geo) {
 static size_t rows_lds(int geo, int K) { return (size_t)ceil_div(K, 64) * RT_GEO[geo].mt * RT_GEO[geo].nt * 64 * 4 * sizeof(float); }
 // backward launches: the data gradient's partial tiles + its waves' W images, or the weight gradient's four images per wave
 static size_t rows_bwd_lds(int geo, int K) {
-    const size_t d = rows_lds(geo, K) + (size_t)RT_WAVES * RT_GEO[geo].nt * 2 * RT_IMG * sizeof(unsigned short);
+    const size_t d = rows_lds(geo, K) + (size_t)RT_WAVES * RT_GEO[geo].nt * RT_FIMG * sizeof(float);
     const size_t w = (size_t)(RT_GEO[geo].mt + RT_WAVES) * 2 * RT_IMG * sizeof(unsigned short);      // the workgroup's dY images + the waves' x images
     return d > w ? d : w;
 }
@@ -482,14 +517,15 @@ const void* gemm_rows_for_fits(const void* fn, const void* recorded_args, int fi
 }
 
 static int check_rows_job(const slnlp_gemm_args& a, bool b_kmajor, const char* who) {
-    SLNLP_CHECK_ARG(a.A_hi && a.B_hi, "%s: operand planes required", who);
+    SLNLP_CHECK_ARG(a.A_hi && a.B, "%s: A as bf16 planes (A_hi / A_lo / lda_p) and the weight B as fp32 (B / ldb) required", who);
     SLNLP_CHECK_ARG(a.a_kmajor && (a.b_kmajor != 0) == b_kmajor, "%s: operand layouts (A k-major; B k-major for a forward product, m-major for a data gradient)", who);
     SLNLP_CHECK_ARG(a.C || a.C_hi, "%s: no output", who);
     SLNLP_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "%s: bad shape M=%d N=%d K=%d", who, a.M, a.N, a.K);
-    SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo && a.B_lo), "%s: precision 1, or 3 with both lo planes", who);
-    SLNLP_CHECK_ARG(a.lda_p % 64 == 0 && a.ldb_p % 64 == 0 && a.lda_p >= a.K && a.ldb_p >= (b_kmajor ? a.K : a.N),
-                    "%s: plane row strides must be multiples of 64 and cover the row (zero-padded)", who);
-    SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.B_hi | (uintptr_t)a.A_lo | (uintptr_t)a.B_lo) & 15) == 0, "%s: planes must be 16-byte aligned", who);
+    SLNLP_CHECK_ARG(a.precision == 1 || (a.precision == 3 && a.A_lo), "%s: precision 1, or 3 with A's lo plane", who);
+    SLNLP_CHECK_ARG(a.lda_p % 64 == 0 && a.lda_p >= a.K, "%s: A's plane row stride must be a multiple of 64 and cover K (zero-padded)", who);
+    SLNLP_CHECK_ARG(a.K % 64 == 0 && a.ldb % 4 == 0 && a.ldb >= (b_kmajor ? a.K : a.N) && (b_kmajor || a.N % 4 == 0),
+                    "%s: K must be a multiple of 64 (the fp32 weight has no padding), ldb a multiple of 4 that covers a row", who);
+    SLNLP_CHECK_ARG((((uintptr_t)a.A_hi | (uintptr_t)a.A_lo | (uintptr_t)a.B) & 15) == 0, "%s: operands must be 16-byte aligned", who);
     SLNLP_CHECK_ARG(!a.C || a.ldc >= a.N, "%s: ldc < N", who);
     SLNLP_CHECK_ARG(!a.C_hi || a.ldc_p >= a.N, "%s: ldc_p < N", who);
     SLNLP_CHECK_ARG(a.drop_p >= 0.f && a.drop_p < 1.f && (a.drop_p == 0.f || a.rng), "%s: bad dropout args", who);

@@ -391,11 +391,11 @@ struct slnlp_tf_plan {
         wplanes_gen = g;
         return 0;
     }
-    // the arena range whose planes have readers: everything behind the embeddings -- the encoder layers' weights (plane GEMMs),
-    // the decoder layers' and the generator's (the B-row products, gemm_rows.hip); the embedding tables are gathered as fp32.
+    // the arena range whose planes have readers: the encoder layers' weights (plane GEMMs).  Everything else -- the embedding tables,
+    // the decoder layers' and the generator's weights (the B-row products split them in registers, gemm_rows.hip) -- is read as fp32.
     // The optimizer kernels write planes for this range only
     long wplane_begin() const { return L.enc.empty() ? 0 : L.enc[0].in_w; }
-    long wplane_end() const { return L.enc.empty() ? 0 : L.total; }
+    long wplane_end() const { return L.enc.empty() ? 0 : L.encn_w; }
     // the optimizer just rewrote the arena (and, with planes, the planes with it)
     void params_stepped() {
         const unsigned long long g = bump_params_generation(buf.params);
@@ -526,13 +526,13 @@ struct slnlp_tf_plan {
         a.precision = prec3();
         return gemm(a, st);
     }
-    // the same product for the decoder's B rows: both operands as planes, register-direct (gemm_rows.hip)
+    // the same product for the decoder's B rows: x as planes, W as fp32 (split in registers), both register-direct (gemm_rows.hip)
     int linear_r(const PP& x, int M, int K, long woff, int N, const float* bias, float* y, long ldy, int relu, float p, int site,
                  const float* resid, const PP* outp, hipStream_t st, int drop_head_dim = 0) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
-        a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; a.b_kmajor = 1;
+        a.B = P(woff); a.ldb = K; a.b_kmajor = 1;
         a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
         a.bias = bias; a.relu = relu;
         a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
@@ -550,7 +550,7 @@ struct slnlp_tf_plan {
         memset(&d, 0, sizeof(d));
         memset(&g, 0, sizeof(g));
         d.A_hi = dy.hi; d.A_lo = dy.lo; d.lda_p = Nout; d.a_kmajor = 1;
-        d.B_hi = w.wp.hi + woff; d.B_lo = w.wp.lo + woff; d.ldb_p = Kin; d.b_kmajor = 0;
+        d.B = P(woff); d.ldb = Kin; d.b_kmajor = 0;
         d.C = dx; d.ldc = Kin; d.M = B; d.N = Kin; d.K = Nout;
         d.gate = gate; d.ldg = Kin; d.gate_scale = gate_scale;
         d.resid = resid; d.ldr = Kin;

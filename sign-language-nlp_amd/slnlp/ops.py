@@ -151,9 +151,10 @@ def gemm_planes(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, prec
     return (out, cp) if want_planes else out
 
 
-def gemm_rows(Ap, Bp, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0,
+def gemm_rows(Ap, W, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0,
               drop_site=0, rng=None, drop_head_dim=0, resid=None, want_planes=False):
-    """C = A B^T for a few rows (the decoder's products) over k-major planes Ap = (hi, lo), Bp = (hi, lo): slnlp_gemm_rows."""
+    """C = A W^T for a few rows (the decoder's products): A as k-major planes Ap = (hi, lo), the weight W [N, K] as fp32 (the kernel
+    splits it in registers -- the same bits as split_planes(W)): slnlp_gemm_rows."""
     _lib.require_gpu()
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=Ap[0].device)
@@ -161,7 +162,7 @@ def gemm_rows(Ap, Bp, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate
     a.C, a.ldc, a.M, a.N, a.K = ptr(out), out.stride(0), M, N, K
     a.a_kmajor, a.b_kmajor, a.precision = 1, 1, precision
     a.A_hi, a.A_lo, a.lda_p = ptr(Ap[0]), ptr(Ap[1]), Ap[0].stride(0)
-    a.B_hi, a.B_lo, a.ldb_p = ptr(Bp[0]), ptr(Bp[1]), Bp[0].stride(0)
+    a.B, a.ldb = ptr(W), W.stride(0)
     a.bias, a.relu = ptr(bias), int(relu)
     a.gate, a.ldg, a.gate_scale, a.gate_mode = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale, gate_mode
     a.drop_p, a.drop_site, a.rng, a.drop_head_dim = drop_p, drop_site, ptr(rng), drop_head_dim
@@ -175,10 +176,10 @@ def gemm_rows(Ap, Bp, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate
     return (out, cp) if want_planes else out
 
 
-def gemm_rows_bwd(dYp, Wp, Xp, *, B, Nout, Kin, precision=3, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0, drop_site=0, rng=None,
+def gemm_rows_bwd(dYp, W, Xp, *, B, Nout, Kin, precision=3, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0, drop_site=0, rng=None,
                   drop_head_dim=0, resid=None, want_planes=False, want_db=True):
-    """dX = dY W (+ epilogue), dW = dY^T x, db = colsum(dY) in one launch (slnlp_gemm_rows_bwd): dYp [B, Nout], Wp [Nout, Kin],
-    Xp [B, Kin] as (hi, lo) planes."""
+    """dX = dY W (+ epilogue), dW = dY^T x, db = colsum(dY) in one launch (slnlp_gemm_rows_bwd): dYp [B, Nout] and Xp [B, Kin] as
+    (hi, lo) planes, the weight W [Nout, Kin] as fp32."""
     _lib.require_gpu()
     dev = dYp[0].device
     dX = torch.empty(B, Kin, dtype=torch.float32, device=dev)
@@ -188,7 +189,7 @@ def gemm_rows_bwd(dYp, Wp, Xp, *, B, Nout, Kin, precision=3, gate=None, gate_sca
     d.C, d.ldc, d.M, d.N, d.K = ptr(dX), dX.stride(0), B, Kin, Nout
     d.a_kmajor, d.b_kmajor, d.precision = 1, 0, precision
     d.A_hi, d.A_lo, d.lda_p = ptr(dYp[0]), ptr(dYp[1]), dYp[0].stride(0)
-    d.B_hi, d.B_lo, d.ldb_p = ptr(Wp[0]), ptr(Wp[1]), Wp[0].stride(0)
+    d.B, d.ldb = ptr(W), W.stride(0)
     d.gate, d.ldg, d.gate_scale, d.gate_mode = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale, gate_mode
     d.drop_p, d.drop_site, d.rng, d.drop_head_dim = drop_p, drop_site, ptr(rng), drop_head_dim
     d.resid, d.ldr = ptr(resid), (resid.stride(0) if resid is not None else 0)

@@ -435,10 +435,10 @@ def test_gemm_planes_epilogue_and_output_planes(ops):
 @pytest.mark.parametrize("M,N,K", [(50, 512, 512), (50, 202, 512), (7, 64, 64), (130, 96, 192), (64, 512, 1024), (256, 1024, 512),
                                    (50, 512, 256), (33, 48, 128), (50, 200, 320)])
 def test_gemm_rows_vs_fp64(ops, M, N, K, prec):
-    """The decoder's B-row products on k-major planes, register-direct (gemm_rows.hip): odd / even numbers of 64-k tiles (the two
-    halves of the K sum), a single tile (the second thread group idles), more than one block of 64 rows, N off the 16-column tile."""
+    """The decoder's B-row products, register-direct (gemm_rows.hip; x as k-major planes, the weight as fp32 split in registers):
+    odd / even numbers of 64-k tiles, a single tile (seven waves idle), more than one block of 64 rows, N off the 16-column tile."""
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
-    out = ops.gemm_rows(ops.split_planes(A.cuda()), ops.split_planes(B.cuda()), M=M, N=N, K=K, precision=prec)
+    out = ops.gemm_rows(ops.split_planes(A.cuda()), B.cuda(), M=M, N=N, K=K, precision=prec)
     assert rel(out, A.double() @ B.double().T) < TOL[prec] * max(1.0, math.sqrt(K / 64))
 
 
@@ -452,7 +452,7 @@ def test_gemm_rows_tiles_return_the_same_bits(ops):
         outs = []
         for (M, N, K) in [(50, 512, 512), (50, 202, 512), (7, 64, 64), (130, 96, 192), (64, 512, 1024), (50, 200, 320)]:
             A, B, bias, R = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
-            Ap, Bp = ops.split_planes(A.cuda()), ops.split_planes(B.cuda())
+            Ap, Bp = ops.split_planes(A.cuda()), B.cuda()
             out, (hi, lo) = ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, bias=bias, relu=1, drop_p=0.2, drop_site=4, rng=rng, resid=R, want_planes=True)
             outs += [out.clone(), hi.clone(), lo.clone()]
         torch.cuda.synchronize()
@@ -472,12 +472,12 @@ def test_gemm_rows_tiles_return_the_same_bits(ops):
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("B,Nout,Kin", [(50, 512, 512), (50, 512, 256), (7, 64, 64), (130, 192, 96), (64, 1024, 512), (50, 128, 200)])
 def test_gemm_rows_bwd_vs_fp64(ops, B, Nout, Kin, prec):
-    """dX = dY W, dW = dY^T x, db = column sums of dY in ONE launch (slnlp_gemm_rows_bwd): W and both wgrad operands m-major through
-    the waves' LDS images, at every workgroup tile (same bits), batches over 64 rows (several K tiles in the weight gradient)."""
+    """dX = dY W, dW = dY^T x, db = column sums of dY in ONE launch (slnlp_gemm_rows_bwd): W (fp32) and both wgrad operands (planes)
+    m-major through the waves' LDS images, at every workgroup tile (same bits), batches over 64 rows (several K tiles in the weight gradient)."""
     from slnlp._lib import load, check
     dY, W, X = rnd(B, Nout, seed=1), rnd(Nout, Kin, seed=2), rnd(B, Kin, seed=3)
     pad = lambda x: torch.nn.functional.pad(x, (0, (-x.shape[1]) % 4))
-    dYp, Wp, Xp = ops.split_planes(pad(dY).cuda()), ops.split_planes(pad(W).cuda()), ops.split_planes(pad(X).cuda())
+    dYp, Wp, Xp = ops.split_planes(pad(dY).cuda()), pad(W).cuda(), ops.split_planes(pad(X).cuda())
     res = []
     try:
         for tile in (0, 1, 2):
@@ -499,7 +499,7 @@ def test_gemm_rows_bwd_epilogue(ops):
     """The data gradient's epilogue: ReLU-with-scale gate (the FFN's backward), residual, per-(row, head) dropout, planes out."""
     B, Nout, Kin, dh = 50, 512, 512, 64
     dY, W, X, G, R = rnd(B, Nout, seed=1), rnd(Nout, Kin, seed=2), rnd(B, Kin, seed=3), rnd(B, Kin, seed=4), rnd(B, Kin, seed=5)
-    dYp, Wp, Xp = ops.split_planes(dY.cuda()), ops.split_planes(W.cuda()), ops.split_planes(X.cuda())
+    dYp, Wp, Xp = ops.split_planes(dY.cuda()), W.cuda(), ops.split_planes(X.cuda())
     base = dY.double() @ W.double()
     dX, dW, db, (hi, lo) = ops.gemm_rows_bwd(dYp, Wp, Xp, B=B, Nout=Nout, Kin=Kin, gate=G.cuda(), gate_scale=1.25, resid=R.cuda(), want_planes=True)
     assert rel(dX, base * (G.double() > 0) * 1.25 + R.double()) < 1e-4
@@ -518,7 +518,7 @@ def test_gemm_rows_epilogue_dropout_and_output_planes(ops):
     tanh / ReLU gates, an in-place residual, and the emitted planes equal to the split of the fp32 result."""
     M, N, K, dh = 50, 512, 512, 64
     A, B, bias, R, G = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
-    Ap, Bp = ops.split_planes(A.cuda()), ops.split_planes(B.cuda())
+    Ap, Bp = ops.split_planes(A.cuda()), B.cuda()
     base = A.double() @ B.double().T
     rng = ops.make_rng(seed=1234, step=7)
     p = 0.3
@@ -543,7 +543,7 @@ def test_gemm_rows_epilogue_dropout_and_output_planes(ops):
     ops.gemm_rows(Ap, Bp, M=M, N=N, K=K, out=Cbuf, resid=Cbuf)
     assert rel(Cbuf, base + R.double()) < 1e-4
     # the K sum is two halves of the 64-k tiles, each in tile order: the same bits as two half-K launches added up
-    h1 = ops.gemm_rows((Ap[0][:, :256].contiguous(), Ap[1][:, :256].contiguous()), (Bp[0][:, :256].contiguous(), Bp[1][:, :256].contiguous()),
+    h1 = ops.gemm_rows((Ap[0][:, :256].contiguous(), Ap[1][:, :256].contiguous()), Bp[:, :256].contiguous(),
                        M=M, N=N, K=256)
     # (a half-K launch splits its own 4 tiles 2 + 2, so only the structure is checked here, not bits)
     assert rel(h1, A[:, :256].double() @ B[:, :256].double().T) < 1e-4
