@@ -308,7 +308,7 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
 // both m-major; WAVE w computes the WM 16 x 16 tiles of columns n0 + 16 w.  The WM dY images are staged ONCE per workgroup (the waves
 // share the DMA instructions; one barrier), each wave stages its own x image.  K = the batch rows (one 64-k tile at the headline
 // batch of 50; more tiles: partials added in tile order, as everywhere in this file).  rowsum_a (the bias gradient: sum over the rows
-// of dY[., m]) is written by the first column unit's wave 0, k ascending, hi + lo per row.  WM = 1 for a solo fit's launch (128 units of
+// of dY[., m]) is the same dY fragments times an all-ones fragment, by the first column unit's wave 0.  WM = 1 for a solo fit's launch (128 units of
 // 36 KB for a 512 x 512 gradient), 4 for merged lockstep launches (a quarter of the x-image reads).
 template <int NSPLIT, int WM>
 __device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int unit, unsigned short* smem) {
@@ -320,11 +320,34 @@ __device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int un
     const bool active = n0 < N;                          // (a wave past the last column tile only keeps the barriers company)
     unsigned short* aimg = smem;                          // [WM][hi, lo][64 k][16 m]: the workgroup's
     unsigned short* bimg = smem + WM * 2 * RT_IMG + wave * 2 * RT_IMG;   // [hi, lo][64 k][16 n]: this wave's
-    f32x4 total[WM];
-    float rsum[WM];
+    f32x4 total[WM], rsum[WM];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) { total[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rsum[i] = 0.f; }
-    const bool do_rs = g.rowsum_a != nullptr && un == 0 && wave == 0;
+    for (int i = 0; i < WM; ++i) { total[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rsum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // the bias gradient is one more product of the same dY fragments: dY^T 1 (an all-ones B fragment, exact in bf16), hi and lo -- two
+    // MFMAs per fragment instead of a lane-serial walk over the image (16 lanes x 64 k x WM dependent LDS reads: 17 us of a 20 us unit
+    // at batch 256, r05 timeline).  Every column of the result tile holds the row sums; column 0's lanes store them.
+    const bool do_rs = g.rowsum_a != nullptr && un == 0 && wave == 0;      // (wave-uniform)
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#if SLNLP_PROBE_FENCES == 256
+    // (probe build: entry, first tile's images landed, first tile's MFMAs issued, K loop done, end; bit 31 of the block word = a weight-gradient unit,
+    //  bit 30 = one that also sums the rows of dY)
+    unsigned long long rts[RTS_W] = {0, 0, 0, 0, 0, 0};
+    struct RtsFlushW {
+        unsigned long long* t;
+        unsigned tag;
+        __device__ ~RtsFlushW() {
+            if (threadIdx.x == 0) {
+                t[4] = __builtin_amdgcn_s_memrealtime();
+                t[5] = ((unsigned long long)(gridDim.x * gridDim.y) << 32) | tag | (unsigned)(blockIdx.y * gridDim.x + blockIdx.x);
+                const unsigned i = atomicAdd(&g_rts_n, 1u) & (unsigned)(RTS_MAX - 1);
+                for (int k = 0; k < RTS_W; ++k) g_rts[i][k] = t[k];
+            }
+        }
+    } rts_flush{rts, 0x80000000u | (g.rowsum_a != nullptr && un == 0 ? 0x40000000u : 0u)};
+    RTS_MARK(0);
+#endif
     for (int t = 0; t < ktiles; ++t) {
         if (t) {                                          // every wave is done with the previous tile's images
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -340,6 +363,9 @@ __device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int un
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if SLNLP_PROBE_FENCES == 256
+        if (t == 0) RTS_MARK(1);
+#endif
         if (active) {
             bf16x8 fb[2], lb[2];
 #pragma unroll
@@ -349,7 +375,7 @@ __device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int un
             }
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, rs = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const bf16x8 fa = rows_tr_frag(aimg + (2 * i) * RT_IMG, kk, lane);
@@ -357,22 +383,20 @@ __device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int un
                         const bf16x8 la = rows_tr_frag(aimg + (2 * i + 1) * RT_IMG, kk, lane);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(la, fb[kk], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, lb[kk], acc, 0, 0, 0);
+                        if (do_rs) rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(la, ones, rs, 0, 0, 0);
                     }
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[kk], acc, 0, 0, 0);
+                    if (do_rs) rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, rs, 0, 0, 0);
                 }
                 total[i] = t == 0 ? acc : total[i] + acc;
+                if (do_rs) rsum[i] = t == 0 ? rs : rsum[i] + rs;
             }
         }
-        if (do_rs && lane < 16) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-                for (int k = 0; k < 64; ++k) {
-                    float v = __uint_as_float((unsigned)aimg[(2 * i) * RT_IMG + k * 16 + lane] << 16);
-                    if (NSPLIT == 3) v += __uint_as_float((unsigned)aimg[(2 * i + 1) * RT_IMG + k * 16 + lane] << 16);
-                    rsum[i] += v;
-                }
-        }
+#if SLNLP_PROBE_FENCES == 256
+        if (t == 0) RTS_MARK(2);
+#endif
     }
+    RTS_MARK(3);
     if (!active) return;
     const int gn = n0 + (lane & 15);
 #pragma unroll
@@ -383,7 +407,11 @@ __device__ __forceinline__ void rows_wgrad_unit(const slnlp_gemm_args& g, int un
             for (int r = 0; r < 4; ++r)
                 if (gm0 + r < M) g.C[(long)(gm0 + r) * g.ldc + gn] = total[i][r];
         }
-        if (do_rs && lane < 16 && m0 + 16 * i + lane < M) g.rowsum_a[m0 + 16 * i + lane] = rsum[i];
+        if (do_rs && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gm0 + r < M) g.rowsum_a[gm0 + r] = rsum[i][r];
+        }
     }
 }
 
@@ -464,7 +492,9 @@ static int rows_geo(int M, int N, int K, int fits, bool bwd) {
     for (int geo = 0; geo < RT_NGEO; ++geo) {
         if (!fits_lds(geo)) continue;
         const dim3 gr = rows_grid(geo, M, N);
-        const long units = (long)gr.x * gr.y * fits, rounds = (units + 255) / 256;
+        // (a backward launch also carries the weight gradient's units: dW [K x N] in pieces of 16 mt x 128)
+        const long wunits = bwd ? (long)ceil_div(K, 16 * RT_GEO[geo].mt) * ceil_div(N, 128) : 0;
+        const long units = ((long)gr.x * gr.y + wunits) * fits, rounds = (units + 255) / 256;
         const long cost = rounds * (16L * (RT_GEO[geo].mt + RT_GEO[geo].nt) * K * 4 + 16384);     // (+ a fixed cost per round)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = geo; }
     }

@@ -391,11 +391,17 @@ struct slnlp_tf_plan {
         wplanes_gen = g;
         return 0;
     }
-    // the arena range whose planes have readers: the encoder layers' weights (plane GEMMs).  Everything else -- the embedding tables,
-    // the decoder layers' and the generator's weights (the B-row products split them in registers, gemm_rows.hip) -- is read as fp32.
-    // The optimizer kernels write planes for this range only
+    // the arena range whose planes have readers: the encoder layers' weights (plane GEMMs) and, for plans whose batches are too tall
+    // for the B-row kernel (rows_for), the decoder's and the generator's.  Everything else -- the embedding tables, the decoder's weights
+    // in a plan of B-row products (gemm_rows.hip splits them in registers) -- is read as fp32.  The optimizer kernels write planes for
+    // this range only
     long wplane_begin() const { return L.enc.empty() ? 0 : L.enc[0].in_w; }
-    long wplane_end() const { return L.enc.empty() ? 0 : L.encn_w; }
+    long wplane_end() const { return L.enc.empty() ? 0 : (use_rows && cfg.B <= ROWS_MAX_B ? L.encn_w : L.total); }
+    // The decoder's products of B rows: the B-row kernel up to one block of 64 rows (a launch lasts as long as one workgroup loads; 16 x 16
+    // tiles), the plane GEMM above (configs[4], B = 256, E = 1024: 15 us per gradient pair against 22 -- 47 before the bias gradient
+    // became an MFMA product -- and 11 against 13 forward; tools/bench_rows_shapes.py)
+    static constexpr int ROWS_MAX_B = 64;
+    bool rows_for(int B, int drop_head_dim) const { return B <= ROWS_MAX_B || drop_head_dim != 0; }   // (per-head dropout is not built into the plane GEMM)
     // the optimizer just rewrote the arena (and, with planes, the planes with it)
     void params_stepped() {
         const unsigned long long g = bump_params_generation(buf.params);
@@ -532,7 +538,10 @@ struct slnlp_tf_plan {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
-        a.B = P(woff); a.ldb = K; a.b_kmajor = 1;
+        const bool rows = rows_for(M, drop_head_dim);
+        if (rows) { a.B = P(woff); a.ldb = K; }
+        else { a.B_hi = w.wp.hi + woff; a.B_lo = w.wp.lo + woff; a.ldb_p = K; }
+        a.b_kmajor = 1;
         a.C = y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
         a.bias = bias; a.relu = relu;
         a.drop_p = p; a.drop_site = site; a.rng = buf.rng;
@@ -540,12 +549,15 @@ struct slnlp_tf_plan {
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
         a.precision = prec3();
         a.drop_head_dim = drop_head_dim;
-        return gemm_rows(a, st);
+        return rows ? gemm_rows(a, st) : gemm(a, st);
     }
     // the backward pair of a decoder Linear y[B, Nout] = x[B, Kin] W^T + b in ONE launch (gemm_rows.hip: gemm_rows_bwd): dX = dY W with
     // its epilogue (gate, per-head dropout, residual; fp32 and / or planes out) and dW = dY^T x, db = colsum(dY)
     int wd_rows(const PP& dy, int B, int Nout, long woff, int Kin, float* dx, const PP* dxp, const float* gate, float gate_scale,
                 const float* resid, const PP& x, long gw, long gb, hipStream_t st, float drop_p = 0.f, int drop_site = 0, int drop_head_dim = 0) const {
+        if (!rows_for(B, drop_head_dim))       // the plane GEMM's gradient pair, as in the encoder
+            return wd_group(wgrad_p_args(dy, Nout, B, Nout, x, Kin, G(gw), G(gb)),
+                            dgrad_p_args(dy, Nout, B, Nout, woff, Kin, dx, gate, gate_scale, resid, dxp), 0, st);
         slnlp_gemm_args d, g;
         memset(&d, 0, sizeof(d));
         memset(&g, 0, sizeof(g));

@@ -35,17 +35,32 @@ def evict():
 
 def report(name, launch):
     for _ in range(20): launch()
-    torch.cuda.synchronize(); read()
-    launch(); warm = read()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): launch()
+    e1.record(); torch.cuda.synchronize()
+    b2b = e0.elapsed_time(e1) / 50 * 1e3
+    read()
+    e0.record(); launch(); e1.record(); torch.cuda.synchronize()
+    print(f"{name:44s} events: {b2b:6.2f} us per launch back to back, {e0.elapsed_time(e1) * 1e3:6.2f} us one launch alone")
+    warm = read()
     cold = []
     for _ in range(8):
         evict(); read(); launch(); cold.append(read())
     cold = np.concatenate(cold)
-    for tag, t in (("warm", warm), ("cold", cold)):
+    groups = []
+    for tag, t in (("warm", warm), ("cold", cold)):       # (backward pairs: the weight-gradient units stamp with bit 31 of the block word, bit 30 = + row sums)
+        kind = (t[:, 5] >> 30) & 3
+        groups.append((tag, t[kind == 0]))
+        if (kind != 0).any():
+            groups += [(tag + " wgrad", t[kind == 2]), (tag + " wgrad+rowsum", t[kind == 3])]
+    for tag, t in groups:
+        if not len(t): continue
         us = lambda a: a / 100.0
         ph = [us(t[:, i + 1] - t[:, i]) for i in range(4)]
         q = lambda a: "%5.2f %5.2f %5.2f" % tuple(np.percentile(a, [10, 50, 90]))
-        span = us(t[:, 4].max() - t[:, 0].min()) if tag == "warm" else float("nan")
+        span = us(t[:, 4].max() - t[:, 0].min()) if tag.startswith("warm") else float("nan")
         print(f"{name:44s} {tag}: {len(t):4d} wg | entry->first tile {q(ph[0])} | K loop {q(ph[1])} | reduce+image {q(ph[2])} | epilogue {q(ph[3])} | "
               f"total {q(us(t[:, 4] - t[:, 0]))} | span {span:5.2f}", flush=True)
 
@@ -70,3 +85,14 @@ xp, Wp, W3p = ops.split_planes(x), W, W3        # (the weight goes in as fp32: t
 report("rows linear [50x512]x[512x512] bias",       lambda: ops.gemm_rows(xp, Wp, M=B, N=E, K=E, bias=bias, out=out))
 report("rows linear ... + dropout + residual",      lambda: ops.gemm_rows(xp, Wp, M=B, N=E, K=E, bias=bias, drop_p=0.1, drop_site=3, rng=rng, resid=R, out=out))
 report("rows linear [50x512]x[512x1536]",           lambda: ops.gemm_rows(xp, W3p, M=B, N=3 * E, K=E, out=out3))
+# the backward pair (data-gradient tiles; weight-gradient units: entry -> images landed -> first tile's MFMAs -> K loop + row sums -> end) and
+# the configs[4] decoder shape, at each workgroup tile
+dYp = ops.split_planes(rnd(B, E))
+report("rows bwd pair [50x512]",                    lambda: ops.gemm_rows_bwd(dYp, W, xp, B=B, Nout=E, Kin=E))
+B5, E5 = 256, 1024
+x5p, dY5p, W5, out5 = ops.split_planes(rnd(B5, E5)), ops.split_planes(rnd(B5, E5)), rnd(E5, E5), torch.empty(B5, E5, device="cuda")
+for tile in (0, 1):
+    lib.slnlp_set_rows_tile(tile)
+    report(f"rows linear [256x1024]x[1024x1024] tile {tile}", lambda: ops.gemm_rows(x5p, W5, M=B5, N=E5, K=E5, out=out5))
+    report(f"rows bwd pair [256x1024] tile {tile}",         lambda: ops.gemm_rows_bwd(dY5p, W5, x5p, B=B5, Nout=E5, Kin=E5))
+lib.slnlp_set_rows_tile(-1)
