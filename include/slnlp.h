@@ -220,7 +220,7 @@ int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, i
  * drop_site for the sub-layer branch; partial [nblk,2,E] per-block partial
  * (dgamma, dbeta) sums, reduced later by slnlp_ln_param_reduce. nblk is
  * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS). */
-#define SLNLP_LN_MAX_PARTIALS 256
+#define SLNLP_LN_MAX_PARTIALS 1024
 int slnlp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
                         int rows, int E, const float* add_to_dx, float* dx, float* dx_drop,
                         float drop_p, int drop_site, const unsigned long long* rng,

@@ -313,9 +313,10 @@ int xmem_bwd(const float* mem, const float* bv, const float* probs, const float*
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, int rows, int E, float eps, float* y,
                   float* stats, hipStream_t st, PlaneOut po = {});
 int ln_bwd_blocks(int rows);
+bool ln_bwd_fused(int full_rows);     // the row kernel of a batch this tall also sums (dgamma, dbeta) per chunk (elementwise.hip)
 int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
                   const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
-                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st,
+                  const unsigned long long* rng, float* partial, int* nblk_out, int full_rows, hipStream_t st,
                   PlaneOut po_dx = {}, PlaneOut po_drop = {});
 int attn_init();
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st);

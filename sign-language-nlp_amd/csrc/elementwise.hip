@@ -377,26 +377,42 @@ SLNLP_ZKERNEL(layernorm_fwd_kernel, 256, layernorm_fwd_body)
 //
 // U = float4 slots per lane (E <= 256 * U), GS = rows per wave (4: many rows; 1: the decoder's B rows, spread over as many waves as
 // possible), RB = rows whose loads are in flight together (U * RB <= 8: every instance stays under 256 registers).
-template <int U, int GS, int RB>
+//
+// FUSE (round 5): a workgroup of four waves takes a CHUNK of `chunk_rows` rows (16 for batches of >= 1024 rows, ln_partial_chunk),
+// a group of GS rows per wave as before (more groups: wave w takes groups w, w + 4, ...), every wave keeps the (dgamma, dbeta) column
+// sums of its rows in registers (rows ascending), and the four waves' sums meet in LDS and are added in wave order:
+// partial[chunk][0][c] = sum dy xhat, partial[chunk][1][c] = sum dy -- instead of ln_param_partial reading dy and x a second time at
+// the end of backward (15 fits in lockstep: 2.5 GB, 380 us of a 14.7 ms step; configs[4]: 350 us of 13.7 ms), for a twelfth of those
+// bytes in partial sums written and read back.  (One wave walking the chunk's four groups one after the other was 2 x slower per
+// launch at every size -- a wave has one group's loads in flight: configs[1] +6 %.)
+template <int U, int GS, int RB, bool FUSE>
 __device__ __forceinline__ void layernorm_bwd_rows(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx, float* __restrict__ dx,
     float* __restrict__ dx_drop, float drop_p, unsigned drop_thr, int drop_site,
-    const unsigned long long* __restrict__ rng, PlaneOut po_dx, PlaneOut po_drop) {
+    const unsigned long long* __restrict__ rng, PlaneOut po_dx, PlaneOut po_drop, float* __restrict__ partial, int chunk_rows, int nchunks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invE = 1.f / (float)E, ik = 1.f / (1.f - drop_p);
     // the dropout-masked copy goes out as fp32 (dx_drop), as bf16 planes (po_drop), or both: a caller whose consumers read planes
     // only (the plane-GEMM path) passes dx_drop = nullptr and saves the fp32 store
     const bool want_drop = dx_drop != nullptr || po_drop.hi != nullptr;
     const bool drop = want_drop && drop_p > 0.f;
-    const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * GS;   // one group per wave: the launch covers ceil(rows / GS) waves
-    if (row0 >= rows) return;
+    const int unit = FUSE ? (int)blockIdx.x : blockIdx.x * (int)(blockDim.x >> 6) + wave;   // a chunk per workgroup / a group per wave
+    float4 ag[U], ab[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ag[u] = ab[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row_begin = FUSE ? unit * chunk_rows + wave * GS : unit * GS;
+    const int row_end = FUSE ? ((unit + 1) * chunk_rows < rows ? (unit + 1) * chunk_rows : rows) : row_begin + GS;
+    const int row_step = FUSE ? 4 * GS : GS;
+    if (!FUSE && row_begin >= rows) return;
     DropKey dkey = {};
     if (drop) dkey = dropout_key(rng, drop_site);
     float4 g[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (lane * 4 + u * 256 < E) g[u] = *reinterpret_cast<const float4*>(gamma + lane * 4 + u * 256);
+#pragma unroll 1
+    for (int row0 = row_begin; row0 < row_end; row0 += row_step)      // (a chunk past the batch's last row: no trip, zero sums -- the reduce table is the full batch's)
 #pragma unroll
     for (int i0 = 0; i0 < GS; i0 += RB) {
         float4 d[RB][U], v[RB][U];
@@ -453,6 +469,10 @@ __device__ __forceinline__ void layernorm_bwd_rows(
                 const float4 dd = d[i][u], vv = v[i][u];
                 const float4 xh = make_float4((vv.x - mean[i]) * rstd[i], (vv.y - mean[i]) * rstd[i], (vv.z - mean[i]) * rstd[i], (vv.w - mean[i]) * rstd[i]);
                 const float4 gv = make_float4(dd.x * g[u].x, dd.y * g[u].y, dd.z * g[u].z, dd.w * g[u].w);
+                if (FUSE) {
+                    ag[u].x += dd.x * xh.x; ag[u].y += dd.y * xh.y; ag[u].z += dd.z * xh.z; ag[u].w += dd.w * xh.w;
+                    ab[u].x += dd.x; ab[u].y += dd.y; ab[u].z += dd.z; ab[u].w += dd.w;
+                }
                 float4 o;
                 o.x = rstd[i] * (gv.x - s1[i] - xh.x * s2[i]); o.y = rstd[i] * (gv.y - s1[i] - xh.y * s2[i]);
                 o.z = rstd[i] * (gv.z - s1[i] - xh.z * s2[i]); o.w = rstd[i] * (gv.w - s1[i] - xh.w * s2[i]);
@@ -475,24 +495,51 @@ __device__ __forceinline__ void layernorm_bwd_rows(
             }
         }
     }
+    if (FUSE) {
+        __shared__ float4 red[4][2][U * 64];             // [wave][dgamma, dbeta][column slot]
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            red[wave][0][u * 64 + lane] = ag[u];
+            red[wave][1][u * 64 + lane] = ab[u];
+        }
+        __syncthreads();
+        // thread t adds the four waves' sums of one (which, slot) pair, in wave order
+        for (int q = threadIdx.x; q < 2 * U * 64; q += 256) {
+            const int which = q / (U * 64), slot = q - which * (U * 64), c = (slot & 63) * 4 + (slot >> 6) * 256;
+            if (c >= E) continue;
+            float4 t = red[0][which][slot];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float4 o = red[k][which][slot];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            *reinterpret_cast<float4*>(partial + ((long)unit * 2 + which) * E + c) = t;
+        }
+    }
 }
 
 // one kernel per (row-length class, rows per wave): a kernel's register allocation is the maximum over its branches
-#define SLNLP_LN_BWD_BODY(name, U, GS, RB)                                                                                          \
+#define SLNLP_LN_BWD_BODY(name, U, GS, RB, FUSE)                                                                                    \
     __device__ __forceinline__ void name(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma, \
                                          const float* __restrict__ stats, int rows, int E, const float* __restrict__ add_to_dx,     \
                                          float* __restrict__ dx, float* __restrict__ dx_drop, float drop_p, unsigned drop_thr,       \
                                          int drop_site, const unsigned long long* __restrict__ rng, PlaneOut po_dx,                  \
-                                         PlaneOut po_drop) {                                                                         \
-        layernorm_bwd_rows<U, GS, RB>(dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, drop_thr, drop_site, rng,       \
-                                      po_dx, po_drop);                                                                              \
+                                         PlaneOut po_drop, float* __restrict__ partial, int chunk_rows, int nchunks) {               \
+        layernorm_bwd_rows<U, GS, RB, FUSE>(dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, drop_thr, drop_site, rng, \
+                                            po_dx, po_drop, partial, chunk_rows, nchunks);                                          \
     }
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g4, 1, 4, 4)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g4, 2, 4, 4)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g4, 4, 4, 2)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g1, 1, 1, 1)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g1, 2, 1, 1)
-SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g1, 4, 1, 1)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g4, 1, 4, 4, false)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g4, 2, 4, 4, false)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g4, 4, 4, 2, false)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g1, 1, 1, 1, false)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g1, 2, 1, 1, false)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g1, 4, 1, 1, false)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u1g4f, 1, 4, 4, true)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u2g4f, 2, 4, 4, true)
+SLNLP_LN_BWD_BODY(layernorm_bwd_body_u4g4f, 4, 4, 2, true)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u1g4f, 256, layernorm_bwd_body_u1g4f)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u2g4f, 256, layernorm_bwd_body_u2g4f)
+SLNLP_ZKERNEL(layernorm_bwd_kernel_u4g4f, 256, layernorm_bwd_body_u4g4f)
 SLNLP_ZKERNEL(layernorm_bwd_kernel_u1g4, 256, layernorm_bwd_body_u1g4)
 SLNLP_ZKERNEL(layernorm_bwd_kernel_u2g4, 256, layernorm_bwd_body_u2g4)
 SLNLP_ZKERNEL(layernorm_bwd_kernel_u4g4, 256, layernorm_bwd_body_u4g4)
@@ -587,9 +634,12 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, int row
 
 static int ln_bwd_group(int rows) { return rows >= 1024 ? 4 : 1; }   // rows per wave
 
-// rows per chunk of the (dgamma, dbeta) partial sums: 64, more when that would exceed SLNLP_LN_MAX_PARTIALS chunks
+// (dgamma, dbeta) sums inside the row kernel (FUSE) for batches of many rows; the few rows of a decoder batch keep one wave per row
+// and the separate column-sum launch
+bool ln_bwd_fused(int full_rows) { return ln_bwd_group(full_rows) == 4; }
+// rows per chunk of the (dgamma, dbeta) partial sums: 16 (fused class) / 64, more when that would exceed SLNLP_LN_MAX_PARTIALS chunks
 int ln_partial_chunk(int rows) {
-    int c = 64;
+    int c = ln_bwd_fused(rows) ? 16 : 64;
     while (ceil_div(rows, c) > SLNLP_LN_MAX_PARTIALS) c *= 2;
     return c;
 }
@@ -602,10 +652,13 @@ int ln_param_partial(const LnPartialEntry* table_dev, const LnPartialEntry* sing
     LnPartialEntry single;
     memset(&single, 0, sizeof(single));
     if (single_host) single = *single_host;
-    // chunk sizes (and so the chunk count every entry writes) follow the FULL batch: smaller batches leave zero chunks
+    // chunk sizes (and so the chunk count every entry writes) follow the FULL batch: smaller batches leave zero chunks.  Encoder
+    // entries of a fused-class batch were summed by their row kernels (layernorm_bwd with a partial pointer): no chunk of theirs here
     const int ce = ln_partial_chunk(full_rows_enc > 0 ? full_rows_enc : 1), cd = ln_partial_chunk(full_rows_dec > 0 ? full_rows_dec : 1);
-    const int ne = full_rows_enc > 0 ? ceil_div(full_rows_enc, ce) : 0, nd = full_rows_dec > 0 ? ceil_div(full_rows_dec, cd) : 0;
+    const int ne = full_rows_enc > 0 && !(table_dev && ln_bwd_fused(full_rows_enc)) ? ceil_div(full_rows_enc, ce) : 0;
+    const int nd = full_rows_dec > 0 ? ceil_div(full_rows_dec, cd) : 0;
     const int nb = std::max(ne, nd);
+    if (nb == 0) return 0;
     const int threads = (ceil_div(E, 4) + 63) / 64 * 64;
     return zlaunch(ln_param_partial_kernel, dim3(nb, n), threads, 0, st, "ln_param_partial", table_dev, single, E,
                    rows_enc, rows_dec, ce, cd, ne, nd);
@@ -613,27 +666,39 @@ int ln_param_partial(const LnPartialEntry* table_dev, const LnPartialEntry* sing
 
 int layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int E,
                   const float* add_to_dx, float* dx, float* dx_drop, float drop_p, int drop_site,
-                  const unsigned long long* rng, float* partial, int* nblk_out, int nblk_force, hipStream_t st,
+                  const unsigned long long* rng, float* partial, int* nblk_out, int full_rows, hipStream_t st,
                   PlaneOut po_dx, PlaneOut po_drop) {
     SLNLP_CHECK_ARG(dy && x && gamma && stats && dx, "layernorm_bwd: null pointer");
     SLNLP_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= LN_MAXU * 256, "layernorm_bwd: need E %% 4 == 0 and E <= %d, got %d", LN_MAXU * 256, E);
     SLNLP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), "layernorm_bwd: bad dropout args");
-    (void)nblk_force;
-    const int gs = ln_bwd_group(rows), u = E <= 256 ? 1 : E <= 512 ? 2 : 4;
+    // full_rows: the rows of the caller's FULL batch (0: this call's) -- the chunk geometry of the (dgamma, dbeta) sums follows it, so
+    // that a shorter last batch writes the same number of chunks (the trailing ones zero) and the reduce table never changes
+    if (full_rows < rows) full_rows = rows;
+    const int u = E <= 256 ? 1 : E <= 512 ? 2 : 4;
+    if (partial && ln_bwd_fused(full_rows)) {     // one wave per chunk: dx and the chunk's column sums in one pass over dy and x
+        const int cr = ln_partial_chunk(full_rows), nchunks = ceil_div(full_rows, cr);
+        auto kern = u == 1 ? layernorm_bwd_kernel_u1g4f : u == 2 ? layernorm_bwd_kernel_u2g4f : layernorm_bwd_kernel_u4g4f;
+        SLNLP_TRY(zlaunch(kern, dim3(nchunks), 256, 0, st, "layernorm_bwd (fused)", dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p,
+                          dropout_threshold(drop_p), drop_site, rng, po_dx, po_drop, partial, cr, nchunks));
+        if (nblk_out) *nblk_out = nchunks;
+        return 0;
+    }
+    const int gs = ln_bwd_group(rows);
     auto kern = gs == 4 ? (u == 1 ? layernorm_bwd_kernel_u1g4 : u == 2 ? layernorm_bwd_kernel_u2g4 : layernorm_bwd_kernel_u4g4)
                         : (u == 1 ? layernorm_bwd_kernel_u1g1 : u == 2 ? layernorm_bwd_kernel_u2g1 : layernorm_bwd_kernel_u4g1);
     // 4-row groups: ONE wave per workgroup -- 2400 rows are 600 waves, which 150 workgroups of four would park on 150 of the 256
     // CUs; single-wave workgroups spread over all of them (the kernel is a stream of 16-byte loads and stores per wave)
     const int wpb = gs == 4 ? 1 : 4;
     SLNLP_TRY(zlaunch(kern, dim3(ceil_div(rows, wpb * gs)), 64 * wpb, 0, st, "layernorm_bwd",
-                      dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, po_dx, po_drop));
+                      dy, x, gamma, stats, rows, E, add_to_dx, dx, dx_drop, drop_p, dropout_threshold(drop_p), drop_site, rng, po_dx, po_drop,
+                      (float*)nullptr, 0, 0));
     // partial != nullptr: also this LayerNorm's (dgamma, dbeta) chunk sums, for callers that reduce one LayerNorm at a time
     // (the C API, tests); a plan passes nullptr and runs ONE table-driven ln_param_partial launch for all its LayerNorms
-    if (nblk_out) *nblk_out = ln_bwd_blocks(rows);
+    if (nblk_out) *nblk_out = ln_bwd_blocks(full_rows);
     if (!partial) return 0;
     LnPartialEntry e;
     e.dy = dy; e.x = x; e.stats = stats; e.partial = partial; e.dec = 0; e.pad = 0;
-    return ln_param_partial(nullptr, &e, 1, E, rows, 0, rows, 0, st);
+    return ln_param_partial(nullptr, &e, 1, E, rows, 0, full_rows, 0, st);
 }
 
 int ln_param_reduce(const slnlp_ln_reduce_entry* table_dev, int n, int max_E, hipStream_t st) {

@@ -397,8 +397,11 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
     SLNLP_TRY(embed_bwd(y, 1, B, 1, E, c.Vt, dt, pl->G(L.tgt_emb), sqrtf((float)E), -1, p, SITE_TGT_EMB, rng, w.emb_scratch_tgt, st));
 
     // encoder: needs the complete d memory
+    // (a tall batch: the encoder's LayerNorm backward kernels also write their (dgamma, dbeta) chunk sums, elementwise.hip)
+    const int Mfull = c.B * c.S;
+    const bool lnf = ln_bwd_fused(Mfull);
     SLNLP_TRY(layernorm_bwd(w.gmem, w.enc[c.N - 1].x2, pl->P(L.encn_w), w.st_mem, M, E, nullptr, w.gxl, nullptr, 0.f, 0,
-                            rng, nullptr, nullptr, 0, st));
+                            rng, lnf ? w.lnp_mem : nullptr, nullptr, Mfull, st));
     const float* dx = w.gxl;
     for (int l = c.N - 1; l >= 0; --l) {
         const EncP& q = L.enc[l];
@@ -411,7 +414,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
         // (plane path: the sub-layer's GEMMs read the planes only, so neither the masked fp32 copy nor the fp32 ReLU-gated
         //  gradient of the FFN hidden layer is stored)
         SLNLP_TRY(layernorm_bwd(dx, a.y2, pl->P(q.n2_w), a.st2, M, E, nullptr, a.gA2, (p > 0.f && !up) ? a.gB2 : nullptr, p,
-                                pl->enc_site(l, 3), rng, nullptr, nullptr, 0, st, (up && p == 0.f) ? a.d2p.out() : none,
+                                pl->enc_site(l, 3), rng, lnf ? a.lnp2 : nullptr, nullptr, Mfull, st, (up && p == 0.f) ? a.d2p.out() : none,
                                 (up && p > 0.f) ? a.d2p.out() : none));
         const float* d2 = p > 0.f ? a.gB2 : a.gA2;
         if (up) {
@@ -426,7 +429,7 @@ int slnlp_tf_backward(slnlp_tf_plan* pl, void* stream) {
                                      pl->dgrad_args(a.gh, F, M, F, pl->P(q.l1_w), E, a.gx1, nullptr, 0.f, a.gA2), st));
         }
         SLNLP_TRY(layernorm_bwd(a.gx1, a.y1, pl->P(q.n1_w), a.st1, M, E, nullptr, a.gA1, (p > 0.f && !up) ? a.gB1 : nullptr, p,
-                                pl->enc_site(l, 1), rng, nullptr, nullptr, 0, st, (up && p == 0.f) ? a.d1p.out() : none,
+                                pl->enc_site(l, 1), rng, lnf ? a.lnp1 : nullptr, nullptr, Mfull, st, (up && p == 0.f) ? a.d1p.out() : none,
                                 (up && p > 0.f) ? a.d1p.out() : none));
         const float* d1 = p > 0.f ? a.gB1 : a.gA1;
         if (up) {

@@ -192,7 +192,8 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     Ws w;
     Bump b(base);
     const size_t B = c.B, S = c.S, E = c.E, F = c.F, H = c.H, M = B * S, Vp = align_up(c.Vt, 4);
-    const size_t lnp = (size_t)SLNLP_LN_MAX_PARTIALS * 2 * E;
+    // (dgamma, dbeta) chunk sums per LayerNorm: [chunks of the full batch][2][E] (encoder: S B rows, decoder: B rows)
+    const size_t lnpE = (size_t)ln_bwd_blocks((int)(B * S)) * 2 * E, lnpD = (size_t)ln_bwd_blocks((int)B) * 2 * E;
     // plane path with single-tile attention (E, F multiples of 64, S <= 64): the attention context, d qkv, the gated FFN gradient and the
     // dropout-masked LayerNorm gradients exist as bf16 planes only -- their fp32 twins have no writer and no reader and are not carved
     // (34 MB per layer at cfg2; the debug layout omits them)
@@ -212,8 +213,8 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.y2 = b.take<float>(M * E);
         a.st2 = b.take<float>(M * 2);
         a.x2 = b.take<float>(M * E);
-        a.lnp1 = b.take<float>(lnp);
-        a.lnp2 = b.take<float>(lnp);
+        a.lnp1 = b.take<float>(lnpE);
+        a.lnp2 = b.take<float>(lnpE);
         a.gA2 = b.take<float>(M * E);
         a.gB2 = opt(M * E);
         a.gh = opt(M * F);
@@ -227,7 +228,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     }
     w.mem = b.take<float>(M * E);
     w.st_mem = b.take<float>(M * 2);
-    w.lnp_mem = b.take<float>(lnp);
+    w.lnp_mem = b.take<float>(lnpE);
     for (int i = 0; i < c.N; ++i) {
         DecA a;
         a.v = b.take<float>(B * E);
@@ -247,9 +248,9 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
         a.y3 = b.take<float>(B * E);
         a.st3 = b.take<float>(B * 2);
         a.t3 = b.take<float>(B * E);
-        a.lnp1 = b.take<float>(lnp);
-        a.lnp2 = b.take<float>(lnp);
-        a.lnp3 = b.take<float>(lnp);
+        a.lnp1 = b.take<float>(lnpD);
+        a.lnp2 = b.take<float>(lnpD);
+        a.lnp3 = b.take<float>(lnpD);
         a.gA3 = b.take<float>(B * E);
         a.gB3 = b.take<float>(B * E);
         a.gh = b.take<float>(B * F);
@@ -271,7 +272,7 @@ static Ws carve(const slnlp_tf_config& c, void* base) {
     }
     w.tfin = b.take<float>(B * E);
     w.st_fin = b.take<float>(B * 2);
-    w.lnp_fin = b.take<float>(lnp);
+    w.lnp_fin = b.take<float>(lnpD);
     w.logits = b.take<float>(B * Vp);
     w.dlogits = b.take<float>(B * Vp);
     w.logp = b.take<float>(B * c.Vt);

@@ -282,7 +282,7 @@ def layernorm_bwd(dy, x, gamma, stats, *, add_to_dx=None, want_drop=False, drop_
     rows, E = x.shape
     dx = torch.empty_like(x)
     dxd = torch.empty_like(x) if want_drop else None
-    partial = torch.empty(256, 2, E, dtype=torch.float32, device=x.device)
+    partial = torch.empty(1024, 2, E, dtype=torch.float32, device=x.device)     # SLNLP_LN_MAX_PARTIALS chunks
     nblk = C.c_int32(0)
     check(load().slnlp_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(stats), rows, E, ptr(add_to_dx), ptr(dx),
                                      ptr(dxd), drop_p, drop_site, ptr(rng), ptr(partial), C.byref(nblk),

@@ -218,7 +218,7 @@ def test_attn_cross(ops, B, S, H, dh, p):
     assert rel(dkv, kv.grad) < 5e-5
 
 
-@pytest.mark.parametrize("rows,E", [(2400, 512), (50, 128), (4, 32), (2400, 1024), (257, 260)])
+@pytest.mark.parametrize("rows,E", [(2400, 512), (50, 128), (4, 32), (2400, 1024), (257, 260), (3203, 512), (16384, 1024), (1030, 200)])
 def test_layernorm(ops, rows, E):
     x = rnd(rows, E, seed=1, scale=3.0).double().requires_grad_(True)
     g = (1 + 0.1 * rnd(E, seed=2)).double().requires_grad_(True)
