@@ -272,7 +272,7 @@ int gemm_rows_bwd(const slnlp_gemm_args& dgrad, const slnlp_gemm_args& wgrad, hi
 int gemm_planes_init();
 // up to 4 independent plane GEMMs in ONE launch, optional deterministic split-K per job (gemm_planes.hip)
 int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs, void* scratch, size_t scratch_bytes,
-                      hipStream_t s);
+                      hipStream_t s, bool defer_reduce = false);   // defer_reduce: a lone split-K job's slices meet in a second launch
 size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k, int njobs);
 // the gradient pair of one dY over plane operands: dW = dY^T x (split-K) and dX = dY W -- one grouped launch, or a launch each when
 // both are large (gemm_planes.hip: gemm_planes_wd_plan holds the rule; split <= WD_MAX_SPLITK)

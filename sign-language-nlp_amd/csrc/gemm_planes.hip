@@ -409,6 +409,7 @@ __device__ __forceinline__ void plane_tile(const PlaneJob& job, int lid, bool pl
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), mine, tid * 16, (i * NT + j) * PTHREADS * 16, SC);
         if (do_rowsum && tid < BM)
             __hip_atomic_store(job.part_rs + ((long)by * nks + ks) * BM + tid, rs_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (job.hand_off == 4) return;                       // the K-slices meet in plane_splitk_reduce_kernel, the next launch on the stream
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -872,6 +873,56 @@ struct Q8GeoInfo { int bm, bn, nst; };
 constexpr int NQGEO = 2;
 constexpr Q8GeoInfo QGEO[NQGEO] = {{64, 64, 4}, {128, 128, 2}};
 
+// ---- the K-slices of a LARGE weight gradient meet in a launch of their own.  Inside the GEMM launch the last workgroup to arrive
+// adds a tile's nks partials and stores it -- 48 workgroups (configs[4] in_proj: 48 tiles of 256 x 256, 5 slices) each pulling 1.25 MB
+// through one CU and writing 256 KB while the other 208 CUs are done: 19.5 us of meeting + 19.3 us of epilogue behind a 142 us K
+// loop (r05 timeline, `PROBE_PAIR=1 tools/probes/probe_tile_timeline.py`).  When that job has a launch to itself (slnlp_gemm_wd, both
+// gradients large) its workgroups only write their partial tiles (hand_off 4) and this kernel adds them, slice order, from zero --
+// the same sums, bit for bit -- on every CU: one (tile, 16 x 16-per-wave slab) per workgroup, all slices' loads in flight at once.
+template <int G>
+__global__ __launch_bounds__(PTHREADS) void plane_splitk_reduce_kernel(const PlaneJob job_in) {
+    constexpr int BM = GEO[G].bm, BN = GEO[G].bn, MT = BM / 64, NT = BN / 32, TILE_FLOATS = BM * BN, SC = 17;
+    PlaneJob job = job_in;
+    launder(job.a);
+    const slnlp_gemm_args& g = job.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x / (MT * NT), slab = blockIdx.x - tile * (MT * NT), i = slab / NT, j = slab - i * NT;
+    const int by = tile / job.tiles_x, bx = tile - by * job.tiles_x, nks = job.nks;
+    const int wm0 = (wave >> 1) * (BM / 4), wn0 = (wave & 1) * (BN / 2);
+    u32x4 p[WD_MAX_SPLITK];
+#pragma unroll
+    for (int s = 0; s < WD_MAX_SPLITK; ++s) {
+        if (s < nks) {
+            const __amdgpu_buffer_rsrc_t q =
+                __builtin_amdgcn_make_buffer_rsrc(job.part + ((long)tile * nks + s) * TILE_FLOATS, 0, TILE_FLOATS * 4, 0x00020000);
+            p[s] = __builtin_amdgcn_raw_buffer_load_b128(q, tid * 16, slab * PTHREADS * 16, SC);
+        }
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < WD_MAX_SPLITK; ++s)
+        if (s < nks) acc += __builtin_bit_cast(f32x4, p[s]);
+    const int gm0 = by * BM + wm0 + 16 * i + ((lane >> 4) << 2), gn = bx * BN + wn0 + 16 * j + (lane & 15);
+    if (gn < g.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (gm0 + r < g.M) g.C[(long)(gm0 + r) * g.ldc + gn] = acc[r];
+    }
+    if (g.rowsum_a && bx == 0 && slab == 0 && tid < BM) {      // the bias gradient's slices (first column tile's workgroups wrote them)
+        float rs_row = 0.f;
+        for (int s = 0; s < nks; ++s) rs_row += __hip_atomic_load(job.part_rs + ((long)by * nks + s) * BM + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (by * BM + tid < g.M) g.rowsum_a[by * BM + tid] = rs_row;
+    }
+}
+static const void* splitk_reduce_kernel_ptr(int geo) {
+    switch (geo) {
+        case 0: return (const void*)plane_splitk_reduce_kernel<0>;
+        case 1: return (const void*)plane_splitk_reduce_kernel<1>;
+        case 2: return (const void*)plane_splitk_reduce_kernel<2>;
+        default: return (const void*)plane_splitk_reduce_kernel<3>;
+    }
+}
+
 template <int G>
 __global__ __launch_bounds__(PTHREADS) void gemm_q8_kernel(const PlaneGroupParams P, const PlaneJob* __restrict__ tab,
                                                            const int* __restrict__ blockmap) {
@@ -1040,7 +1091,7 @@ size_t gemm_group_scratch_bytes(const slnlp_gemm_args* jobs, const int* split_k,
 }
 
 int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs, void* scratch, size_t scratch_bytes,
-                      hipStream_t s) {
+                      hipStream_t s, bool defer_reduce) {
     SLNLP_CHECK_ARG(jobs && njobs >= 1 && njobs <= MAX_JOBS, "gemm_group: 1..%d jobs", MAX_JOBS);
     PlaneGroupParams P;
     P.njobs = njobs;
@@ -1108,6 +1159,13 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
         fn = q8_kernel_ptr(qg);
         lds = q8_lds(qg);
     }
+    // a split-K job with a launch to itself and a plain store for an epilogue: its slices meet in a second launch (see
+    // plane_splitk_reduce_kernel).  Not under a lockstep recorder: a merged launch re-tiles its jobs and keeps the in-kernel meeting
+    const slnlp_gemm_args& a0 = jobs[0];
+    const bool deferred = defer_reduce && njobs == 1 && P.job[0].nks > 1 && P.job[0].nks <= WD_MAX_SPLITK && !recording() && a0.precision != 8 &&
+                          splitk_mode() == 0 && a0.C && !a0.bias && !a0.relu && !a0.gate && a0.drop_p == 0.f && !a0.resid && !a0.C_hi && !a0.C_q8 &&
+                          !a0.col_scale;
+    if (deferred) P.job[0].hand_off = 4;
     if (recording()) return record_op(fn, dim3(blocks), dim3(PTHREADS), lds, REC_PLANE_GROUP, &P, sizeof(P), "gemm_planes");
     void* args[3];
     const PlaneJob* tab = nullptr;
@@ -1117,6 +1175,15 @@ int gemm_planes_group(const slnlp_gemm_args* jobs, const int* split_k, int njobs
     if (hipLaunchKernel(fn, dim3(blocks), dim3(PTHREADS), args, lds, s) != hipSuccess) {
         set_error("gemm_planes: %s", hipGetErrorString(hipGetLastError()));
         return SLNLP_ERR_LAUNCH;
+    }
+    if (deferred) {
+        PlaneJob j = P.job[0];
+        void* rargs[1] = {&j};
+        const int rblocks = j.tiles_x * j.tiles_y * (GEO[geo].bm / 64) * (GEO[geo].bn / 32);
+        if (hipLaunchKernel(splitk_reduce_kernel_ptr(geo), dim3(rblocks), dim3(PTHREADS), rargs, 0, s) != hipSuccess) {
+            set_error("gemm_planes (split-K reduce): %s", hipGetErrorString(hipGetLastError()));
+            return SLNLP_ERR_LAUNCH;
+        }
     }
     if (timed >= 0) launch_timer_end(timed, s, blocks, njobs, geo);
     return 0;
@@ -1161,7 +1228,8 @@ int gemm_planes_wd(const slnlp_gemm_args& wg, const slnlp_gemm_args& dg, void* s
     const WdPlan p = gemm_planes_wd_plan(wg, dg);
     if (p.separate) {
         const int one = 1;
-        SLNLP_TRY(gemm_planes_group(&wg, &p.split, 1, scratch, scratch_bytes, st));
+        static const bool defer = [] { const char* e = getenv("SLNLP_WD_DEFER"); return !(e && atoi(e) == 0); }();   // (A / B measurements)
+        SLNLP_TRY(gemm_planes_group(&wg, &p.split, 1, scratch, scratch_bytes, st, defer));
         return gemm_planes_group(&dg, &one, 1, scratch, scratch_bytes, st);
     }
     const slnlp_gemm_args jobs[2] = {wg, dg};

@@ -549,6 +549,33 @@ def test_gemm_rows_epilogue_dropout_and_output_planes(ops):
     assert rel(h1, A[:, :256].double() @ B[:, :256].double().T) < 1e-4
 
 
+@pytest.mark.parametrize("Mtok,Nout,Kin", [(2400, 512, 512), (16384, 3072, 1024), (16384, 2048, 1024), (16300, 1024, 512)])
+def test_gradient_pair_as_the_plans_launch_it(ops, Mtok, Nout, Kin):
+    """slnlp_gemm_wd: the weight and data gradient of one dY in ONE grouped launch, or -- both large -- a launch each with the weight
+    gradient's K-slices added by a launch of their own (plane_splitk_reduce_kernel).  Whatever the library picks, the results are the
+    grouped launch's with the same split, bit for bit (the K partition and the slice order define the sums), and close to fp64."""
+    dY, X, W = rnd(Mtok, Nout, seed=1).cuda(), rnd(Mtok, Kin, seed=2).cuda(), rnd(Nout, Kin, seed=3).cuda()
+    dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+    rs = torch.empty(Nout, device="cuda")
+    jw, dW = ops.plane_job(dYp, Xp, M=Nout, N=Kin, K=Mtok, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=2)
+    jd, dX = ops.plane_job(dYp, Wp, M=Mtok, N=Kin, K=Nout, a_kmajor=True, b_kmajor=False, precision=2)
+    split, separate, _, _ = ops.gemm_wd_plan(jw, jd)
+    assert separate == int(Nout >= 2048)      # (the rule: gemm_planes_wd_plan -- both products large)
+    ops.gemm_wd(jw, jd)
+    torch.cuda.synchronize()
+    got = [dW.clone(), rs.clone(), dX.clone()]
+    for t in (dW, rs, dX): t.fill_(float("nan"))
+    ops.gemm_group([jw, jd], [split, 1])
+    torch.cuda.synchronize()
+    for a, b, name in zip(got, (dW, rs, dX), ("dW", "db", "dX")):
+        assert torch.equal(a, b), f"{name}: slnlp_gemm_wd differs from the grouped launch with split {split}"
+    # two-pass products: dY enters with its bf16 head -- held against the fp64 product of bf16(dY) (on the GPU: these are 100-GFLOP products)
+    dYh = dY.bfloat16().double()
+    relg = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    tol = 1e-4 * max(1.0, math.sqrt(max(Mtok, Nout) / 2400))
+    assert relg(dW, dYh.T @ X.double()) < tol and relg(dX, dYh @ W.double()) < tol and relg(rs, dYh.sum(0)) < tol
+
+
 @pytest.mark.parametrize("knob", [64, 128, 12832, 256])
 def test_plane_epilogue_is_the_per_element_composition_bit_for_bit(ops, knob):
     """The plane GEMM's epilogue takes two routes through an LDS image of the tile -- bias / ReLU / gate / residual row-major for

@@ -86,6 +86,22 @@ def grads(M, N, K, split):
     scr = ops.gemm_group([jw, jd], [split, 1])
     return lambda: ops.gemm_group([jw, jd], [split, 1], scr)
 
+def one_grad(M, N, K, split, which):
+    dY, X, W = [torch.randn(*s, generator=g).cuda() for s in ((M, N), (M, K), (N, K))]
+    dYp, Xp, Wp = ops.split_planes(dY), ops.split_planes(X), ops.split_planes(W)
+    rs = torch.empty(N, device="cuda")
+    if which == "wgrad":
+        j, _ = ops.plane_job(dYp, Xp, M=N, N=K, K=M, a_kmajor=False, b_kmajor=False, rowsum_a=rs, precision=2)
+    else:
+        j, _ = ops.plane_job(dYp, Wp, M=M, N=K, K=N, a_kmajor=True, b_kmajor=False, precision=2)
+    scr = ops.gemm_group([j], [split])
+    return lambda: ops.gemm_group([j], [split], scr)
+
+if os.environ.get("PROBE_PAIR"):      # the configs[4] in_proj gradient products ALONE, as slnlp_gemm_wd launches them (two-pass, 256 x 256)
+    report("configs[4] in_proj dgrad alone          ", one_grad(16384, 3072, 1024, 1, "dgrad"), 256)
+    for sp in (5, 4, 3):
+        report(f"configs[4] in_proj wgrad alone, split {sp}", one_grad(16384, 3072, 1024, sp, "wgrad"), 256)
+    sys.exit(0)
 report("cfg2 forward 2400x512x512        ", fwd(2400, 512, 512), 64)
 report("cfg2 dgrad+wgrad (split 3)       ", grads(2400, 512, 512, 3), 64)
 report("15 fits' forward 36000x512x512   ", fwd(36000, 512, 512), 128)
