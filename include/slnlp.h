@@ -133,16 +133,18 @@ int slnlp_gemm_wd_plan(const slnlp_gemm_args* wgrad, const slnlp_gemm_args* dgra
                        int32_t* geo_dgrad);
 /* The decoder's products: the reference decodes ONE target position (transformer.py:82-87), so every nn.Linear of its
  * decoder (and the generator, transformer.py:46-48,88) is y[B rows, N] = x[B rows, K] W[N, K]^T on a dependent chain.
- * Both operands as k-major bf16 hi / lo planes (A_hi / A_lo / lda_p, B_hi / B_lo / ldb_p; rows zero-padded to multiples of
- * 64, strides multiples of 64 covering K); each wave loads its MFMA fragments straight from the planes -- no conversion, no
- * LDS staging, no barrier in the K loop.  Same epilogue fields as slnlp_gemm (bias, relu, gate, dropout incl. drop_head_dim,
- * resid, C and / or C_hi / C_lo); the K sum is (first half of the 64-k tiles) + (second half), as slnlp_gemm defines it. */
+ * x as k-major bf16 hi / lo planes (A_hi / A_lo / lda_p; rows zero-padded to multiples of 64, stride a multiple of 64 covering
+ * K), the weight W as fp32 (B / ldb, k-major, K a multiple of 64): the kernel splits it in registers -- hi = bf16(w), lo =
+ * bf16(w - hi), the bits a plane of W would hold -- so nobody maintains planes of these weights.  Each wave loads its MFMA
+ * fragments straight from memory: no LDS staging, no barrier in the K loop.  Same epilogue fields as slnlp_gemm (bias, relu,
+ * gate, dropout incl. drop_head_dim, resid, C and / or C_hi / C_lo); the K sum is per 64-k tile: partial products from zero, added
+ * in tile order.  Meant for up to 64 rows (one block of rows; more work, the plans use the plane GEMM there). */
 int slnlp_gemm_rows(const slnlp_gemm_args* args, void* stream);
 /* The backward pair of such a product in ONE launch (autograd's two mm calls for nn.Linear at batch rows):
  *   dgrad: dX[B rows, Kin] = dY[B rows, Nout] W[Nout, Kin] (+ the slnlp_gemm epilogue: gate, dropout, residual, planes out) --
- *          A = dY planes k-major, B = W planes NOT k-major (m-major: k = W's row);
- *   wgrad: dW[Nout, Kin] = dY^T x, rowsum_a = db[Nout] = column sums of dY (optional) -- A = the same dY planes, B = x planes, both
- *          NOT k-major, K = the batch rows (plane rows beyond them must be zero), C = dW fp32, no epilogue.
+ *          A = dY planes k-major, B = W as fp32 (B / ldb), NOT k-major (m-major: k = W's row; Nout a multiple of 64, Kin of 4);
+ *   wgrad: dW[Nout, Kin] = dY^T x, rowsum_a = db[Nout] = column sums of dY (optional; computed as dY^T 1 on the MFMA) -- A = the same
+ *          dY planes, B = x planes, both NOT k-major, K = the batch rows (plane rows beyond them must be zero), C = dW fp32, no epilogue.
  * Same precision for both; K sums per 64-k tile in tile order, as slnlp_gemm_rows. */
 int slnlp_gemm_rows_bwd(const slnlp_gemm_args* dgrad, const slnlp_gemm_args* wgrad, void* stream);
 /* Output tile of slnlp_gemm_rows launches: -1 = automatic (16 x 16 for one fit's launch -- it is bound by what ONE compute unit can
@@ -219,7 +221,8 @@ int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, i
 /* dx (+ optional add_to_dx [rows,E]) ; dx_drop (optional) = dropout_bwd(dx) at
  * drop_site for the sub-layer branch; partial [nblk,2,E] per-block partial
  * (dgamma, dbeta) sums, reduced later by slnlp_ln_param_reduce. nblk is
- * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS). */
+ * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS).  Blocks are 16 rows for rows >= 1024 (the row kernel
+ * then sums them itself, one pass over dy and x), 64 rows below (a separate column-sum launch). */
 #define SLNLP_LN_MAX_PARTIALS 1024
 int slnlp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
                         int rows, int E, const float* add_to_dx, float* dx, float* dx_drop,
