@@ -265,7 +265,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------- internal kernel launchers
 namespace slnlp {
 int gemm(const slnlp_gemm_args& a, hipStream_t s);
-int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s);   // fp32-operand jobs, one launch (gemm.hip)
+int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s, unsigned wide_mask = 0);   // fp32-operand jobs, one launch (gemm.hip)
 int gemm_planes(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_rows(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_rows_bwd(const slnlp_gemm_args& dgrad, const slnlp_gemm_args& wgrad, hipStream_t s);   // dX = dY W and dW = dY^T x, db in one launch     // B-row products on k-major planes, register-direct (gemm_rows.hip)

@@ -638,7 +638,10 @@ int gemm(const slnlp_gemm_args& a, hipStream_t s) {
 
 // fp32-operand jobs in one launch; a job with operands that cannot take 16-B vector loads makes the whole group
 // fall back to one launch per job (same results, just not fused)
-int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
+// wide_mask bit i: job i takes 64-column tiles although it has one block of rows (16-column tiles spread a skinny product over 4 x
+// the CUs, which pays while its K loop is long; a product cut into short K-slices has its workgroups from the slices, and wide tiles
+// quarter the re-reads of its A rows).  Same K order: same bits either way.
+int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s, unsigned wide_mask) {
     SLNLP_CHECK_ARG(jobs && njobs >= 1 && njobs <= GEMM_GROUP_MAX, "gemm_group: 1..%d jobs", GEMM_GROUP_MAX);
     GemmGroupParams P;
     P.njobs = njobs;
@@ -650,7 +653,7 @@ int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s) {
         SLNLP_CHECK_ARG(a.precision == jobs[0].precision, "gemm_group: jobs of one launch share the precision");
         SLNLP_TRY(fill_params(a, P.job[i]));
         fusable = fusable && P.job[i].a_vec && P.job[i].b_vec;
-        const bool narrow = a.M <= BM && a.rowsum_a == nullptr;
+        const bool narrow = a.M <= BM && a.rowsum_a == nullptr && !((wide_mask >> i) & 1u);
         P.variant[i] = (a.a_kmajor && a.b_kmajor ? 0 : a.a_kmajor ? 2 : 4) + (narrow ? 1 : 0);
         P.gx[i] = ceil_div(a.N, narrow ? 16 : 64);
         P.gy[i] = ceil_div(a.M, BM);

@@ -92,7 +92,13 @@ __device__ __forceinline__ void rnn_cell_bwd_body(slnlp_rnn_cell_bwd_dir d0, sln
         const int b = (int)(idx / Hd), j = (int)(idx % Hd);
         const bool valid = lengths ? (d.t < lengths[b]) : true;
         float dh = d.dh_state[idx];
-        for (int e = 0; e < d.n_extra; ++e) dh += d.dh_extra[e * d.extra_stride + idx];   // fixed order
+        for (int e0 = 0; e0 < d.n_extra; e0 += 8) {        // fixed order; eight partial products' loads in flight (15 of them with 128-k slices)
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = e0 + e < d.n_extra ? d.dh_extra[(e0 + e) * d.extra_stride + idx] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dh += x[e];
+        }
         float* gx = d.dgx + (long)b * G * Hd;
         float* gh = LSTM ? gx : d.dgh + (long)b * G * Hd;
         if (!valid) {

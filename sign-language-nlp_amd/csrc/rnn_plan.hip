@@ -16,10 +16,19 @@
 
 #include "common.hpp"
 #include "launch.hpp"
+#include <cstring>
 
 namespace slnlp {
 
 static inline long align_up_r(long v, long a) { return (v + a - 1) / a * a; }
+
+// K-slices of the recurrent data gradient (see slnlp_rnn_plan::kslices).  SLNLP_RNN_KSLICE=gate: one per gate (A / B measurements)
+static int rnn_kslices(const slnlp_rnn_config& c) {
+    const int G = c.lstm ? 4 : 3;
+    if (!(c.Hd >= 256 && c.Hd % 4 == 0)) return 1;
+    static const bool per_gate = [] { const char* e = getenv("SLNLP_RNN_KSLICE"); return e && !strcmp(e, "gate"); }();
+    return (!per_gate && c.Hd % 128 == 0) ? G * c.Hd / 128 : G;
+}
 
 struct RParam {
     std::string name;
@@ -167,7 +176,7 @@ static RWs rcarve(const slnlp_rnn_config& c, void* base) {
             e.dh = b.take<float>(B * Hd);
             e.dc = w.zero_bwd + (size_t)(2 * l + d) * B * Hd;
             e.carry = b.take<float>(B * Hd);
-            e.dhx = b.take<float>(3 * B * Hd);
+            e.dhx = b.take<float>((size_t)(rnn_kslices(c) > 1 ? rnn_kslices(c) - 1 : 1) * B * Hd);
         }
         a.out = b.take<float>(M * 2 * Hd);
         a.dout = b.take<float>(M * 2 * Hd);
@@ -343,9 +352,11 @@ struct slnlp_rnn_plan {
         a.precision = cfg.precision == 3 ? wgrad_p : cfg.precision;
         return a;
     }
-    // the recurrent dgrad dh(t-1) = dgh W_hh + carry contracts over the G*Hd gate columns: one K-slice per gate
-    // (each its own GEMM job, partial products summed by the next cell kernel) keeps the serial K loop at Hd
-    int kslices() const { const int G = cfg.lstm ? 4 : 3; return (cfg.Hd >= 256 && cfg.Hd % 4 == 0) ? G : 1; }
+    // the recurrent dgrad dh(t-1) = dgh W_hh + carry contracts over the G*Hd gate columns, cut into K-slices (each its own GEMM job or
+    // one GEMM of a batched job; partial products summed by the next cell kernel).  Rounds 1-4: one slice per gate on 64 x 16 tiles --
+    // 256 workgroups of 160 KB (64 rows x 512 k of dgh, re-read by each of the 32 column tiles, + 512 k x 16 columns of W_hh).  Round 5:
+    // slices of 128 on 64 x 64 tiles -- the same 256 workgroups, 64 KB each (32 + 32): a launch lasts as long as one workgroup loads.
+    int kslices() const { return rnn_kslices(cfg); }
     // dW[Nout,Kin](ldw) = dy[T,Nout](ldy)^T x[T,Kin](ldx);  db = colsum(dy)
     int wgr(const float* dy, long ldy, int T, int Nout, const float* x, long ldx, int Kin, float* dW, long ldw, float* db,
             hipStream_t st) const {
@@ -697,14 +708,25 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
             SLNLP_TRY(rnn_cell_bwd(lstm, dirs, 2, B, Hd, lengths, 2 * Hd, last ? 0.f : p, RSITE_ENC0 + l, rng, st));
             slnlp_gemm_args rec[8];
             int nj = 0;
+            unsigned wide = 0;
             for (int d = 0; d < 2; ++d) {
                 const RnnW& q = L.enc[d][l];
-                for (int sl = 0; sl < nsl; ++sl)
-                    rec[nj++] = pl->dgr_args(dirs[d].dgh + sl * Ks, GH, B, Ks, pl->P(q.w_hh) + (long)sl * Ks * Hd, Hd, Hd,
-                                             sl == 0 ? a.d[d].dh : a.d[d].dhx + (long)(sl - 1) * B * Hd, Hd,
-                                             sl == 0 ? a.d[d].carry : nullptr);
+                if (nsl <= 4) {
+                    for (int sl = 0; sl < nsl; ++sl)
+                        rec[nj++] = pl->dgr_args(dirs[d].dgh + sl * Ks, GH, B, Ks, pl->P(q.w_hh) + (long)sl * Ks * Hd, Hd, Hd,
+                                                 sl == 0 ? a.d[d].dh : a.d[d].dhx + (long)(sl - 1) * B * Hd, Hd,
+                                                 sl == 0 ? a.d[d].carry : nullptr);
+                    continue;
+                }
+                // slice 0 (+ carry) -> dh; slices 1 .. nsl-1 as ONE batched job -> dhx[0 .. nsl-2]; 64-column tiles
+                rec[nj] = pl->dgr_args(dirs[d].dgh, GH, B, Ks, pl->P(q.w_hh), Hd, Hd, a.d[d].dh, Hd, a.d[d].carry);
+                wide |= 1u << nj++;
+                rec[nj] = pl->dgr_args(dirs[d].dgh + Ks, GH, B, Ks, pl->P(q.w_hh) + (long)Ks * Hd, Hd, Hd, a.d[d].dhx, Hd, nullptr);
+                rec[nj].batch = nsl - 1;
+                rec[nj].batch_stride_a = Ks; rec[nj].batch_stride_b = (long)Ks * Hd; rec[nj].batch_stride_c = (long)B * Hd;
+                wide |= 1u << nj++;
             }
-            SLNLP_TRY(gemm_group(rec, nj, st));
+            SLNLP_TRY(gemm_group(rec, nj, st, wide));
         }
         float* dx = l > 0 ? w.enc[l - 1].dout : w.demb;
         for (int d = 0; d < 2; ++d) {
