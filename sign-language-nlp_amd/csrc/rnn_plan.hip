@@ -26,9 +26,10 @@ static inline long align_up_r(long v, long a) { return (v + a - 1) / a * a; }
 static int rnn_kslices(const slnlp_rnn_config& c) {
     const int G = c.lstm ? 4 : 3;
     if (!(c.Hd >= 256 && c.Hd % 4 == 0)) return 1;
-    static const bool per_gate = [] { const char* e = getenv("SLNLP_RNN_KSLICE"); return e && !strcmp(e, "gate"); }();
-    return (!per_gate && c.Hd % 128 == 0) ? G * c.Hd / 128 : G;
+    static const int len = [] { const char* e = getenv("SLNLP_RNN_KSLICE"); return e && strcmp(e, "gate") ? atoi(e) : 0; }();   // (0: one per gate)
+    return (len >= 64 && c.Hd % len == 0) ? G * c.Hd / len : G;
 }
+static bool rnn_kslice_wide() { static const bool w = [] { const char* e = getenv("SLNLP_RNN_KSLICE"); return e && strchr(e, 'w'); }(); return w; }
 
 struct RParam {
     std::string name;
@@ -711,7 +712,7 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
             unsigned wide = 0;
             for (int d = 0; d < 2; ++d) {
                 const RnnW& q = L.enc[d][l];
-                if (nsl <= 4) {
+                if (nsl <= 4 && !rnn_kslice_wide()) {
                     for (int sl = 0; sl < nsl; ++sl)
                         rec[nj++] = pl->dgr_args(dirs[d].dgh + sl * Ks, GH, B, Ks, pl->P(q.w_hh) + (long)sl * Ks * Hd, Hd, Hd,
                                                  sl == 0 ? a.d[d].dh : a.d[d].dhx + (long)(sl - 1) * B * Hd, Hd,
@@ -720,11 +721,13 @@ int slnlp_rnn_backward(slnlp_rnn_plan* pl, void* stream) {
                 }
                 // slice 0 (+ carry) -> dh; slices 1 .. nsl-1 as ONE batched job -> dhx[0 .. nsl-2]; 64-column tiles
                 rec[nj] = pl->dgr_args(dirs[d].dgh, GH, B, Ks, pl->P(q.w_hh), Hd, Hd, a.d[d].dh, Hd, a.d[d].carry);
-                wide |= 1u << nj++;
+                if (rnn_kslice_wide()) wide |= 1u << nj;
+                ++nj;
                 rec[nj] = pl->dgr_args(dirs[d].dgh + Ks, GH, B, Ks, pl->P(q.w_hh) + (long)Ks * Hd, Hd, Hd, a.d[d].dhx, Hd, nullptr);
                 rec[nj].batch = nsl - 1;
                 rec[nj].batch_stride_a = Ks; rec[nj].batch_stride_b = (long)Ks * Hd; rec[nj].batch_stride_c = (long)B * Hd;
-                wide |= 1u << nj++;
+                if (rnn_kslice_wide()) wide |= 1u << nj;
+                ++nj;
             }
             SLNLP_TRY(gemm_group(rec, nj, st, wide));
         }
