@@ -235,8 +235,8 @@ int slnlp_layernorm_fwd(const float* x, const float* gamma, const float* beta, i
 /* dx (+ optional add_to_dx [rows,E]) ; dx_drop (optional) = dropout_bwd(dx) at
  * drop_site for the sub-layer branch; partial [nblk,2,E] per-block partial
  * (dgamma, dbeta) sums, reduced later by slnlp_ln_param_reduce. nblk is
- * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS).  Blocks are 16 rows for rows >= 1024 (the row kernel
- * then sums them itself, one pass over dy and x), 64 rows below (a separate column-sum launch). */
+ * returned through *nblk_out (<= SLNLP_LN_MAX_PARTIALS).  Blocks are 16 rows; for rows >= 1024 the row kernel
+ * sums them itself (one pass over dy and x), below a separate column-sum launch does. */
 #define SLNLP_LN_MAX_PARTIALS 1024
 int slnlp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
                         int rows, int E, const float* add_to_dx, float* dx, float* dx_drop,
