@@ -140,20 +140,6 @@ int slnlp_gemm_wd_plan(const slnlp_gemm_args* wgrad, const slnlp_gemm_args* dgra
  * gate, dropout incl. drop_head_dim, resid, C and / or C_hi / C_lo); the K sum is per 64-k tile: partial products from zero, added
  * in tile order.  Meant for up to 64 rows (one block of rows; more work, the plans use the plane GEMM there). */
 int slnlp_gemm_rows(const slnlp_gemm_args* args, void* stream);
-/* The same product with a LayerNorm in front of it: y = LayerNorm(x) W^T, where nn.TransformerDecoderLayer's norm1 / norm2 / norm3
- * and nn.TransformerDecoder's final norm each feed exactly one such product (transformer.py:82-88 -> torch).  x [M, K] fp32 (row
- * stride ldx, K <= 512, a multiple of 64); args->A_hi / A_lo are ignored.  The normalised rows are also stored -- ln->y (fp32, row
- * stride ldy) and / or ln->y_hi / y_lo (bf16 planes, row stride ldy_p; the padding rows / columns of the planes are not written) --
- * and ln->stats [M][2] = (mean, rstd), each optional: what slnlp_layernorm_fwd would have produced (two-pass statistics, eps
- * added to the biased variance), to fp32 rounding. */
-typedef struct slnlp_rows_ln {
-    const float* x; int64_t ldx;
-    const float* gamma; const float* beta; float eps;
-    float* y; int64_t ldy;
-    uint16_t* y_hi; uint16_t* y_lo; int64_t ldy_p;
-    float* stats;
-} slnlp_rows_ln;
-int slnlp_gemm_rows_ln(const slnlp_gemm_args* args, const slnlp_rows_ln* ln, void* stream);
 /* The backward pair of such a product in ONE launch (autograd's two mm calls for nn.Linear at batch rows):
  *   dgrad: dX[B rows, Kin] = dY[B rows, Nout] W[Nout, Kin] (+ the slnlp_gemm epilogue: gate, dropout, residual, planes out) --
  *          A = dY planes k-major, B = W as fp32 (B / ldb), NOT k-major (m-major: k = W's row; Nout a multiple of 64, Kin of 4);

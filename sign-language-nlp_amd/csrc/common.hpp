@@ -267,7 +267,7 @@ namespace slnlp {
 int gemm(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_group(const slnlp_gemm_args* jobs, int njobs, hipStream_t s, unsigned wide_mask = 0);   // fp32-operand jobs, one launch (gemm.hip)
 int gemm_planes(const slnlp_gemm_args& a, hipStream_t s);
-int gemm_rows(const slnlp_gemm_args& a, hipStream_t s, const slnlp_rows_ln* ln = nullptr);   // ln: A = LayerNorm(ln->x), computed by the kernel
+int gemm_rows(const slnlp_gemm_args& a, hipStream_t s);
 int gemm_rows_bwd(const slnlp_gemm_args& dgrad, const slnlp_gemm_args& wgrad, hipStream_t s);   // dX = dY W and dW = dY^T x, db in one launch     // B-row products on k-major planes, register-direct (gemm_rows.hip)
 int gemm_planes_init();
 // up to 4 independent plane GEMMs in ONE launch, optional deterministic split-K per job (gemm_planes.hip)

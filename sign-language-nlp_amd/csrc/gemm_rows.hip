@@ -36,12 +36,9 @@ struct RowsParams {
     slnlp_gemm_args a;
     unsigned drop_thr;
     float drop_scale;
-    slnlp_rows_ln ln;          // ln.x != nullptr: A = LayerNorm(ln.x), computed here (forward products, K <= 512)
 };
 __device__ __forceinline__ RowsParams as_global(RowsParams p) {
     launder(p.a);
-    p.ln.x = as_global(p.ln.x); p.ln.gamma = as_global(p.ln.gamma); p.ln.beta = as_global(p.ln.beta);
-    p.ln.y = as_global(p.ln.y); p.ln.y_hi = as_global(p.ln.y_hi); p.ln.y_lo = as_global(p.ln.y_lo); p.ln.stats = as_global(p.ln.stats);
     return p;
 }
 
@@ -172,99 +169,6 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
         const long off = (long)(min(bm0 + 16 * i, am_last) + (lane & 15)) * g.lda_p + koct;
         ah[i] = g.A_hi + off; al[i] = g.A_lo + off;
     }
-    // ---- LayerNorm in front of the product (the decoder's norm1 / norm2 / norm3 / final norm feed exactly one B-row product each:
-    // transformer.py:82-88 through nn.TransformerDecoderLayer): the workgroup needs its rows of the normalised activation whole -- the
-    // bytes it would load as planes anyway -- so it loads the un-normalised fp32 rows instead, wave w the 64 columns of K tile w, and
-    // normalises them itself: row sums over the lane's 16 values, the 4 lanes of a row (xor 16, 32), the 8 waves (LDS, wave order) ->
-    // mean; the same for sum (x - mean)^2 -> rstd (two passes, as layernorm_fwd); (x - mean) rstd gamma + beta; split -> fragments.
-    // The workgroups of the first column tile also store the result (fp32, planes: later residuals, the backward's operands) and
-    // (mean, rstd).  One launch less per LayerNorm on the decoder's dependent chain (4.5 us each, 18 per configs[1] step).  Per row the
-    // arithmetic does not depend on the tile: a fit in lockstep keeps its bits.
-    const bool ln_on = BK && p.ln.x != nullptr;            // (block-uniform)
-    bf16x8 lnf[2][MT], lnl[2][MT];
-    if (BK && ln_on) {
-        const slnlp_rows_ln& q = p.ln;
-        float* red = part + (size_t)ktiles * MT * NT * 256;           // [2 passes][8 waves][16 MT rows] behind the partial tiles
-        const bool mine = wave < ktiles;                               // (K <= 512: at most one K tile per wave)
-        float xv[2][MT][8];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = min(bm0 + 16 * i + (lane & 15), M - 1);
-                if (mine) rows_load8(q.x + (long)row * q.ldx + wave * 64 + kk * 32 + koct, xv[kk][i]);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[kk][i][e] = 0.f;
-                }
-            }
-        const float invK = 1.f / (float)g.K;
-        float mean[MT], rstd[MT];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                float a = 0.f;
-                if (mine) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float d = pass == 0 ? xv[kk][i][e] : xv[kk][i][e] - mean[i];
-                            a += pass == 0 ? d : d * d;
-                        }
-                }
-                a += __shfl_xor(a, 16);
-                a += __shfl_xor(a, 32);
-                if (lane < 16) red[(pass * RT_WAVES + wave) * (16 * MT) + 16 * i + lane] = a;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                float a = 0.f;
-#pragma unroll
-                for (int w8 = 0; w8 < RT_WAVES; ++w8) a += red[(pass * RT_WAVES + w8) * (16 * MT) + 16 * i + (lane & 15)];
-                if (pass == 0) mean[i] = a * invK;
-                else rstd[i] = 1.f / sqrtf(a * invK + q.eps);
-            }
-        }
-        if (mine) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int k = wave * 64 + kk * 32 + (int)koct;
-                float gm[8], bt[8];
-                rows_load8(q.gamma + k, gm);
-                rows_load8(q.beta + k, bt);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (xv[kk][i][e] - mean[i]) * rstd[i] * gm[e] + bt[e];
-                    rows_split8<NSPLIT>(v, lnf[kk][i], lnl[kk][i]);
-                    const int row = bm0 + 16 * i + (lane & 15);
-                    if (bx == 0 && row < M) {
-                        if (q.y) {
-                            *reinterpret_cast<float4*>(q.y + (long)row * q.ldy + k) = make_float4(v[0], v[1], v[2], v[3]);
-                            *reinterpret_cast<float4*>(q.y + (long)row * q.ldy + k + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                        }
-                        if (q.y_hi) {
-                            bf16x8 h, l;
-                            rows_split8<3>(v, h, l);
-                            *reinterpret_cast<bf16x8*>(q.y_hi + (long)row * q.ldy_p + k) = h;
-                            if (q.y_lo) *reinterpret_cast<bf16x8*>(q.y_lo + (long)row * q.ldy_p + k) = l;
-                        }
-                    }
-                }
-            }
-        }
-        if (bx == 0 && wave == 0 && lane < 16 && q.stats) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = bm0 + 16 * i + lane;
-                if (row < M) { q.stats[2 * row] = mean[i]; q.stats[2 * row + 1] = rstd[i]; }
-            }
-        }
-    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         bcol[j] = min(bn0 + 16 * j, bn_last);
@@ -311,7 +215,6 @@ __device__ __forceinline__ void rows_tile(const RowsParams& p, int bx, int by, f
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if (BK && ln_on) { fa[kk][i] = lnf[kk][i]; la[kk][i] = lnl[kk][i]; continue; }
                 fa[kk][i] = *reinterpret_cast<const bf16x8*>(ah[i] + k);
                 if (NSPLIT == 3) la[kk][i] = *reinterpret_cast<const bf16x8*>(al[i] + k);
             }
@@ -564,10 +467,7 @@ static RowsBwdKernel rows_bwd_kernel(int precision, int geo) {
     if (precision == 3) return geo == 0 ? gemm_rows_bwd_kernel_3_0 : geo == 1 ? gemm_rows_bwd_kernel_3_1 : gemm_rows_bwd_kernel_3_2;
     return geo == 0 ? gemm_rows_bwd_kernel_1_0 : geo == 1 ? gemm_rows_bwd_kernel_1_1 : gemm_rows_bwd_kernel_1_2;
 }
-static size_t rows_lds(int geo, int K, bool ln = false) {
-    return (size_t)ceil_div(K, 64) * RT_GEO[geo].mt * RT_GEO[geo].nt * 64 * 4 * sizeof(float) +
-           (ln ? (size_t)2 * RT_WAVES * 16 * RT_GEO[geo].mt * sizeof(float) : 0);      // (+ the LayerNorm's row sums: [2][8 waves][16 mt])
-}
+static size_t rows_lds(int geo, int K) { return (size_t)ceil_div(K, 64) * RT_GEO[geo].mt * RT_GEO[geo].nt * 64 * 4 * sizeof(float); }
 // backward launches: the data gradient's partial tiles + its waves' W images, or the weight gradient's four images per wave
 static size_t rows_bwd_lds(int geo, int K) {
     const size_t d = rows_lds(geo, K) + (size_t)RT_WAVES * RT_GEO[geo].nt * RT_FIMG * sizeof(float);
@@ -642,19 +542,11 @@ const void* gemm_rows_for_fits(const void* fn, const void* recorded_args, int fi
     const slnlp_gemm_args& a = reinterpret_cast<const RowsParams*>(recorded_args)->a;
     const int geo = rows_geo(a.M, a.N, a.K, fits, false);
     *grid = rows_grid(geo, a.M, a.N);
-    *lds = rows_lds(geo, a.K, reinterpret_cast<const RowsParams*>(recorded_args)->ln.x != nullptr);
+    *lds = rows_lds(geo, a.K);
     return (const void*)rows_kernel(prec, geo);
 }
 
-static int check_rows_job(const slnlp_gemm_args& a_in, bool b_kmajor, const char* who, const slnlp_rows_ln* ln = nullptr) {
-    slnlp_gemm_args a = a_in;
-    if (ln && ln->x) {          // A comes from the LayerNorm: no planes to check -- stand-ins that pass the plane checks below
-        SLNLP_CHECK_ARG(b_kmajor && ln->gamma && ln->beta && a.K <= 512 && ln->ldx >= a.K && ln->ldx % 4 == 0 &&
-                        (((uintptr_t)ln->x | (uintptr_t)ln->gamma | (uintptr_t)ln->beta | (uintptr_t)ln->y | (uintptr_t)ln->y_hi | (uintptr_t)ln->y_lo) & 15) == 0 &&
-                        (!ln->y || (ln->ldy >= a.K && ln->ldy % 4 == 0)) && (!ln->y_hi || (ln->ldy_p >= a.K && ln->ldy_p % 8 == 0)),
-                        "%s: LayerNorm operand: forward products with K <= 512, 16-byte aligned rows", who);
-        a.A_hi = reinterpret_cast<const uint16_t*>(ln->x); a.A_lo = a.A_hi; a.lda_p = (a.K + 63) / 64 * 64;
-    }
+static int check_rows_job(const slnlp_gemm_args& a, bool b_kmajor, const char* who) {
     SLNLP_CHECK_ARG(a.A_hi && a.B, "%s: A as bf16 planes (A_hi / A_lo / lda_p) and the weight B as fp32 (B / ldb) required", who);
     SLNLP_CHECK_ARG(a.a_kmajor && (a.b_kmajor != 0) == b_kmajor, "%s: operand layouts (A k-major; B k-major for a forward product, m-major for a data gradient)", who);
     SLNLP_CHECK_ARG(a.C || a.C_hi, "%s: no output", who);
@@ -688,7 +580,6 @@ int gemm_rows_bwd(const slnlp_gemm_args& dgrad, const slnlp_gemm_args& wgrad, hi
     SLNLP_CHECK_ARG((((uintptr_t)w.A_hi | (uintptr_t)w.B_hi | (uintptr_t)w.A_lo | (uintptr_t)w.B_lo) & 15) == 0, "gemm_rows_bwd (wgrad): planes must be 16-byte aligned");
     SLNLP_CHECK_ARG(!w.bias && !w.gate && !w.resid && w.drop_p == 0.f && !w.C_hi && w.relu == 0 && w.batch <= 1, "gemm_rows_bwd (wgrad): no epilogue");
     RowsBwdParams p;
-    memset(&p.d.ln, 0, sizeof(p.d.ln));
     p.d.a = dgrad;
     p.d.drop_thr = dropout_threshold(dgrad.drop_p);
     p.d.drop_scale = 1.f / (1.f - dgrad.drop_p);
@@ -700,17 +591,15 @@ int gemm_rows_bwd(const slnlp_gemm_args& dgrad, const slnlp_gemm_args& wgrad, hi
                    "gemm_rows_bwd", p);
 }
 
-int gemm_rows(const slnlp_gemm_args& a, hipStream_t st, const slnlp_rows_ln* ln) {
-    SLNLP_TRY(check_rows_job(a, true, "gemm_rows", ln));
+int gemm_rows(const slnlp_gemm_args& a, hipStream_t st) {
+    SLNLP_TRY(check_rows_job(a, true, "gemm_rows"));
     RowsParams p;
-    memset(&p.ln, 0, sizeof(p.ln));
     p.a = a;
     p.drop_thr = dropout_threshold(a.drop_p);
     p.drop_scale = 1.f / (1.f - a.drop_p);
-    if (ln && ln->x) p.ln = *ln;
     SLNLP_TRY(rows_init());
     const int geo = rows_geo(a.M, a.N, a.K, 1, false);
-    return zlaunch(rows_kernel(a.precision, geo), rows_grid(geo, a.M, a.N), RT_THREADS, rows_lds(geo, a.K, p.ln.x != nullptr), st, "gemm_rows", p);
+    return zlaunch(rows_kernel(a.precision, geo), rows_grid(geo, a.M, a.N), RT_THREADS, rows_lds(geo, a.K), st, "gemm_rows", p);
 }
 
 }  // namespace slnlp
@@ -753,11 +642,4 @@ extern "C" int slnlp_gemm_rows(const slnlp_gemm_args* args, void* stream) {
         return SLNLP_ERR_INVALID_ARG;
     }
     return slnlp::gemm_rows(*args, (hipStream_t)stream);
-}
-extern "C" int slnlp_gemm_rows_ln(const slnlp_gemm_args* args, const slnlp_rows_ln* ln, void* stream) {
-    if (!args || !ln || !ln->x) {
-        slnlp::set_error("gemm_rows_ln: null args");
-        return SLNLP_ERR_INVALID_ARG;
-    }
-    return slnlp::gemm_rows(*args, (hipStream_t)stream, ln);
 }

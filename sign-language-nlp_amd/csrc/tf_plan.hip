@@ -152,19 +152,14 @@ int slnlp_tf_create(const slnlp_tf_config* cfg, const slnlp_tf_buffers* buf, sln
 // Decoder layer l up to its cross-attention query: self-attention over ONE key (softmax == 1 -> out_proj(v_proj(t));
 // the q/k rows of in_proj are dead; in train mode the weight-1 "attention" is still dropped per (row, head) -- fused into
 // the V projection), residual + norm1, then q = in_proj_q(t1) (transformer.py:82-87).
-int slnlp_tf_plan::dec_self_block(int l, const float* t, const PP* tp, int B, float p, hipStream_t st, const float* ln_in, long ln_w, long ln_b,
-                                  float* ln_out, float* ln_stats) const {
+int slnlp_tf_plan::dec_self_block(int l, const float* t, const PP* tp, int B, float p, hipStream_t st) const {
     const slnlp_tf_plan* pl = this;
     const int E = cfg.E, dh = E / cfg.H;
     const DecP& q = L.dec[l];
     const DecA& a = w.dec[l];
     if (use_rows) {        // B-row products on planes (gemm_rows.hip): every producer also emits its output as the next product's operand
-        // (ln_in: the layer's input t = norm3 of the layer below, normalised inside the V projection's kernel, which stores t / *tp / stats)
-        SLNLP_TRY(pl->linear_r(*tp, B, E, q.sin_w + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, &a.vp, st, dh,
-                               ln_in, ln_w, ln_b, ln_out, ln_stats));
+        SLNLP_TRY(pl->linear_r(*tp, B, E, q.sin_w + 2L * E * E, E, pl->P(q.sin_b) + 2 * E, a.v, E, 0, p, pl->dec_site(l, 0), nullptr, &a.vp, st, dh));
         SLNLP_TRY(pl->linear_r(a.vp, B, E, q.sout_w, E, pl->P(q.sout_b), a.y1, E, 0, p, pl->dec_site(l, 1), t, nullptr, st));
-        if (pl->ln_fused(B))   // t1 = norm1(y1) inside the query projection's kernel
-            return pl->linear_r(a.t1p, B, E, q.cin_w, E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, nullptr, st, 0, a.y1, q.n1_w, q.n1_b, a.t1, a.st1);
         SLNLP_TRY(layernorm_fwd(a.y1, pl->P(q.n1_w), pl->P(q.n1_b), B, E, 1e-5f, a.t1, a.st1, st, a.t1p.out()));
         SLNLP_TRY(pl->linear_r(a.t1p, B, E, q.cin_w, E, pl->P(q.cin_b), a.q, E, 0, 0.f, 0, nullptr, nullptr, st));
         return 0;
@@ -233,11 +228,7 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
     for (int l = 0; l < c.N; ++l) {
         const DecP& q = L.dec[l];
         const DecA& a = w.dec[l];
-        if (l > 0) {   // (layer 0's block ran ahead of the encoder, above)
-            const DecA& b = w.dec[l - 1];
-            if (ln_fused(B)) SLNLP_TRY(dec_self_block(l, t, tp, B, p, st, b.y3, L.dec[l - 1].n3_w, L.dec[l - 1].n3_b, b.t3, b.st3));
-            else SLNLP_TRY(dec_self_block(l, t, tp, B, p, st));
-        }
+        if (l > 0) SLNLP_TRY(dec_self_block(l, t, tp, B, p, st));   // (layer 0's block ran ahead of the encoder, above)
         // cross-attention over the memory itself: with ONE query per sequence the K / V projections of the S memory rows
         // re-associate into B-row products (attention_mem.hip) -- no [S*B, 2E] projection, no K|V gradient GEMMs:
         // qk = Wk_h^T q_h (batched GEMM) -> scores / softmax / dropout / mbar (+ ctx0 = bv sum_s p_s) -> ctx = Wv_h mbar + ctx0
@@ -251,13 +242,11 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
             SLNLP_TRY(gemm_group(&j2, 1, st));
         }
         if (use_rows) {
-            const bool lnf = ln_fused(B);     // norm2 inside linear1's kernel, norm3 inside the next layer's V projection (the last layer's: a launch)
             SLNLP_TRY(pl->linear_r(a.xctxp, B, E, q.cout_w, E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, nullptr, st));
-            if (!lnf) SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st, a.t2p.out()));
-            SLNLP_TRY(pl->linear_r(a.t2p, B, E, q.l1_w, F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, &a.hp, st, 0,
-                                   lnf ? a.y2 : nullptr, q.n2_w, q.n2_b, a.t2, a.st2));
+            SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st, a.t2p.out()));
+            SLNLP_TRY(pl->linear_r(a.t2p, B, E, q.l1_w, F, pl->P(q.l1_b), a.h, F, 1, p, pl->dec_site(l, 4), nullptr, &a.hp, st));
             SLNLP_TRY(pl->linear_r(a.hp, B, F, q.l2_w, E, pl->P(q.l2_b), a.y3, E, 0, p, pl->dec_site(l, 5), a.t2, nullptr, st));
-            if (!lnf || l + 1 == c.N) SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st, a.t3p.out()));
+            SLNLP_TRY(layernorm_fwd(a.y3, pl->P(q.n3_w), pl->P(q.n3_b), B, E, 1e-5f, a.t3, a.st3, st, a.t3p.out()));
         } else {
             SLNLP_TRY(pl->linear(a.xctx, B, E, pl->P(q.cout_w), E, pl->P(q.cout_b), a.y2, E, 0, p, pl->dec_site(l, 3), a.t1, st));
             SLNLP_TRY(layernorm_fwd(a.y2, pl->P(q.n2_w), pl->P(q.n2_b), B, E, 1e-5f, a.t2, a.st2, st));
@@ -269,10 +258,8 @@ int slnlp_tf_plan::forward_impl(const int64_t* X, const int64_t* y, int B, int t
         tp = &a.t3p;
     }
     if (use_rows) {
-        const bool lnf = ln_fused(B);         // the final norm inside the generator's kernel
-        if (!lnf) SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st, w.tfinp.out()));
-        SLNLP_TRY(pl->linear_r(w.tfinp, B, E, L.lin_w, c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, nullptr, st, 0,
-                               lnf ? t : nullptr, L.decn_w, L.decn_b, w.tfin, w.st_fin));
+        SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st, w.tfinp.out()));
+        SLNLP_TRY(pl->linear_r(w.tfinp, B, E, L.lin_w, c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, nullptr, st));
     } else {
         SLNLP_TRY(layernorm_fwd(t, pl->P(L.decn_w), pl->P(L.decn_b), B, E, 1e-5f, w.tfin, w.st_fin, st));
         SLNLP_TRY(pl->linear(w.tfin, B, E, pl->P(L.lin_w), c.Vt, pl->P(L.lin_b), w.logits, Vp, 0, 0.f, 0, nullptr, st));

@@ -402,13 +402,6 @@ struct slnlp_tf_plan {
     // tiles), the plane GEMM above (configs[4], B = 256, E = 1024: 15 us per gradient pair against 22 -- 47 before the bias gradient
     // became an MFMA product -- and 11 against 13 forward; tools/bench_rows_shapes.py)
     static constexpr int ROWS_MAX_B = 64;
-    // The decoder's LayerNorms (norm1 / norm2 / norm3, the final norm) each feed exactly one B-row product: with K = E <= 512 that product's
-    // kernel normalises its rows itself (gemm_rows.hip) -- 18 launches of 4.5 us less on the configs[1] step's dependent chain.
-    // SLNLP_DEC_LN_FUSE=0: separate layernorm_fwd launches (A / B measurements)
-    bool ln_fused(int B) const {
-        static const bool on = [] { const char* e = getenv("SLNLP_DEC_LN_FUSE"); return !(e && atoi(e) == 0); }();
-        return on && use_rows && B <= ROWS_MAX_B && cfg.E <= 512 && cfg.E % 64 == 0;
-    }
     bool rows_for(int B, int drop_head_dim) const { return B <= ROWS_MAX_B || drop_head_dim != 0; }   // (per-head dropout is not built into the plane GEMM)
     // the optimizer just rewrote the arena (and, with planes, the planes with it)
     void params_stepped() {
@@ -427,8 +420,7 @@ struct slnlp_tf_plan {
     int enc_site(int l, int k) const { return SITE_LAYER0 + l * SITE_PER_LAYER + k; }
     int dec_site(int l, int k) const { return SITE_LAYER0 + (cfg.N + l) * SITE_PER_LAYER + k; }
 
-    int dec_self_block(int l, const float* t, const PP* tp, int B, float p, hipStream_t st, const float* ln_in = nullptr, long ln_w = 0, long ln_b = 0,
-                       float* ln_out = nullptr, float* ln_stats = nullptr) const;
+    int dec_self_block(int l, const float* t, const PP* tp, int B, float p, hipStream_t st) const;
 
     // y[M,N] = x[M,K] W[N,K]^T + b  (+relu) (+dropout) (+resid)
     int linear(const float* x, int M, int K, const float* W, int N, const float* bias, float* y, long ldy, int relu,
@@ -542,11 +534,8 @@ struct slnlp_tf_plan {
         return gemm(a, st);
     }
     // the same product for the decoder's B rows: x as planes, W as fp32 (split in registers), both register-direct (gemm_rows.hip)
-    // ln_* (optional): x = LayerNorm(ln_in) with weight / bias at arena offsets ln_w / ln_b, computed INSIDE the product's kernel, which
-    // also stores it (ln_out fp32, the planes `x`, ln_stats) -- see ln_fused()
     int linear_r(const PP& x, int M, int K, long woff, int N, const float* bias, float* y, long ldy, int relu, float p, int site,
-                 const float* resid, const PP* outp, hipStream_t st, int drop_head_dim = 0, const float* ln_in = nullptr, long ln_w = 0,
-                 long ln_b = 0, float* ln_out = nullptr, float* ln_stats = nullptr) const {
+                 const float* resid, const PP* outp, hipStream_t st, int drop_head_dim = 0) const {
         slnlp_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A_hi = x.hi; a.A_lo = x.lo; a.lda_p = K; a.a_kmajor = 1;
@@ -561,13 +550,6 @@ struct slnlp_tf_plan {
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
         a.precision = prec3();
         a.drop_head_dim = drop_head_dim;
-        if (ln_in) {
-            slnlp_rows_ln q;
-            memset(&q, 0, sizeof(q));
-            q.x = ln_in; q.ldx = K; q.gamma = P(ln_w); q.beta = P(ln_b); q.eps = 1e-5f;
-            q.y = ln_out; q.ldy = K; q.y_hi = x.hi; q.y_lo = x.lo; q.ldy_p = K; q.stats = ln_stats;
-            return gemm_rows(a, st, &q);
-        }
         return rows ? gemm_rows(a, st) : gemm(a, st);
     }
     // the backward pair of a decoder Linear y[B, Nout] = x[B, Kin] W^T + b in ONE launch (gemm_rows.hip: gemm_rows_bwd): dX = dY W with

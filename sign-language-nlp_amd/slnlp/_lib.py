@@ -78,11 +78,6 @@ class RnnStepBwdDir(C.Structure):
     _fields_ = [("cell", RnnCellBwdDir), ("dgh_next", vp), ("w_hh", vp)]
 
 
-class RowsLn(C.Structure):      # slnlp_rows_ln: a LayerNorm in front of a B-row product
-    _fields_ = [("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("eps", f32),
-                ("y", vp), ("ldy", i64), ("y_hi", vp), ("y_lo", vp), ("ldy_p", i64), ("stats", vp)]
-
-
 class LnReduceEntry(C.Structure):
     _fields_ = [("partial", vp), ("dgamma", vp), ("dbeta", vp), ("nblk", i32), ("E", i32)]
 
@@ -99,7 +94,6 @@ SIGNATURES = {
     "slnlp_gemm_wd": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp, i64, vp]),
     "slnlp_gemm_wd_plan": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "slnlp_gemm_rows": (i32, [C.POINTER(GemmArgs), vp]),
-    "slnlp_gemm_rows_ln": (i32, [C.POINTER(GemmArgs), C.POINTER(RowsLn), vp]),
     "slnlp_gemm_rows_bwd": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
     "slnlp_set_rows_tile": (i32, [i32]),
     "slnlp_quant_rows_fp8": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),

@@ -152,17 +152,16 @@ def gemm_planes(Ap, Bp, *, M, N, K, a_kmajor=True, b_kmajor=True, out=None, prec
 
 
 def gemm_rows(Ap, W, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate=None, gate_scale=1.0, gate_mode=0, drop_p=0.0,
-              drop_site=0, rng=None, drop_head_dim=0, resid=None, want_planes=False, ln=None):
+              drop_site=0, rng=None, drop_head_dim=0, resid=None, want_planes=False):
     """C = A W^T for a few rows (the decoder's products): A as k-major planes Ap = (hi, lo), the weight W [N, K] as fp32 (the kernel
     splits it in registers -- the same bits as split_planes(W)): slnlp_gemm_rows."""
     _lib.require_gpu()
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32, device=W.device)
+        out = torch.empty(M, N, dtype=torch.float32, device=Ap[0].device)
     a = GemmArgs()
     a.C, a.ldc, a.M, a.N, a.K = ptr(out), out.stride(0), M, N, K
     a.a_kmajor, a.b_kmajor, a.precision = 1, 1, precision
-    if ln is None:
-        a.A_hi, a.A_lo, a.lda_p = ptr(Ap[0]), ptr(Ap[1]), Ap[0].stride(0)
+    a.A_hi, a.A_lo, a.lda_p = ptr(Ap[0]), ptr(Ap[1]), Ap[0].stride(0)
     a.B, a.ldb = ptr(W), W.stride(0)
     a.bias, a.relu = ptr(bias), int(relu)
     a.gate, a.ldg, a.gate_scale, a.gate_mode = ptr(gate), (gate.stride(0) if gate is not None else 0), gate_scale, gate_mode
@@ -173,16 +172,6 @@ def gemm_rows(Ap, W, *, M, N, K, out=None, precision=3, bias=None, relu=0, gate=
         cp = (torch.zeros(pad64(M), pad64(N), dtype=torch.int16, device=out.device),
               torch.zeros(pad64(M), pad64(N), dtype=torch.int16, device=out.device))
         a.C_hi, a.C_lo, a.ldc_p = ptr(cp[0]), ptr(cp[1]), cp[0].stride(0)
-    if ln is not None:
-        # ln = (x [M, K] fp32, gamma, beta, eps): A = LayerNorm(x), computed by the kernel (slnlp_gemm_rows_ln); Ap is ignored.
-        # -> (out[, planes], (y fp32, (y_hi, y_lo), stats))
-        x, gamma, beta, eps = ln
-        y = torch.empty(M, K, dtype=torch.float32, device=x.device)
-        yp = (torch.zeros(pad64(M), pad64(K), dtype=torch.int16, device=x.device), torch.zeros(pad64(M), pad64(K), dtype=torch.int16, device=x.device))
-        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
-        q = _lib.RowsLn(ptr(x), x.stride(0), ptr(gamma), ptr(beta), eps, ptr(y), y.stride(0), ptr(yp[0]), ptr(yp[1]), yp[0].stride(0), ptr(stats))
-        check(load().slnlp_gemm_rows_ln(C.byref(a), C.byref(q), stream_ptr()), "gemm_rows_ln")
-        return ((out, cp) if want_planes else out), (y, yp, stats)
     check(load().slnlp_gemm_rows(C.byref(a), stream_ptr()), "gemm_rows")
     return (out, cp) if want_planes else out
 

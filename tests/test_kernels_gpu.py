@@ -469,41 +469,6 @@ def test_gemm_rows_tiles_return_the_same_bits(ops):
             assert torch.equal(a, b), f"output {i} differs between workgroup tiles"
 
 
-@pytest.mark.parametrize("M,N,K", [(50, 512, 512), (50, 202, 512), (7, 64, 64), (64, 1024, 512), (33, 48, 256), (50, 200, 320)])
-def test_gemm_rows_with_layernorm_in_front(ops, M, N, K):
-    """slnlp_gemm_rows_ln: y = LayerNorm(x) W^T with the LayerNorm computed by the product's kernel (the decoder's norm1 / norm2 /
-    norm3 / final norm): the stored normalised rows, their planes and (mean, rstd) against slnlp_layernorm_fwd (fp32 rounding: the
-    sums run in another order), the product against fp64, and all of it bit for bit across the workgroup tiles -- a fit in lockstep
-    keeps its bits."""
-    from slnlp._lib import load, check
-    x, W = rnd(M, K, seed=1, scale=2.0).cuda() + 0.3, rnd(N, K, seed=2).cuda()
-    gamma, beta, bias = (1 + 0.1 * rnd(K, seed=3)).cuda(), (0.1 * rnd(K, seed=4)).cuda(), rnd(N, seed=5).cuda()
-    y_ref, stats_ref = ops.layernorm_fwd(x, gamma, beta)
-    res = []
-    try:
-        for tile in (0, 1, 2):
-            check(load().slnlp_set_rows_tile(tile), "set_rows_tile")
-            out, (y, (hi, lo), stats) = ops.gemm_rows(None, W, M=M, N=N, K=K, bias=bias, relu=1, ln=(x, gamma, beta, 1e-5))
-            torch.cuda.synchronize()
-            res.append([t.clone() for t in (out, y, hi, lo, stats)])
-    finally:
-        load().slnlp_set_rows_tile(-1)
-    out, y, hi, lo, stats = res[0]
-    assert rel(y, y_ref) < 2e-6 and rel(stats, stats_ref.view(M, 2)) < 2e-6
-    h2, l2 = ops.split_planes(y)
-    assert torch.equal(hi[:M, :K], h2[:M, :K]) and torch.equal(lo[:M, :K], l2[:M, :K])
-    assert float(hi[M:].abs().max() if M % 64 else 0) == 0                        # the planes' padding rows are not touched
-    xd = x.double().cpu()
-    yd = torch.nn.functional.layer_norm(xd, (K,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
-    assert rel(out, torch.relu(yd @ W.double().cpu().T + bias.double().cpu())) < 1e-4
-    # ... and equal to the two-launch path on the rows it stored (same operand bits in, same product)
-    out2 = ops.gemm_rows((hi, lo), W, M=M, N=N, K=K, bias=bias, relu=1)
-    assert torch.equal(out, out2)
-    for other in res[1:]:
-        for a, b in zip(res[0], other):
-            assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("prec", [3, 1])
 @pytest.mark.parametrize("B,Nout,Kin", [(50, 512, 512), (50, 512, 256), (7, 64, 64), (130, 192, 96), (64, 1024, 512), (50, 128, 200)])
 def test_gemm_rows_bwd_vs_fp64(ops, B, Nout, Kin, prec):
