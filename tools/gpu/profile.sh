@@ -3,7 +3,7 @@
 # sections (default: all): trace traffic traffic_more sq big lockstep cfg5 cfg5p8 rnn
 #   trace     kernel trace of the default bench command -> <tag>_bench_cfg2_kernel_trace_summary.txt, <tag>_bench_cfg2_roofline_kernel.json
 #   traffic   FETCH_SIZE / WRITE_SIZE passes of the eager cfg2 step -> <tag>_pmc_cfg2_step_traffic.json
-#   traffic_more  the same for the cfg5 and cfg3 steps -> <tag>_pmc_cfg5_step_traffic.json, <tag>_pmc_cfg3_step_traffic.json
+#   traffic_more  the same for the other workloads' steps (TRAFFIC_WORKLOADS, default cfg5 cfg3 cfg1 e1024 cfg3gru) -> <tag>_pmc_<workload>_step_traffic.json
 #   sq        SQ counters of the cfg2 dgrad + wgrad group -> <tag>_mfma_util_sq.json, <tag>_pmc_plane_gemm_sq*_raw.txt
 #   big       configs[4] in_proj gradient group: SQ + L2 + HBM counters -> <tag>_pmc_plane_gemm_cfg5_raw.txt, <tag>_pmc_large_launch_traffic.json
 #   lockstep  kernel trace of a 4-fit and a 15-fit lockstep step (cfg2)
@@ -51,6 +51,7 @@ if has big; then
     d=$R/big_$(echo $c | cut -c1-8 | tr ' ' '_')
     rocprofv3 --pmc $c --output-format csv -d $d -- python3 tools/bench_plane_one.py 16384 3072 1024 0 0 3 > $O/bench_plane_big.txt 2> $d.err || tail -3 $d.err
     python3 tools/pmc_summary.py $d gemm_planes >> $O/${TAG}_pmc_plane_gemm_cfg5_raw.txt 2>/dev/null || true
+    python3 tools/pmc_summary.py $d plane_splitk_reduce >> $O/${TAG}_pmc_plane_gemm_cfg5_raw.txt 2>/dev/null || true   # (the weight gradient's K-slices meet there)
   done
   python3 tools/pmc_large_launch.py $O/${TAG}_pmc_plane_gemm_cfg5_raw.txt $O/${TAG}_pmc_large_launch_traffic.json || true
   echo "[prof] big launch done"
@@ -60,12 +61,12 @@ if has lockstep; then
   trace ls15 ${TAG}_lockstep_cfg2_k15_kernel_trace_summary.txt python3 tools/bench_lockstep.py --workload cfg2 --ks 15 --steps 6
 fi
 if has traffic_more; then   # HBM traffic of the configs[4] and configs[2] steps too (their bench records carry roofline.traffic)
-  for w in cfg5 cfg3; do
+  for w in ${TRAFFIC_WORKLOADS:-cfg5 cfg3 cfg1 e1024 cfg3gru}; do
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/fetch_$w -- python3 bench.py --workload $w --steps 3 --warmup 3 --no-cpu-baseline --no-grid --launch eager > /dev/null 2> $R/fetch_$w.err || { tail -5 $R/fetch_$w.err; exit 1; }
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/write_$w -- python3 bench.py --workload $w --steps 3 --warmup 3 --no-cpu-baseline --no-grid --launch eager > /dev/null 2> $R/write_$w.err || { tail -5 $R/write_$w.err; exit 1; }
     python3 tools/pmc_step_traffic.py $R/fetch_$w $R/write_$w $O/${TAG}_pmc_${w}_step_traffic.json > /dev/null
   done
-  echo "[prof] traffic cfg5 / cfg3 done"
+  echo "[prof] traffic of the other workloads done"
 fi
 if has cfg5; then trace c5 ${TAG}_bench_cfg5_kernel_trace_summary.txt python3 bench.py --workload cfg5 --steps 8 --warmup 4 --no-cpu-baseline --no-grid; fi
 if has cfg5p8; then trace c5p8 ${TAG}_bench_cfg5_p8_kernel_trace_summary.txt python3 bench.py --workload cfg5 --precision 8 --steps 8 --warmup 4 --no-cpu-baseline --no-grid; fi

@@ -13,7 +13,7 @@ M, Nout, Kin = 16384, 3072, 1024
 fetch, write = vals.get("FETCH_SIZE", 0.0) * 1024 * 2, vals.get("WRITE_SIZE", 0.0) * 1024
 alg = 4.0 * (M * Nout + M * Kin + Nout * Kin) + 4.0 * (M * Kin + Nout * Kin) + 4.0 * M * Kin
 out = {"kernel": "gemm_planes_kernel<3> dgrad + wgrad of one dY [16384x3072]x[3072x1024] (configs[4] in_proj) as the plans launch it -- slnlp_gemm_wd: a launch each, "
-                 "256x256 tiles, wgrad split-K 5 (tools/bench_plane_one.py 16384 3072 1024 0 0 3); counters summed over the pair's launches",
+                 "256x256 tiles, wgrad split-K 5 with its slices added by plane_splitk_reduce_kernel (tools/bench_plane_one.py 16384 3072 1024 0 0 3); counters summed over the pair's THREE launches",
        "fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write, "algorithmic_bytes": alg, "ratio": round((fetch + write) / alg, 2),
        "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE exact; KiB -> bytes; separate --pmc passes"}
 if "TCC_HIT_sum" in vals:
