@@ -224,7 +224,7 @@ __device__ __forceinline__ void xmem_dmem_body(const float* __restrict__ probs, 
             a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (accumulate && r < DMEM_ROWS && s_ < S) a[i] = *reinterpret_cast<const float4*>(dmem + ((long)s_ * B + b) * E + e);
         }
-#pragma unroll 2
+#pragma unroll 8                                         // (all eight heads' vectors requested together: 16 loads in flight, not 4 x 4 round trips)
         for (int h = 0; h < H; ++h) {
             const long bh = (long)b * H + h;
             const float4 g = *reinterpret_cast<const float4*>(dmbar + bh * E + e), k = *reinterpret_cast<const float4*>(qk + bh * E + e);
@@ -266,31 +266,37 @@ SLNLP_ZKERNEL(xmem_colsum_kernel, 256, xmem_colsum_body)
 // results are bit-identical, HP is a scheduling choice (xmem_heads_per_wg).
 __device__ __forceinline__ float dot4(const float4& q4, const float4& m4) { return q4.x * m4.x + q4.y * m4.y + q4.z * m4.z + q4.w * m4.w; }
 
-// dots of the HP LDS vectors v[hp][E] (stride vs) with memory rows s = wave, wave + 4, ... : four rows per trip, each row chunk
-// loaded once for all HP heads
+// dots of the HP LDS vectors v[hp][E] (stride vs) with memory rows s = wave, wave + 4, ... : RU rows per trip, each row chunk loaded
+// once for all HP heads.  The column loop is the OUTER one and a trip's RU row chunks are requested together: with the rows outside
+// (rounds 2-4) every chunk was one load followed by its own s_waitcnt -- 24 dependent round trips per wave for a 48-frame sequence,
+// most of the kernel's 13.9 us (ISA of xmem_fwd_h2_kernel).  Per (row, head) the sum still runs over the columns in increasing order
+// with the same dot4 expression: same bits.
 template <int HP, class F>
 __device__ __forceinline__ void row_dots_multi(const float* __restrict__ v, int vs, const float* __restrict__ mem, int B, int b, int S, int E,
                                                int lane, int wave, F&& put) {
-    for (int s0 = wave; s0 < S; s0 += 16) {
-        float a[4][HP];
+    constexpr int RU = 12;
+    for (int s0 = wave; s0 < S; s0 += 4 * RU) {
+        float a[RU][HP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < RU; ++u)
 #pragma unroll
             for (int hp = 0; hp < HP; ++hp) a[u][hp] = 0.f;
+        for (int e = lane * 4; e < E; e += 256) {
+            float4 m4[RU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = s0 + 4 * u;
-            if (s < S) {
-                const float* mr = mem + ((long)s * B + b) * E;
-                for (int e = lane * 4; e < E; e += 256) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(mr + e);
+            for (int u = 0; u < RU; ++u) {
+                const int s = s0 + 4 * u < S ? s0 + 4 * u : s0;             // (a row past the end: a repeat of the first, never reported)
+                m4[u] = *reinterpret_cast<const float4*>(mem + ((long)s * B + b) * E + e);
+            }
 #pragma unroll
-                    for (int hp = 0; hp < HP; ++hp) a[u][hp] += dot4(*reinterpret_cast<const float4*>(v + (long)hp * vs + e), m4);
-                }
+            for (int hp = 0; hp < HP; ++hp) {
+                const float4 q4 = *reinterpret_cast<const float4*>(v + (long)hp * vs + e);
+#pragma unroll
+                for (int u = 0; u < RU; ++u) a[u][hp] += dot4(q4, m4[u]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < RU; ++u)
 #pragma unroll
             for (int hp = 0; hp < HP; ++hp) {
                 const float r = wave_sum(a[u][hp]);
@@ -349,7 +355,7 @@ __device__ __forceinline__ void xmem_fwd_multi_body(const float* __restrict__ qk
         float4 a[HP];
 #pragma unroll
         for (int hp = 0; hp < HP; ++hp) a[hp] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
+#pragma unroll 16
         for (int s_ = 0; s_ < S; ++s_) {
             const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s_ * B + b) * E + e);
 #pragma unroll
@@ -434,7 +440,7 @@ __device__ __forceinline__ void xmem_bwd_multi_body(const float* __restrict__ me
         float4 a[HP];
 #pragma unroll
         for (int hp = 0; hp < HP; ++hp) a[hp] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
+#pragma unroll 16
         for (int s_ = 0; s_ < S; ++s_) {
             const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s_ * B + b) * E + e);
 #pragma unroll
