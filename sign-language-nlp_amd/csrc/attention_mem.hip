@@ -274,7 +274,7 @@ __device__ __forceinline__ float dot4(const float4& q4, const float4& m4) { retu
 template <int HP, class F>
 __device__ __forceinline__ void row_dots_multi(const float* __restrict__ v, int vs, const float* __restrict__ mem, int B, int b, int S, int E,
                                                int lane, int wave, F&& put) {
-    constexpr int RU = 12;
+    constexpr int RU = 6;
     for (int s0 = wave; s0 < S; s0 += 4 * RU) {
         float a[RU][HP];
 #pragma unroll
@@ -355,7 +355,7 @@ __device__ __forceinline__ void xmem_fwd_multi_body(const float* __restrict__ qk
         float4 a[HP];
 #pragma unroll
         for (int hp = 0; hp < HP; ++hp) a[hp] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
+#pragma unroll 8
         for (int s_ = 0; s_ < S; ++s_) {
             const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s_ * B + b) * E + e);
 #pragma unroll
@@ -440,7 +440,7 @@ __device__ __forceinline__ void xmem_bwd_multi_body(const float* __restrict__ me
         float4 a[HP];
 #pragma unroll
         for (int hp = 0; hp < HP; ++hp) a[hp] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
+#pragma unroll 8
         for (int s_ = 0; s_ < S; ++s_) {
             const float4 m4 = *reinterpret_cast<const float4*>(mem + ((long)s_ * B + b) * E + e);
 #pragma unroll
