@@ -90,15 +90,27 @@ __device__ __forceinline__ void rnn_cell_bwd_body(slnlp_rnn_cell_bwd_dir d0, sln
     const long n = (long)B * Hd;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
         const int b = (int)(idx / Hd), j = (int)(idx % Hd);
-        const bool valid = lengths ? (d.t < lengths[b]) : true;
+        // ---- every operand is requested before the first one is used: ONE memory round trip per element.  (Rounds 1-4 read the length,
+        // branched on it, then read the gate activations, then the saved states: three to four dependent round trips in a kernel that
+        // runs 192 times per configs[2] step on the backward chain.)  All of them exist for masked timesteps too.
+        const long len = lengths ? lengths[b] : 0;
         float dh = d.dh_state[idx];
-        for (int e0 = 0; e0 < d.n_extra; e0 += 8) {        // fixed order; eight partial products' loads in flight (15 of them with 128-k slices)
-            float x[8];
+        float x[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = e0 + e < d.n_extra ? d.dh_extra[(e0 + e) * d.extra_stride + idx] : 0.f;
+        for (int e0 = 0; e0 < 2; ++e0)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dh += x[e];
+            for (int e = 0; e < 8; ++e) x[e0][e] = 8 * e0 + e < d.n_extra ? d.dh_extra[(8 * e0 + e) * d.extra_stride + idx] : 0.f;
+        float g_out = d.dout ? d.dout[(long)b * ld_dout + j] : 0.f;
+        const float* a = d.acts + (long)b * G * Hd;
+        float a0 = a[j], a1 = a[Hd + j], a2 = a[2 * Hd + j], a3 = LSTM ? a[3 * Hd + j] : 0.f;
+        float s0 = LSTM ? d.cprev_save[idx] : d.hprev_save[idx], s1 = LSTM ? d.dc_state[idx] : d.hn_save[idx];
+        asm volatile("" : "+v"(dh), "+v"(g_out), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(s0), "+v"(s1));    // (keeps the loads above the branches)
+        const bool valid = lengths ? (d.t < len) : true;
+        for (int e0 = 0; e0 < 2 && 8 * e0 < d.n_extra; ++e0) {        // fixed order (the K-slices of the recurrent data gradient: 3, or up to 15)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dh += x[e0][e];
         }
+        for (int e = 16; e < d.n_extra; ++e) dh += d.dh_extra[e * d.extra_stride + idx];
         float* gx = d.dgx + (long)b * G * Hd;
         float* gh = LSTM ? gx : d.dgh + (long)b * G * Hd;
         if (!valid) {
@@ -111,18 +123,17 @@ __device__ __forceinline__ void rnn_cell_bwd_body(slnlp_rnn_cell_bwd_dir d0, sln
             continue;
         }
         if (d.dout) {
-            float g = d.dout[(long)b * ld_dout + j];
+            float g = g_out;
             if (drop_p > 0.f)
                 g = dropout_keep(rng, drop_site, (unsigned)(d.out_row0 + b), (unsigned)(d.out_col0 + j), drop_thr)
                         ? g / (1.f - drop_p) : 0.f;
             dh += g;
         }
-        const float* a = d.acts + (long)b * G * Hd;
         if (LSTM) {
-            const float gi = a[j], gf = a[Hd + j], gg = a[2 * Hd + j], go = a[3 * Hd + j];
-            const float cprev = d.cprev_save[idx];
+            const float gi = a0, gf = a1, gg = a2, go = a3;
+            const float cprev = s0;
             const float tc = tanhf(gf * cprev + gi * gg);
-            const float dc = d.dc_state[idx] + dh * go * (1.f - tc * tc);
+            const float dc = s1 + dh * go * (1.f - tc * tc);
             gx[j] = dc * gg * gi * (1.f - gi);
             gx[Hd + j] = dc * cprev * gf * (1.f - gf);
             gx[2 * Hd + j] = dc * gi * (1.f - gg * gg);
@@ -130,8 +141,8 @@ __device__ __forceinline__ void rnn_cell_bwd_body(slnlp_rnn_cell_bwd_dir d0, sln
             d.dc_state[idx] = dc * gf;
             d.carry[idx] = 0.f;
         } else {
-            const float r = a[j], z = a[Hd + j], nn = a[2 * Hd + j];
-            const float hprev = d.hprev_save[idx], hn = d.hn_save[idx];
+            const float r = a0, z = a1, nn = a2;
+            const float hprev = s0, hn = s1;
             const float dn_pre = dh * (1.f - z) * (1.f - nn * nn);
             const float dr_pre = dn_pre * hn * r * (1.f - r);
             const float dz_pre = dh * (hprev - nn) * z * (1.f - z);
