@@ -531,12 +531,6 @@ struct slnlp_tf_plan {
         a.resid = resid; a.ldr = ldy;
         if (outp) { a.C_hi = outp->hi; a.C_lo = outp->lo; a.ldc_p = N; }
         a.precision = prec3();
-        // (experiment, SLNLP_FWD_SPLITK=n: a forward launch of few 64 x 64 tiles cut into n K-slices -- fewer bytes on the busiest CU)
-        static const int fsk = [] { const char* e = getenv("SLNLP_FWD_SPLITK"); return e ? atoi(e) : 1; }();
-        if (fsk > 1 && K >= 512 && (long)((M + 63) / 64) * ((N + 63) / 64) < 400) {
-            const int split = fsk;
-            if (gemm_group_scratch_bytes(&a, &split, 1) <= w.gscr_bytes) return gemm_planes_group(&a, &split, 1, w.gscr[0], w.gscr_bytes, st);
-        }
         return gemm(a, st);
     }
     // the same product for the decoder's B rows: x as planes, W as fp32 (split in registers), both register-direct (gemm_rows.hip)
